@@ -1,0 +1,180 @@
+"""Pin the CPU oracle to golden vectors produced by the imported reference
+(tests/golden/make_golden.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mimo_oracle as O
+from tests.helpers import cfg_from_meta, load_npz, rel_err, state_from
+
+TOL = 2e-5  # oracle and reference run the same torch leaf ops; only op order differs
+
+
+def _replay(fx, steps):
+    meta = fx["meta"]
+    cfg = cfg_from_meta(meta)
+    S = cfg.num_subnetworks
+    ts = O.TrainState(cfg=cfg, st=state_from(fx, "init/"), loss_kind=str(fx["loss_kind"]), lr=float(fx["lr"]),
+                      weight_decay=float(fx["wd"]),
+                      loss_buffer=O.LossBuffer(S, float(fx["temperature"]), 10))
+    results = []
+    for it in range(steps):
+        mask = torch.from_numpy(fx[f"s{it}/mask"]) if f"s{it}/mask" in fx else None
+        r = O.train_step(ts, torch.from_numpy(fx[f"s{it}/image"]), torch.from_numpy(fx[f"s{it}/label"]), mask,
+                         torch.from_numpy(fx[f"s{it}/perms"]), want_input_grad=(it == 0))
+        results.append(r)
+    return ts, results
+
+
+@pytest.mark.parametrize("name", ["cfg1_step.npz", "mini_s2_step.npz", "mini_gauss_step.npz"])
+def test_train_steps_match_reference(name):
+    fx = load_npz(name)
+    steps = int(fx["meta"][8])
+    ts, results = _replay(fx, steps)
+    r0 = results[0]
+    assert rel_err(r0["out"], fx["s0/out"]) < TOL
+    assert rel_err(r0["dx"], fx["s0/dx"]) < 1e-4
+    for it, r in enumerate(results):
+        np.testing.assert_allclose(r["loss"].numpy(), fx[f"s{it}/loss"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(r["weights"].numpy(), fx[f"s{it}/weights"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r["total"].numpy(), fx[f"s{it}/total"], rtol=1e-4, atol=1e-6)
+    worst = 0.0
+    for k, g in r0["grads"].items():
+        ref = fx["s0/grad/" + k]
+        # conv biases in front of BatchNorm have a mathematically-zero gradient: compare on the
+        # scale of the layer's weight gradient instead of their own (pure rounding noise).
+        scale_ref = ref
+        if k.endswith((".0.bias", ".3.bias")) and "double_conv" in k:
+            scale_ref = fx["s0/grad/" + k[:-4] + "weight"]
+        e = float(np.abs(g.numpy() - ref).max()) / max(float(np.abs(scale_ref).max()), 1e-30)
+        worst = max(worst, e)
+        assert e < 5e-4, (k, e)
+    for k, v in ts.st.items():
+        ref = fx["final/" + k]
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref)
+        elif k.endswith((".0.bias", ".3.bias")) and "double_conv" in k:
+            # Zero-gradient parameters: Adam turns their rounding-noise gradient into +-lr steps
+            # of arbitrary sign, so two correct implementations differ by up to 2*steps*lr.
+            assert float(np.abs(v.numpy() - ref).max()) <= steps * float(fx["lr"]) * 2.02, k
+        elif k.endswith("running_mean"):
+            # contains the (noise-driven) conv bias above
+            assert float(np.abs(v.numpy() - ref).max()) <= steps * float(fx["lr"]) * 2.02 + 1e-5, k
+        elif O.is_buffer(k):
+            assert rel_err(v, ref) < 1e-4, k
+        else:
+            # Adam moves a parameter by at most ~lr per step: judge the error against that budget
+            # (elements whose gradient is rounding noise behave like the biases above, hence max vs rms).
+            d = np.abs(v.numpy() - ref)
+            budget = steps * float(fx["lr"])
+            assert float(d.max()) <= 0.2 * budget + 1e-5 * float(np.abs(ref).max()), (k, float(d.max()))
+            assert float(np.sqrt((d ** 2).mean())) <= 0.01 * budget, (k, float(np.sqrt((d ** 2).mean())))
+    np.testing.assert_allclose(ts.loss_buffer.buffer.numpy(), fx["final/loss_buffer"], rtol=1e-4, atol=1e-6)
+
+
+def test_bn_buffers_after_first_step():
+    fx = load_npz("mini_s2_step.npz")
+    ts, _ = _replay(fx, 1)
+    for k, v in ts.st.items():
+        if "running" in k:
+            assert rel_err(v, fx["s0/after/" + k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("tag", ["50x70", "100x100", "128x160"])
+def test_odd_sizes(tag):
+    fx = load_npz("odd_sizes.npz")
+    cfg = O.NetConfig(3, 2, 2, 4)
+    st = state_from(fx, "init/")
+    x = torch.from_numpy(fx[tag + "/x"])
+    with torch.no_grad():
+        out_train = O.mimo_unet_forward(cfg, st, x, training=True)
+        out_eval = O.mimo_unet_forward(cfg, st, x, training=False)
+    assert rel_err(out_train, fx[tag + "/out_train"]) < TOL
+    assert rel_err(out_eval, fx[tag + "/out_eval"]) < TOL
+    for k in st:
+        if "running" in k:
+            assert rel_err(st[k], fx[f"{tag}/after/{k}"]) < 1e-5
+
+
+def test_losses_and_helpers():
+    fx = load_npz("losses.npz")
+    mu, y, ls, mask = (torch.from_numpy(fx[k]) for k in ("mu", "y", "ls", "mask"))
+    for kind, name in (("laplace", "laplace_nll"), ("gaussian", "gaussian_nll")):
+        a = mu.clone().requires_grad_(True)
+        b = ls.clone().requires_grad_(True)
+        raw = O.loss_forward(name, a, b, y, mask=mask, reduce_mean=False)
+        raw.sum().backward()
+        np.testing.assert_allclose(raw.detach().numpy(), fx[kind + "/raw"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(a.grad.numpy(), fx[kind + "/dmu"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(b.grad.numpy(), fx[kind + "/dls"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(O.loss_forward(name, mu, ls, y).numpy(), fx[kind + "/mean"], rtol=1e-6)
+        std = O.loss_std(name, ls)
+        np.testing.assert_allclose(std.numpy(), fx[kind + "/std"], rtol=1e-6)
+        np.testing.assert_allclose(O.calculate_dist_param(name, std).numpy(), fx[kind + "/dist_param"], rtol=1e-6)
+        np.testing.assert_allclose(O.calculate_dist_param(name, std, log=True).numpy(), fx[kind + "/dist_param_log"],
+                                   rtol=1e-5, atol=1e-6)
+        for S in (1, 2, 16):
+            p1, p2 = torch.from_numpy(fx[f"{kind}/unc{S}/p1"]), torch.from_numpy(fx[f"{kind}/unc{S}/p2"])
+            m, al, ep = O.compute_uncertainties(name, p1, p2)
+            np.testing.assert_allclose(m.numpy(), fx[f"{kind}/unc{S}/mean"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(al.numpy(), fx[f"{kind}/unc{S}/alea"], rtol=1e-6)
+            np.testing.assert_allclose(ep.numpy(), fx[f"{kind}/unc{S}/epi"], rtol=1e-5, atol=1e-7)
+    # closed-form Laplace gradient (used by the fused head+loss kernel) == autograd of the reference
+    gm, gl = O.laplace_nll_grads(mu, ls, y)
+    np.testing.assert_allclose((gm * mask).numpy(), fx["laplace/dmu"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose((gl * mask).numpy(), fx["laplace/dls"], rtol=1e-5, atol=1e-6)
+
+
+def test_loss_buffer_sequence():
+    fx = load_npz("losses.npz")
+    lb = O.LossBuffer(3, 0.3, 10)
+    for i, row in enumerate(torch.from_numpy(fx["lossbuf/seq"])):
+        np.testing.assert_allclose(lb.get_weights().numpy(), fx["lossbuf/weights"][i], rtol=1e-6)
+        lb.add(row)
+    np.testing.assert_allclose(lb.buffer.numpy(), fx["lossbuf/final"])
+    lb0 = O.LossBuffer(2, 1.0, 0)
+    lb0.add(torch.ones(2))
+    np.testing.assert_allclose(lb0.get_weights().numpy(), fx["lossbuf/size0_weights"])
+    assert torch.equal(O.LossBuffer(4, 0.3, 10).get_weights(), torch.ones(4))  # first step: exactly 1
+
+
+def test_mc_dropout_ensemble():
+    fx = load_npz("mc_dropout.npz")
+    Ci, Co, S, f, N, H, W, passes = (int(v) for v in fx["meta"])
+    p = float(fx["p"])
+    cfg = O.NetConfig(Ci, Co, S, f, encoder_dropout_rate=p, core_dropout_rate=p, decoder_dropout_rate=p)
+    st = state_from(fx, "state/")
+    prefixes = [s[0] for s in O.double_conv_specs(cfg)]
+    pass_masks = []
+    for i in range(passes):
+        assert int(fx[f"pass{i}/nmask"]) == len(prefixes)
+        pass_masks.append({pre: torch.from_numpy(fx[f"pass{i}/mask{j}"]) for j, pre in enumerate(prefixes)})
+    x = torch.from_numpy(fx["x"])
+    p1, p2 = O.ensemble_forward(cfg, st, x, monte_carlo_steps=passes, pass_masks=pass_masks, raw=True)
+    assert rel_err(p1, fx["p1"]) < TOL and rel_err(p2, fx["p2"]) < TOL
+    mean, al, ep = O.ensemble_forward(cfg, st, x, monte_carlo_steps=passes, pass_masks=pass_masks)
+    assert rel_err(mean, fx["mean"]) < TOL and rel_err(al, fx["alea"]) < 1e-4 and rel_err(ep, fx["epi"]) < 1e-3
+
+
+def test_param_inventory_matches_reference_state_dict():
+    fx = load_npz("cfg1_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    shapes = O.param_shapes(cfg)
+    ref = {k[len("init/"):]: v.shape for k, v in fx.items() if k.startswith("init/")}
+    assert set(shapes) == set(ref)
+    for k in shapes:
+        assert tuple(shapes[k]) == tuple(ref[k]), k
+    n = sum(int(np.prod(s)) for k, s in shapes.items() if not O.is_buffer(k))
+    assert n == 271458  # BASELINE.md model size cfg1
+
+
+def test_draw_perms_replays_apply_input_transform():
+    fx = load_npz("mini_s2_step.npz")
+    seed = 1000 + 2
+    perms = O.draw_perms(3, 2, generator=torch.Generator().manual_seed(seed))
+    # the generator-based draw uses the same algorithm as the global RNG the reference uses
+    torch.manual_seed(seed)
+    main = torch.randperm(3)
+    ref = torch.stack([main[torch.randperm(3)] for _ in range(2)])
+    assert torch.equal(perms, ref)
+    assert np.array_equal(ref.numpy(), fx["s0/perms"])
