@@ -1,0 +1,136 @@
+/*
+ * mimo_hip.h — C ABI of libmimo_hip.so: the MI355X (gfx950) execution engine for the
+ * MIMO U-Net forward + backward + loss + optimiser hot path.
+ *
+ * The reference (antonbaumann/MIMO-Unet @ 2024_10_08) has no FFI seam: the path is plain
+ * nn.Module composition.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference root).  All pointers are raw device
+ * pointers unless marked "host"; no torch types cross this boundary.  Every function
+ * returns 0 on success or a negative mimo_status; mimo_last_error() gives the message
+ * (thread-local).  Calls are asynchronous on the given hipStream_t, never synchronise,
+ * never allocate after mimo_plan_create(), and are not re-entrant on one plan.
+ */
+#ifndef MIMO_HIP_H
+#define MIMO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mimo_plan mimo_plan;
+typedef void* mimo_stream; /* hipStream_t */
+
+enum mimo_status {
+  MIMO_OK = 0,
+  MIMO_ERR_INVALID = -1, /* bad argument / unsupported configuration */
+  MIMO_ERR_HIP = -2,     /* a HIP runtime call failed */
+  MIMO_ERR_STATE = -3    /* call order violated (e.g. backward before forward) */
+};
+
+enum mimo_loss_kind { MIMO_LOSS_LAPLACE_NLL = 0, MIMO_LOSS_GAUSSIAN_NLL = 1 };
+
+/* Constructor arguments of mimo.models.mimo_components.model.MimoUNet (model.py:31-44) plus
+ * the batch geometry the plan is specialised for.  bilinear=True/use_pooling_indices=False are
+ * hard-wired exactly as mimo/models/mimo_unet.py:73-74 hard-wires them. */
+typedef struct mimo_config {
+  int32_t in_channels;
+  int32_t out_channels; /* total head width = 2 * targets (mimo_unet.py:110-111) */
+  int32_t num_subnetworks;
+  int32_t filter_base_count;
+  int32_t batch, height, width;
+  float encoder_dropout_rate, core_dropout_rate, decoder_dropout_rate; /* Dropout2d, components.py:29 */
+  float bn_eps, bn_momentum; /* 1e-5, 0.1: nn.BatchNorm2d defaults (components.py:24,27) */
+  int32_t loss_kind;         /* mimo_loss_kind; mimo/losses.py:39,124 */
+  float eps_min, eps_max;    /* clamp of the scale/variance, losses.py:42-45,127-130: 1e-5, 1e3 */
+  int32_t device;            /* HIP device ordinal */
+} mimo_config;
+
+const char* mimo_last_error(void);
+int mimo_version(void);
+
+/* ---- plan life cycle: replaces MimoUNet.__init__ (model.py:31-92) ---------------------- */
+int mimo_plan_create(const mimo_config* cfg, mimo_plan** out);
+void mimo_plan_destroy(mimo_plan* plan);
+size_t mimo_plan_workspace_bytes(const mimo_plan* plan);
+
+/* Parameter inventory in canonical order, with the reference's state_dict names and OIHW
+ * shapes (probe of MimoUNet.state_dict(); SURVEY §5 checkpoint row).  kind: 0 = trainable
+ * parameter (offset into the flat parameter / gradient buffers), 1 = BatchNorm running
+ * buffer (offset into the flat buffer array).  Offsets are in floats. */
+int mimo_plan_num_tensors(const mimo_plan* plan);
+int mimo_plan_tensor_info(const mimo_plan* plan, int index, char* name, int name_cap, int64_t shape[4],
+                          int* ndim, int* kind, int64_t* offset);
+int64_t mimo_plan_param_floats(const mimo_plan* plan);
+int64_t mimo_plan_buffer_floats(const mimo_plan* plan);
+
+/* Bind the torch-owned flat storage.  grads may be NULL for inference-only plans. */
+int mimo_plan_bind(mimo_plan* plan, float* params, float* grads, float* bn_buffers);
+
+/* ---- forward: replaces MimoUNet.forward (model.py:94-117) ------------------------------
+ * x is NCHW-strided fp32: element (n,s,c,y,x) at x[n*stride_n + s*stride_s + c*H*W + y*W + x]
+ * (stride_s = 0 gives repeat_subnetworks, utils.py:51-61).  perm (int64 [S][N], device) is
+ * the gather of apply_input_transform (utils.py:38-41) fused into the load; NULL = identity.
+ * out is [N,S,Co,H,W] contiguous.  training: BatchNorm uses batch statistics and updates
+ * the running buffers.  drop_masks: host array with one device pointer per DoubleConv (forward
+ * order, see mimo_plan_num_double_convs), each [N][Cout] multipliers (0 or 1/(1-p)) or NULL for
+ * "no dropout at this site" — Dropout2d (components.py:29) incl. MC-dropout (ensemble.py:54-66). */
+typedef struct mimo_forward_args {
+  const float* x;
+  int64_t stride_n, stride_s;
+  const int64_t* perm;
+  int32_t training;
+  const float* const* drop_masks; /* host array [num_double_convs] or NULL */
+  float* out;
+} mimo_forward_args;
+int mimo_plan_num_double_convs(const mimo_plan* plan);
+int mimo_plan_double_conv_channels(const mimo_plan* plan, int index); /* Cout of DoubleConv #index */
+int mimo_forward(mimo_plan* plan, const mimo_forward_args* args, mimo_stream stream);
+
+/* ---- loss: replaces UncertaintyLoss.forward(reduce_mean=False).mean((0,2,3,4))
+ * (losses.py:132-164, mimo_unet.py:241-242) on the logits of the last mimo_forward.
+ * label [N,Ct,H,W], mask [N,1,H,W] or NULL, both gathered through perm like x.
+ * loss_out: device [S]. */
+int mimo_loss_forward(mimo_plan* plan, const float* label, const float* mask, const int64_t* perm,
+                      float* loss_out, mimo_stream stream);
+
+/* ---- backward: replaces autograd through MimoUNet (+ the loss when dloss != NULL) --------
+ * dout  [N,S,Co,H,W] upstream gradient of the logits, or NULL.
+ * dloss device [S]: upstream gradient of the per-subnetwork losses returned by
+ *       mimo_loss_forward (e.g. weights/S, mimo_unet.py:138), or NULL.  The closed-form
+ *       Laplace/Gaussian gradient is evaluated inside the head kernel.
+ * dx    [N,S,Ci,H,W] gradient w.r.t. the input (FGSM, scripts/test/test_nyuv2_depth.py:41-55)
+ *       or NULL to skip the first-layer dgrad.  Requires perm == NULL in the forward.
+ * Parameter gradients are written (not accumulated) into the bound flat grads buffer. */
+int mimo_backward(mimo_plan* plan, const float* dout, const float* dloss, float* dx, mimo_stream stream);
+
+/* ---- optimiser: replaces torch.optim.Adam.step (mimo_unet.py:186-190; L2-in-grad) ------ */
+int mimo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                   float grad_scale, mimo_stream stream);
+
+/* ---- uncertainties: replaces compute_uncertainties (utils.py:76-101) --------------------
+ * p1, p2 [N,S,C,HW] contiguous -> mean, aleatoric_var, epistemic_var [N,C,HW]. */
+int mimo_uncertainties(const float* p1, const float* p2, int32_t n, int32_t s, int32_t c, int64_t hw,
+                       int32_t loss_kind, float* mean, float* aleatoric, float* epistemic, mimo_stream stream);
+
+/* ---- single-operator entry points (NHWC, channel-padded) used by the parity tests -------
+ * They run the same kernels the plan runs.  x [N,H,W,cin_p], w OIHW [cout][cin][3][3]. */
+int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, float* z, double* stats,
+                            int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cin_p, int32_t cout,
+                            int32_t cout_p, mimo_stream stream);
+int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n, int32_t h, int32_t wd,
+                          int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p, mimo_stream stream);
+int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbias, int32_t n, int32_t h,
+                          int32_t wd, int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p,
+                          mimo_stream stream);
+int mimo_op_maxpool2x2(const float* x, float* y, int32_t n, int32_t h, int32_t w, int32_t c_p, mimo_stream stream);
+int mimo_op_upsample_cat(const float* skip, const float* low, float* out, int32_t n, int32_t hs, int32_t ws,
+                         int32_t cs_p, int32_t hl, int32_t wl, int32_t cl_p, mimo_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIMO_HIP_H */

@@ -1,0 +1,77 @@
+// Shared host/device helpers of libmimo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mimo_hip.h"
+
+namespace mimo {
+
+void set_error(const char* fmt, ...);
+
+#define MIMO_HIP_CHECK(expr)                                                                          \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      ::mimo::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);   \
+      return MIMO_ERR_HIP;                                                                            \
+    }                                                                                                 \
+  } while (0)
+#define MIMO_KERNEL_CHECK() MIMO_HIP_CHECK(hipGetLastError())
+#define MIMO_TRY(expr)            \
+  do {                            \
+    int rc_ = (expr);             \
+    if (rc_ != MIMO_OK) return rc_; \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Channel padding of every NHWC activation tensor (floats per pixel).
+static inline int pad_channels(int c) { return round_up(c, 8); }
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------ conv3x3 (conv3x3.hip)
+// "forward-type" 3x3 correlation on the f32 MFMA: y[n,oy,ox,co] = bias[co] +
+//   sum_{kh,kw,ci} w[kh,kw][co][ci] * X(n, oy+kh-off, ox+kw-off, ci)
+// off == 1: Ho==Hi, X is reflect-padded (forward conv, components.py:23,26)
+// off == 2: Ho==Hi+2, X is zero outside the image (transposed conv producing the gradient on
+//           the reflect-PADDED domain; consumers fold the border back, see fold_* in elementwise.hip)
+struct ConvLaunch {
+  const float* x;
+  float* y;
+  const float* w;     // packed [9][cout_pad][cin_p]
+  const float* bias;  // [cout_pad] or nullptr
+  float* stats;       // per-block partial sums [blocks][2][cout_pad] or nullptr
+  int N, Hi, Wi, ldx, cin_p;
+  int Ho, Wo, ldy, cout_pad, cout_store;
+  int off;
+};
+// returns number of partial-stat rows (spatial blocks) through *rows when stats != nullptr
+int conv3x3_launch(const ConvLaunch& a, int* rows, hipStream_t stream);
+int conv3x3_pick_nfrag(int cout);            // fragments (of 16 output channels) per workgroup
+int conv3x3_cout_pad(int cout);              // packed weight rows for that choice
+int conv3x3_stat_rows(int N, int Ho, int Wo);  // spatial workgroups == partial-stat rows
+
+struct WgradLaunch {
+  const float* x;   // [N,H,W,ldx] activations feeding the conv (reflect-padded on the fly)
+  const float* dz;  // [N,H,W,lddz]
+  float* partial;   // [splits][9][cin_pad][cout_pad]
+  int N, H, W, ldx, lddz;
+  int cin_p, cout_p;      // valid channel extents in x / dz (multiples of 4)
+  int cin_pad, cout_pad;  // multiples of 32
+  int splits;
+};
+int wgrad_launch(const WgradLaunch& a, hipStream_t stream);
+int wgrad_pick_splits(int N, int H, int W, int cin_pad, int cout_pad);
+// dW[co][ci][kh][kw] (torch OIHW) = sum over splits of partial[..][tap][cin_map^-1(ci)][co]
+int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map,
+                        int cin_p, int cin, int cout, float* dw, hipStream_t stream);
+
+// weight packing: torch OIHW -> [9][rows_pad][cols] (see conv3x3.hip)
+int pack_weights_launch(const float* w, float* dst, int cout, int cin, int rows_pad, int cols,
+                        const int* row_map, const int* col_map, int transposed, hipStream_t stream);
+
+}  // namespace mimo

@@ -1,0 +1,469 @@
+// 3x3 convolution kernels for gfx950 (MI355X): forward / data-gradient as an LDS-tiled
+// implicit GEMM on the f32-input MFMA (v_mfma_f32_16x16x4_f32, exact fp32 fma chain), and the
+// weight gradient as a pixel-reduction GEMM on the same instruction.
+//
+// Replaces (reference, relative to /root/reference):
+//   nn.Conv2d(k=3, padding=1, padding_mode="reflect") forward + autograd
+//   mimo/models/mimo_components/components.py:23,26
+//
+// Layout: activations NHWC with the channel count padded to a multiple of 8 (zero-filled).
+// Implicit GEMM: M = output pixels of a TR x TC tile (linearised, 16 per MFMA fragment),
+// N = output channels (16 per fragment), K = 9 taps x input channels (4 per MFMA).
+#include "common.h"
+
+namespace mimo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxTilePix = 360;  // (TR+2)*(TC+2) upper bound held in LDS
+
+// ---------------------------------------------------------------------------------------
+// tile geometry (host)
+// ---------------------------------------------------------------------------------------
+static void pick_tile(int Ho, int Wo, int* TR, int* TC) {
+  double best_eff = -1.0;
+  int best_tr = 1, best_tc = 4, best_pix = 1 << 30;
+  for (int k = 1; k <= Wo; ++k) {
+    int tc = ceil_div(Wo, k);
+    if (tc > 254) continue;
+    int tr = 256 / tc;
+    if (tr > Ho) tr = Ho;
+    while (tr > 1 && (tr + 2) * (tc + 2) > kMaxTilePix) --tr;
+    if (tr < 1 || (tr + 2) * (tc + 2) > kMaxTilePix) continue;
+    double eff = double(Ho) * Wo / (double(ceil_div(Ho, tr)) * ceil_div(Wo, tc) * 256.0);
+    int pix = (tr + 2) * (tc + 2);
+    if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && pix < best_pix)) {
+      best_eff = eff;
+      best_tr = tr;
+      best_tc = tc;
+      best_pix = pix;
+    }
+    if (tc <= 4) break;
+  }
+  *TR = best_tr;
+  *TC = best_tc;
+}
+
+int conv3x3_stat_rows(int N, int Ho, int Wo) {
+  int TR, TC;
+  pick_tile(Ho, Wo, &TR, &TC);
+  return N * ceil_div(Ho, TR) * ceil_div(Wo, TC);
+}
+
+int conv3x3_pick_nfrag(int cout) {
+  int nfr = ceil_div(cout, 16);
+  if (nfr <= 1) return 1;
+  int best = 2, best_cost = 1 << 30;
+  for (int nf = 4; nf >= 2; --nf) {
+    int cost = round_up(nfr, nf);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = nf;
+    }
+  }
+  return best;
+}
+
+int conv3x3_cout_pad(int cout) { return round_up(ceil_div(cout, 16), conv3x3_pick_nfrag(cout)) * 16; }
+
+// ---------------------------------------------------------------------------------------
+// forward-type kernel
+// ---------------------------------------------------------------------------------------
+template <int NFRAG, int CK>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX) {
+  constexpr int NB = NFRAG * 16;
+  constexpr int XS = CK + 1;  // odd LDS pitch: conflict-free b32 fragment reads
+  constexpr int Q = CK / 4;
+  __shared__ float xs[kMaxTilePix * XS];
+  __shared__ float ws[9 * NB * XS];
+  __shared__ int goff[kMaxTilePix];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int TCP = TC + 2, TRP = TR + 2;
+  const int npix_lds = TRP * TCP;
+  const int npix_out = TR * TC;
+
+  int bx = blockIdx.x;
+  const int tx = bx % tilesX;
+  bx /= tilesX;
+  const int ty = bx % tilesY;
+  const int n = bx / tilesY;
+  const int y0 = ty * TR, x0 = tx * TC;
+  const int co0 = blockIdx.y * NB;
+
+  // global offset (floats, relative to image n) of every LDS tile pixel; -1 = zero fill
+  for (int p = tid; p < npix_lds; p += 256) {
+    const int tr = p / TCP, tc = p - tr * TCP;
+    int iy = y0 - a.off + tr, ix = x0 - a.off + tc;
+    int o;
+    if (a.off == 1) {  // reflect (then clamp for tile overhang; overhang feeds masked outputs only)
+      iy = iy < 0 ? -iy : iy;
+      iy = iy >= a.Hi ? 2 * a.Hi - 2 - iy : iy;
+      ix = ix < 0 ? -ix : ix;
+      ix = ix >= a.Wi ? 2 * a.Wi - 2 - ix : ix;
+      iy = min(max(iy, 0), a.Hi - 1);
+      ix = min(max(ix, 0), a.Wi - 1);
+      o = (iy * a.Wi + ix) * a.ldx;
+    } else {
+      o = (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) ? (iy * a.Wi + ix) * a.ldx : -1;
+    }
+    goff[p] = o;
+  }
+
+  const float* ximg = a.x + (size_t)n * a.Hi * a.Wi * a.ldx;
+
+  int pbase[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    int idx = (wave * 4 + m) * 16 + lr;
+    if (idx >= npix_out) idx = 0;
+    const int r = idx / TC, c = idx - r * TC;
+    pbase[m] = (r * TCP + c) * XS + g;
+  }
+  const int wbase = lr * XS + g;
+
+  f32x4 acc[4][NFRAG];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int nf = 0; nf < NFRAG; ++nf) acc[m][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int c0 = 0; c0 < a.cin_p; c0 += CK) {
+    __syncthreads();  // goff ready (first pass) / previous chunk fully consumed
+    for (int i = tid; i < npix_lds * Q; i += 256) {
+      const int p = i / Q, q = i - p * Q;
+      const int o = goff[p];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o >= 0) v = *reinterpret_cast<const float4*>(ximg + o + c0 + 4 * q);
+      float* d = xs + p * XS + 4 * q;
+      d[0] = v.x;
+      d[1] = v.y;
+      d[2] = v.z;
+      d[3] = v.w;
+    }
+    for (int i = tid; i < 9 * NB * Q; i += 256) {
+      const int q = i % Q;
+      const int row = i / Q;  // tap*NB + co
+      const int tap = row / NB, co = row - tap * NB;
+      const float4 v =
+          *reinterpret_cast<const float4*>(a.w + ((size_t)tap * a.cout_pad + co0 + co) * a.cin_p + c0 + 4 * q);
+      float* d = ws + row * XS + 4 * q;
+      d[0] = v.x;
+      d[1] = v.y;
+      d[2] = v.z;
+      d[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int toff = (kh * TCP + kw) * XS;
+        const float* wt = ws + (kh * 3 + kw) * NB * XS + wbase;
+#pragma unroll
+        for (int ks = 0; ks < Q; ++ks) {
+          float bf[NFRAG], af[4];
+#pragma unroll
+          for (int nf = 0; nf < NFRAG; ++nf) bf[nf] = wt[nf * 16 * XS + ks * 4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) af[m] = xs[pbase[m] + toff + ks * 4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nf = 0; nf < NFRAG; ++nf)
+              acc[m][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[nf], acc[m][nf], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, store, per-channel sum / sum-of-squares for BatchNorm -------------
+  float bv[NFRAG], s1[NFRAG], s2[NFRAG];
+#pragma unroll
+  for (int nf = 0; nf < NFRAG; ++nf) {
+    bv[nf] = a.bias ? a.bias[co0 + nf * 16 + lr] : 0.f;
+    s1[nf] = 0.f;
+    s2[nf] = 0.f;
+  }
+  float* yimg = a.y + (size_t)n * a.Ho * a.Wo * a.ldy;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int idx = (wave * 4 + m) * 16 + g * 4 + r4;
+      const int orow = idx / TC, ocol = idx - orow * TC;
+      const int oy = y0 + orow, ox = x0 + ocol;
+      const bool ok = idx < npix_out && oy < a.Ho && ox < a.Wo;
+      if (ok) {
+        float* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy + co0 + lr;
+#pragma unroll
+        for (int nf = 0; nf < NFRAG; ++nf) {
+          const float v = acc[m][nf][r4] + bv[nf];
+          if (co0 + nf * 16 + lr < a.cout_store) yp[nf * 16] = v;
+          s1[nf] += v;
+          s2[nf] += v * v;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int nf = 0; nf < NFRAG; ++nf) {
+      s1[nf] += __shfl_xor(s1[nf], 16);
+      s1[nf] += __shfl_xor(s1[nf], 32);
+      s2[nf] += __shfl_xor(s2[nf], 16);
+      s2[nf] += __shfl_xor(s2[nf], 32);
+    }
+    __syncthreads();  // all waves are done with ws
+    float* red = ws;  // [4 waves][2][NB]
+    if (g == 0) {
+#pragma unroll
+      for (int nf = 0; nf < NFRAG; ++nf) {
+        red[(wave * 2 + 0) * NB + nf * 16 + lr] = s1[nf];
+        red[(wave * 2 + 1) * NB + nf * 16 + lr] = s2[nf];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * NB) {
+      const int which = tid / NB, c = tid - which * NB;
+      const float v = red[(0 * 2 + which) * NB + c] + red[(1 * 2 + which) * NB + c] +
+                      red[(2 * 2 + which) * NB + c] + red[(3 * 2 + which) * NB + c];
+      a.stats[((size_t)blockIdx.x * 2 + which) * a.cout_pad + co0 + c] = v;
+    }
+  }
+}
+
+template <int NFRAG, int CK>
+static int launch_conv(const ConvLaunch& a, int TR, int TC, int tilesY, int tilesX, hipStream_t stream) {
+  dim3 grid(a.N * tilesY * tilesX, a.cout_pad / (NFRAG * 16));
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<NFRAG, CK>), grid, dim3(256), 0, stream, a, TR, TC, tilesY, tilesX);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+template <int NFRAG>
+static int launch_conv_ck(const ConvLaunch& a, int TR, int TC, int tilesY, int tilesX, hipStream_t stream) {
+  if (a.cin_p % 16 == 0) return launch_conv<NFRAG, 16>(a, TR, TC, tilesY, tilesX, stream);
+  if (a.cin_p % 8 == 0) return launch_conv<NFRAG, 8>(a, TR, TC, tilesY, tilesX, stream);
+  return launch_conv<NFRAG, 4>(a, TR, TC, tilesY, tilesX, stream);
+}
+
+int conv3x3_launch(const ConvLaunch& a, int* rows, hipStream_t stream) {
+  if (a.cin_p % 4 != 0 || a.ldx % 4 != 0 || a.cout_pad % 16 != 0 || a.Hi < 2 || a.Wi < 2) {
+    set_error("conv3x3: bad geometry cin_p=%d ldx=%d cout_pad=%d H=%d W=%d", a.cin_p, a.ldx, a.cout_pad, a.Hi, a.Wi);
+    return MIMO_ERR_INVALID;
+  }
+  int TR, TC;
+  pick_tile(a.Ho, a.Wo, &TR, &TC);
+  const int tilesY = ceil_div(a.Ho, TR), tilesX = ceil_div(a.Wo, TC);
+  if (rows) *rows = a.N * tilesY * tilesX;
+  const int nfr = a.cout_pad / 16;
+  int nfrag = 4;
+  while (nfr % nfrag != 0) --nfrag;
+  switch (nfrag) {
+    case 4: return launch_conv_ck<4>(a, TR, TC, tilesY, tilesX, stream);
+    case 3: return launch_conv_ck<3>(a, TR, TC, tilesY, tilesX, stream);
+    case 2: return launch_conv_ck<2>(a, TR, TC, tilesY, tilesX, stream);
+    default: return launch_conv_ck<1>(a, TR, TC, tilesY, tilesX, stream);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient: dW[tap][ci][co] = sum_pixels A(pixel+tap, ci) * dz(pixel, co)
+// MFMA: rows = 16 input channels, cols = 16 output channels, K = 4 consecutive pixels.
+// LDS holds both tiles channel-major with pitch == 2 (mod 32): conflict-free b32 reads.
+// ---------------------------------------------------------------------------------------
+template <int TC>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
+  constexpr int TR = 256 / TC;
+  constexpr int TCP = TC + 2, TRP = TR + 2;
+  constexpr int APIX = TRP * TCP;
+  constexpr int APITCH = ((APIX + 31) / 32) * 32 + 2;
+  constexpr int DPITCH = 258;
+  __shared__ float as[32 * APITCH];
+  __shared__ float ds[32 * DPITCH];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int mi = wave >> 1, ni = wave & 1;
+  const int coTiles = a.cout_pad / 32;
+  const int ciT = blockIdx.x / coTiles, coT = blockIdx.x - ciT * coTiles;
+  const int ci0 = ciT * 32, co0 = coT * 32;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int abase = (mi * 16 + lr) * APITCH + g;
+  const int bbase = (ni * 16 + lr) * DPITCH + g;
+
+  for (int tile = blockIdx.y; tile < numTiles; tile += gridDim.y) {
+    int t = tile;
+    const int tx = t % tilesX;
+    t /= tilesX;
+    const int ty = t % tilesY;
+    const int n = t / tilesY;
+    const int y0 = ty * TR, x0 = tx * TC;
+    const float* ximg = a.x + (size_t)n * a.H * a.W * a.ldx;
+    const float* dimg = a.dz + (size_t)n * a.H * a.W * a.lddz;
+    __syncthreads();
+    for (int i = tid; i < APIX * 8; i += 256) {
+      const int p = i >> 3, q = i & 7;
+      const int tr = p / TCP, tc = p - tr * TCP;
+      int iy = y0 - 1 + tr, ix = x0 - 1 + tc;
+      iy = iy < 0 ? -iy : iy;
+      iy = iy >= a.H ? 2 * a.H - 2 - iy : iy;
+      ix = ix < 0 ? -ix : ix;
+      ix = ix >= a.W ? 2 * a.W - 2 - ix : ix;
+      iy = min(max(iy, 0), a.H - 1);
+      ix = min(max(ix, 0), a.W - 1);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ci0 + 4 * q < a.cin_p) v = *reinterpret_cast<const float4*>(ximg + ((size_t)iy * a.W + ix) * a.ldx + ci0 + 4 * q);
+      float* d = as + (4 * q) * APITCH + p;
+      d[0] = v.x;
+      d[APITCH] = v.y;
+      d[2 * APITCH] = v.z;
+      d[3 * APITCH] = v.w;
+    }
+    for (int i = tid; i < 256 * 8; i += 256) {
+      const int p = i >> 3, q = i & 7;
+      const int r = p / TC, c = p - r * TC;
+      const int y = y0 + r, x = x0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y < a.H && x < a.W && co0 + 4 * q < a.cout_p)
+        v = *reinterpret_cast<const float4*>(dimg + ((size_t)y * a.W + x) * a.lddz + co0 + 4 * q);
+      float* d = ds + (4 * q) * DPITCH + p;
+      d[0] = v.x;
+      d[DPITCH] = v.y;
+      d[2 * DPITCH] = v.z;
+      d[3 * DPITCH] = v.w;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int ks = 0; ks < 64; ++ks) {
+      const int pix = ks * 4;
+      const int r = pix / TC, c = pix - r * TC;
+      const float b = ds[bbase + pix];
+      const float* ap = as + abase + r * TCP + c;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kh * TCP + kw], b, acc[kh * 3 + kw], 0, 0, 0);
+    }
+  }
+  float* out = a.partial + (size_t)blockIdx.y * 9 * a.cin_pad * a.cout_pad;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int ci = ci0 + mi * 16 + g * 4 + r4;
+      const int co = co0 + ni * 16 + lr;
+      out[((size_t)t * a.cin_pad + ci) * a.cout_pad + co] = acc[t][r4];
+    }
+}
+
+static int wgrad_tc(int W) { return W >= 24 ? 32 : (W >= 12 ? 16 : 8); }
+
+static int wgrad_num_tiles(int N, int H, int W) {
+  const int tc = wgrad_tc(W), tr = 256 / tc;
+  return N * ceil_div(H, tr) * ceil_div(W, tc);
+}
+
+int wgrad_pick_splits(int N, int H, int W, int cin_pad, int cout_pad) {
+  const int wtiles = (cin_pad / 32) * (cout_pad / 32);
+  const int tiles = wgrad_num_tiles(N, H, W);
+  int splits = ceil_div(2048, wtiles);
+  if (splits > tiles) splits = tiles;
+  if (splits > 1024) splits = 1024;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+int wgrad_launch(const WgradLaunch& a, hipStream_t stream) {
+  if (a.cin_pad % 32 || a.cout_pad % 32 || a.cin_p % 4 || a.cout_p % 4 || a.ldx % 4 || a.lddz % 4 || a.H < 2 || a.W < 2) {
+    set_error("wgrad: bad geometry");
+    return MIMO_ERR_INVALID;
+  }
+  const int tc = wgrad_tc(a.W), tr = 256 / tc;
+  const int tilesY = ceil_div(a.H, tr), tilesX = ceil_div(a.W, tc);
+  const int numTiles = a.N * tilesY * tilesX;
+  dim3 grid((a.cin_pad / 32) * (a.cout_pad / 32), a.splits);
+  if (tc == 32)
+    hipLaunchKernelGGL((wgrad_mfma_kernel<32>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
+  else if (tc == 16)
+    hipLaunchKernelGGL((wgrad_mfma_kernel<16>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
+  else
+    hipLaunchKernelGGL((wgrad_mfma_kernel<8>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// dw (torch OIHW [cout][cin][3][3]) <- sum over splits; cin_map[padded ci] = logical ci or -1
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int cin_pad, int cout_pad,
+                                    const int* __restrict__ cin_map, int cin_p, int cin, int cout,
+                                    float* __restrict__ dw) {
+  const int total = 9 * cin_p * cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i % cout;
+    const int rest = i / cout;
+    const int cip = rest % cin_p, tap = rest / cin_p;
+    const int ci = cin_map ? cin_map[cip] : (cip < cin ? cip : -1);
+    if (ci < 0) continue;
+    const size_t stride = (size_t)9 * cin_pad * cout_pad;
+    const float* p = partial + ((size_t)tap * cin_pad + cip) * cout_pad + co;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += p[k * stride];
+    dw[((size_t)co * cin + ci) * 9 + tap] = s;
+  }
+}
+
+int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map, int cin_p,
+                        int cin, int cout, float* dw, hipStream_t stream) {
+  const int total = 9 * cin_p * cout;
+  const int blocks = min(ceil_div(total, 256), 4096);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, splits, cin_pad, cout_pad,
+                     cin_map, cin_p, cin, cout, dw);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// weight packing: torch OIHW -> dst[tap][row][col]
+//   transposed == 0 (forward):  row -> co = row_map[row], col -> ci = col_map[col], tap = kh*3+kw
+//   transposed == 1 (dgrad):    row -> ci = row_map[row], col -> co = col_map[col], tap = (2-kh)*3+(2-kw)
+// map value -1 = zero padding.
+// ---------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst, int cout, int cin,
+                                    int rows_pad, int cols, const int* __restrict__ row_map,
+                                    const int* __restrict__ col_map, int transposed) {
+  const int total = 9 * rows_pad * cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int col = i % cols;
+    const int rest = i / cols;
+    const int row = rest % rows_pad, tap = rest / rows_pad;
+    const int rm = row_map[row], cm = col_map[col];
+    float v = 0.f;
+    if (rm >= 0 && cm >= 0) {
+      const int co = transposed ? cm : rm, ci = transposed ? rm : cm;
+      const int kh = transposed ? 2 - tap / 3 : tap / 3, kw = transposed ? 2 - tap % 3 : tap % 3;
+      v = w[(((size_t)co * cin + ci) * 3 + kh) * 3 + kw];
+    }
+    dst[i] = v;
+  }
+}
+
+int pack_weights_launch(const float* w, float* dst, int cout, int cin, int rows_pad, int cols, const int* row_map,
+                        const int* col_map, int transposed, hipStream_t stream) {
+  const int total = 9 * rows_pad * cols;
+  const int blocks = min(ceil_div(total, 256), 4096);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, stream, w, dst, cout, cin, rows_pad, cols,
+                     row_map, col_map, transposed);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+}  // namespace mimo

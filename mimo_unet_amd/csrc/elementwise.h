@@ -1,0 +1,89 @@
+// Launch wrappers of the bandwidth-class kernels (elementwise.hip).  All tensors NHWC, fp32,
+// channel count padded to a multiple of 8; "ld" = floats per pixel of the buffer a pointer
+// indexes (a tensor may be a channel slice of a wider concat buffer).
+#pragma once
+#include "common.h"
+
+namespace mimo {
+
+constexpr int kMaxChunks = 64;   // second-level partial rows kept for finalize kernels
+constexpr int kEwMaxBlocks = 1024;
+constexpr int kMaxHeadOut = 8;   // out_channels supported by the fused head kernels
+
+// ---- generic two-level column reduction of per-workgroup partial rows -------------------
+// partial [rows][cols] (float) -> sums [chunks][cols] (double); returns chunks via *chunks.
+int rowsum_launch(const float* partial, int rows, int cols, double* sums, int* chunks, hipStream_t s);
+
+// ---- input / output layout conversion ---------------------------------------------------
+// x NCHW-strided (see mimo_forward_args) -> NHWC [N,H,W,cp] for subnetwork s (zero pad channels)
+int pack_input_launch(const float* x, int64_t stride_n, int64_t stride_s, const int64_t* perm, int s, int N, int C,
+                      int H, int W, float* out, int cp, hipStream_t st);
+// dx[n][s][c][y][x] = fold(dxpad)[n][y][x][c]
+int unpack_dx_launch(const float* dxpad, int ldp, int N, int S, int s, int C, int H, int W, float* dx, hipStream_t st);
+
+// ---- BatchNorm + ReLU (+ Dropout2d) forward ---------------------------------------------
+// training: sums = rowsum of the conv epilogue partials ([chunks][2*cout_pad]).
+int bn_fwd_finalize_launch(const double* sums, int chunks, int cout_pad, int C, int Cp, int64_t count,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                           hipStream_t st);
+int bn_eval_prepare_launch(int C, int Cp, const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, float* mean, float* invstd, float* scale,
+                           float* shift, hipStream_t st);
+// a = relu(z*scale+shift) * mask[n][c]
+int bn_relu_fwd_launch(const float* z, int ldz, float* a, int lda, const float* scale, const float* shift,
+                       const float* mask, int C, int Cp, int64_t P, int HW, hipStream_t st);
+
+// ---- pooling / upsampling ---------------------------------------------------------------
+int maxpool_fwd_launch(const float* a, int lda, int N, int H, int W, int Cp, float* out, int ldo, hipStream_t st);
+// out[N,H,W,csp+clp] = cat(skip, zero_pad(bilinear_x2_align_corners(low)))
+int upcat_fwd_launch(const float* skip, int lds, int csp, const float* low, int ldl, int clp, int N, int H, int W,
+                     int h, int w, float* out, hipStream_t st);
+
+// ---- backward gathers.  "dxpad" = gradient on the reflect-padded domain [N,H+2,W+2,ldp]
+// produced by the dgrad convolution; fold = transpose of reflect padding. ------------------
+// da[N,H,W] (lda) (=|+=) maxpool2x2 backward of fold(dxpad at pooled size), argmax from a
+int pool_bwd_launch(const float* dxpad, int ldp, int choff, const float* a, int lda, float* da, int ldda, int N,
+                    int H, int W, int Cp, int accumulate, hipStream_t st);
+// da (=|+=) fold(dxpad)[..., choff : choff+Cp]
+int fold_slice_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, int N, int H, int W, int Cp,
+                      int accumulate, hipStream_t st);
+// da_low[N,h,w] (=|+=) bilinear^T(fold(dxpad [N,H+2,W+2])[..., choff : choff+Cp])
+int up_bwd_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, int N, int H, int W, int h, int w,
+                  int Cp, int accumulate, hipStream_t st);
+
+// ---- BatchNorm + ReLU backward ------------------------------------------------------------
+// dy = da * mask * [z*scale+shift > 0]; partial rows of (sum dy, sum dy*xhat).
+// da source: plain (da != nullptr, ldda) or folded from dxpad (da == nullptr).
+int bnrelu_bwd_reduce_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             const float* mask, int C, int Cp, int N, int H, int W, float* dy, float* partial,
+                             int* rows, hipStream_t st);
+// c1 = sum_dy/count, c2 = sum_dyxhat/count (zero when !training); dgamma, dbeta -> grads
+int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_t count, int training, float* c1,
+                           float* c2, float* dgamma, float* dbeta, hipStream_t st);
+// dz = scale * (dy - c1 - xhat*c2); partial rows of sum dz (conv bias gradient)
+int bn_bwd_apply_launch(const float* dy, const float* z, int ldz, const float* scale, const float* mean,
+                        const float* invstd, const float* c1, const float* c2, int Cp, int64_t P, float* dz,
+                        float* partial, int* rows, hipStream_t st);
+// out[c] = sum over chunks of sums[chunk][c], c < C
+int vec_finalize_launch(const double* sums, int chunks, int cols, int C, float* out, hipStream_t st);
+
+// ---- 1x1 head + loss ------------------------------------------------------------------------
+// out[n][s][co][yx] = bias[co] + sum_c a[n,yx,c] * w[co][c]      (components.py:126)
+int head_fwd_launch(const float* a, int lda, const float* w, const float* bias, int C, int Co, int N, int S, int s,
+                    int HW, float* out, hipStream_t st);
+// per-subnetwork sum of the un-reduced NLL (losses.py:151-160) -> partial [S][blocks]
+int loss_fwd_launch(const float* out, const float* label, const float* mask, const int64_t* perm, int N, int S,
+                    int Co, int HW, int kind, float eps_min, float eps_max, float* partial, int* blocks,
+                    hipStream_t st);
+int loss_finalize_launch(const float* partial, int S, int blocks, double count, float* loss_out, hipStream_t st);
+// dlogit = dout + dloss[s]/count * dNLL/dlogit; da = W^T dlogit; partial rows of (dW [Co][Cp], db [Co])
+int head_bwd_launch(const float* a, int lda, const float* w, int C, int Cp, int Co, int N, int S, int s, int HW,
+                    const float* out, const float* dout, const float* dloss, const float* label, const float* mask,
+                    const int64_t* perm, int kind, float eps_min, float eps_max, float* da, float* partial,
+                    int* rows, hipStream_t st);
+int head_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int Co, float* dw, float* db,
+                             hipStream_t st);
+
+}  // namespace mimo

@@ -1,0 +1,903 @@
+// Bandwidth-class kernels of the MIMO U-Net path for gfx950: everything that is not a 3x3
+// convolution.  One float4 (4 channels of one pixel) per thread per step, fully coalesced
+// NHWC accesses, per-thread register accumulation + LDS block reduction + per-workgroup
+// partial rows (deterministic two-level reduction, no float atomics).
+//
+// Reference operators replaced (relative to /root/reference):
+//   BatchNorm2d / ReLU / Dropout2d ........ mimo/models/mimo_components/components.py:24-29
+//   MaxPool2d(2) .......................... components.py:48
+//   Upsample(bilinear, align_corners) + F.pad + cat ... components.py:78,110-119
+//   OutConv 1x1 ........................... components.py:123-129
+//   LaplaceNLL / GaussianNLL .............. mimo/losses.py:47-79,132-164
+//   apply_input_transform gather .......... mimo/models/utils.py:38-48
+#include <algorithm>
+
+#include "elementwise.h"
+
+namespace mimo {
+
+// ---------------------------------------------------------------------------------------
+// thread mapping: 256 threads = QB channel-quads x PPI pixels; quad fixed per thread
+// ---------------------------------------------------------------------------------------
+struct PQ {
+  int q;       // channel quad handled by this thread
+  int ql, pl;  // position inside the workgroup
+  int QB, PPI;
+  int p, pstep;  // first pixel, pixel stride
+  bool active;
+};
+
+__device__ __forceinline__ PQ pixquad(int Cv) {
+  PQ r;
+  r.QB = Cv < 256 ? Cv : 256;
+  r.PPI = 256 / r.QB;
+  r.ql = threadIdx.x % r.QB;
+  r.pl = threadIdx.x / r.QB;
+  r.q = blockIdx.y * r.QB + r.ql;
+  r.active = r.pl < r.PPI && r.q < Cv;
+  r.p = blockIdx.x * r.PPI + r.pl;
+  r.pstep = gridDim.x * r.PPI;
+  return r;
+}
+
+static dim3 pq_grid(int Cv, int64_t P, int max_blocks = kEwMaxBlocks) {
+  const int QB = Cv < 256 ? Cv : 256;
+  const int PPI = 256 / QB;
+  int64_t gx = ceil_div64(P, PPI);
+  if (gx > max_blocks) gx = max_blocks;
+  if (gx < 1) gx = 1;
+  return dim3((unsigned)gx, (unsigned)ceil_div(Cv, QB));
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// sum the accumulators of the threads that share a channel quad; result valid for pl == 0
+__device__ __forceinline__ float4 quad_block_sum(float4 v, const PQ& t, float4* red) {
+  __syncthreads();
+  red[threadIdx.x] = t.active ? v : f4zero();
+  __syncthreads();
+  float4 s = f4zero();
+  if (t.pl == 0)
+    for (int j = 0; j < t.PPI; ++j) s = f4add(s, red[j * t.QB + t.ql]);
+  return s;
+}
+
+// gradient on the reflect-padded domain folded back onto the image (transpose of reflect pad):
+// pad row -1 lands on row 1, pad row H on row H-2 (same for columns).
+__device__ __forceinline__ float4 fold_read(const float* dxpad, int ldp, int n, int y, int x, int H, int W, int ch) {
+  int ry[3], rx[3], ny = 1, nx = 1;
+  ry[0] = y;
+  rx[0] = x;
+  if (y == 1) ry[ny++] = -1;
+  if (y == H - 2) ry[ny++] = H;
+  if (x == 1) rx[nx++] = -1;
+  if (x == W - 2) rx[nx++] = W;
+  float4 s = f4zero();
+  const float* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + ch;
+  for (int i = 0; i < ny; ++i)
+    for (int j = 0; j < nx; ++j) s = f4add(s, ld4(base + ((size_t)(ry[i] + 1) * (W + 2) + (rx[j] + 1)) * ldp));
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// two-level column reduction
+// ---------------------------------------------------------------------------------------
+__global__ void rowsum_kernel(const float* __restrict__ partial, int rows, int cols, int rows_per_chunk,
+                              double* __restrict__ sums) {
+  __shared__ double red[256];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(rows, r0 + rows_per_chunk);
+  double s = 0.0;
+  if (col < cols)
+    for (int r = r0 + rl; r < r1; r += 4) s += (double)partial[(size_t)r * cols + col];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && col < cols) sums[(size_t)blockIdx.y * cols + col] = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
+}
+
+int rowsum_launch(const float* partial, int rows, int cols, double* sums, int* chunks, hipStream_t s) {
+  int nch = ceil_div(rows, 32);
+  if (nch > kMaxChunks) nch = kMaxChunks;
+  if (nch < 1) nch = 1;
+  const int rpc = ceil_div(rows, nch);
+  nch = ceil_div(rows, rpc);
+  *chunks = nch;
+  hipLaunchKernelGGL(rowsum_kernel, dim3(ceil_div(cols, 64), nch), dim3(256), 0, s, partial, rows, cols, rpc, sums);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+__global__ void vec_finalize_kernel(const double* __restrict__ sums, int chunks, int cols, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < chunks; ++k) s += sums[(size_t)k * cols + c];
+  out[c] = (float)s;
+}
+
+int vec_finalize_launch(const double* sums, int chunks, int cols, int C, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(vec_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, sums, chunks, cols, C, out);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// layout conversion
+// ---------------------------------------------------------------------------------------
+__global__ void pack_input_kernel(const float* __restrict__ x, int64_t stride_n, int64_t stride_s,
+                                  const int64_t* __restrict__ perm, int s, int N, int C, int HW,
+                                  float* __restrict__ out, int cp) {
+  const int64_t total = (int64_t)N * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / HW);
+    const int yx = (int)(i - (int64_t)n * HW);
+    const int64_t src_n = perm ? perm[(int64_t)s * N + n] : n;
+    const float* src = x + src_n * stride_n + (int64_t)s * stride_s + yx;
+    float* dst = out + i * cp;
+    for (int c = 0; c < cp; ++c) dst[c] = c < C ? src[(int64_t)c * HW] : 0.f;
+  }
+}
+
+int pack_input_launch(const float* x, int64_t stride_n, int64_t stride_s, const int64_t* perm, int s, int N, int C,
+                      int H, int W, float* out, int cp, hipStream_t st) {
+  const int64_t total = (int64_t)N * H * W;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 4096);
+  hipLaunchKernelGGL(pack_input_kernel, dim3(blocks), dim3(256), 0, st, x, stride_n, stride_s, perm, s, N, C, H * W, out, cp);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+__global__ void unpack_dx_kernel(const float* __restrict__ dxpad, int ldp, int N, int S, int s, int C, int H, int W,
+                                 float* __restrict__ dx) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / (H * W));
+    const int yx = (int)(i - (int64_t)n * H * W);
+    const int y = yx / W, x = yx - y * W;
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      const float4 v = fold_read(dxpad, ldp, n, y, x, H, W, c0);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      for (int j = 0; j < 4 && c0 + j < C; ++j) dx[(((int64_t)n * S + s) * C + c0 + j) * H * W + yx] = vv[j];
+    }
+  }
+}
+
+int unpack_dx_launch(const float* dxpad, int ldp, int N, int S, int s, int C, int H, int W, float* dx, hipStream_t st) {
+  const int64_t total = (int64_t)N * H * W;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 4096);
+  hipLaunchKernelGGL(unpack_dx_kernel, dim3(blocks), dim3(256), 0, st, dxpad, ldp, N, S, s, C, H, W, dx);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm statistics -> scale/shift
+// ---------------------------------------------------------------------------------------
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ sums, int chunks, int cout_pad, int C, int Cp,
+                                       double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var,
+                                       float momentum, float eps, float* __restrict__ mean, float* __restrict__ invstd,
+                                       float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  if (c >= C) {
+    mean[c] = 0.f;
+    invstd[c] = 0.f;
+    scale[c] = 0.f;
+    shift[c] = 0.f;
+    return;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  const int cols = 2 * cout_pad;
+  for (int k = 0; k < chunks; ++k) {
+    s1 += sums[(size_t)k * cols + c];
+    s2 += sums[(size_t)k * cols + cout_pad + c];
+  }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  var = var > 0.0 ? var : 0.0;
+  const double is = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] * is;
+  mean[c] = (float)m;
+  invstd[c] = (float)is;
+  scale[c] = (float)sc;
+  shift[c] = (float)((double)beta[c] - m * sc);
+  const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+  running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+  running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+}
+
+int bn_fwd_finalize_launch(const double* sums, int chunks, int cout_pad, int C, int Cp, int64_t count,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, st, sums, chunks, cout_pad, C, Cp,
+                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+__global__ void bn_eval_prepare_kernel(int C, int Cp, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                       float eps, float* __restrict__ mean, float* __restrict__ invstd,
+                                       float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  if (c >= C) {
+    mean[c] = 0.f;
+    invstd[c] = 0.f;
+    scale[c] = 0.f;
+    shift[c] = 0.f;
+    return;
+  }
+  const double m = running_mean[c];
+  const double is = 1.0 / sqrt((double)running_var[c] + (double)eps);
+  const double sc = (double)gamma[c] * is;
+  mean[c] = (float)m;
+  invstd[c] = (float)is;
+  scale[c] = (float)sc;
+  shift[c] = (float)((double)beta[c] - m * sc);
+}
+
+int bn_eval_prepare_launch(int C, int Cp, const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, float* mean, float* invstd, float* scale,
+                           float* shift, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, st, C, Cp, gamma, beta,
+                     running_mean, running_var, eps, mean, invstd, scale, shift);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+__device__ __forceinline__ float4 mask4(const float* mask, int n, int C, int c0) {
+  float4 m;
+  const float* mp = mask + (size_t)n * C;
+  m.x = c0 + 0 < C ? mp[c0 + 0] : 0.f;
+  m.y = c0 + 1 < C ? mp[c0 + 1] : 0.f;
+  m.z = c0 + 2 < C ? mp[c0 + 2] : 0.f;
+  m.w = c0 + 3 < C ? mp[c0 + 3] : 0.f;
+  return m;
+}
+
+__global__ void bn_relu_fwd_kernel(const float* __restrict__ z, int ldz, float* __restrict__ a, int lda,
+                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                   const float* __restrict__ mask, int C, int Cv, int P, int HW) {
+  const PQ t = pixquad(Cv);
+  if (!t.active) return;
+  const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q);
+  for (int p = t.p; p < P; p += t.pstep) {
+    const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
+    float4 r;
+    r.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+    r.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+    r.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+    r.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+    if (mask) {
+      const float4 m = mask4(mask, p / HW, C, 4 * t.q);
+      r.x *= m.x;
+      r.y *= m.y;
+      r.z *= m.z;
+      r.w *= m.w;
+    }
+    st4(a + (size_t)p * lda + 4 * t.q, r);
+  }
+}
+
+int bn_relu_fwd_launch(const float* z, int ldz, float* a, int lda, const float* scale, const float* shift,
+                       const float* mask, int C, int Cp, int64_t P, int HW, hipStream_t st) {
+  const int Cv = Cp / 4;
+  hipLaunchKernelGGL(bn_relu_fwd_kernel, pq_grid(Cv, P, 4096), dim3(256), 0, st, z, ldz, a, lda, scale, shift, mask, C,
+                     Cv, (int)P, HW);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// max pooling 2x2 (floor) and bilinear x2 upsample + zero pad + concat
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 f4max(float4 a, float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
+__global__ void maxpool_fwd_kernel(const float* __restrict__ a, int lda, int N, int H, int W, int Cv,
+                                   float* __restrict__ out, int ldo) {
+  const PQ t = pixquad(Cv);
+  if (!t.active) return;
+  const int Ho = H / 2, Wo = W / 2;
+  const int P = N * Ho * Wo;
+  for (int p = t.p; p < P; p += t.pstep) {
+    const int n = p / (Ho * Wo);
+    const int r = p - n * Ho * Wo;
+    const int oy = r / Wo, ox = r - oy * Wo;
+    const float* src = a + (((size_t)n * H + 2 * oy) * W + 2 * ox) * lda + 4 * t.q;
+    const float4 v = f4max(f4max(ld4(src), ld4(src + lda)), f4max(ld4(src + (size_t)W * lda), ld4(src + (size_t)(W + 1) * lda)));
+    st4(out + (size_t)p * ldo + 4 * t.q, v);
+  }
+}
+
+int maxpool_fwd_launch(const float* a, int lda, int N, int H, int W, int Cp, float* out, int ldo, hipStream_t st) {
+  const int Cv = Cp / 4;
+  const int64_t P = (int64_t)N * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, pq_grid(Cv, P, 4096), dim3(256), 0, st, a, lda, N, H, W, Cv, out, ldo);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// source index / weight of bilinear align_corners=True interpolation, as torch computes it in
+// fp32: src = dst * (in-1)/(out-1); i0 = (int)src; lambda = src - i0; i1 = i0 + (i0 < in-1)
+struct Lerp {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lerp lerp_src(int dst, int in, int out) {
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = scale * (float)dst;
+  Lerp r;
+  r.i0 = min((int)src, in - 1);
+  r.l1 = fminf(fmaxf(src - (float)r.i0, 0.f), 1.f);
+  r.l0 = 1.f - r.l1;
+  r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+  return r;
+}
+
+__global__ void upcat_fwd_kernel(const float* __restrict__ skip, int lds, int csv, const float* __restrict__ low,
+                                 int ldl, int clv, int N, int H, int W, int h, int w, int padT, int padL,
+                                 float* __restrict__ out) {
+  const int Cv = csv + clv;
+  const PQ t = pixquad(Cv);
+  if (!t.active) return;
+  const int ldo = 4 * Cv;
+  const int P = N * H * W;
+  for (int p = t.p; p < P; p += t.pstep) {
+    float4 v;
+    if (t.q < csv) {
+      v = ld4(skip + (size_t)p * lds + 4 * t.q);
+    } else {
+      const int n = p / (H * W);
+      const int r = p - n * H * W;
+      const int y = r / W, x = r - y * W;
+      const int uy = y - padT, ux = x - padL;
+      v = f4zero();
+      if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w) {
+        const Lerp ly = lerp_src(uy, h, 2 * h), lx = lerp_src(ux, w, 2 * w);
+        const float* b = low + (size_t)n * h * w * ldl + 4 * (t.q - csv);
+        const float4 v00 = ld4(b + ((size_t)ly.i0 * w + lx.i0) * ldl), v01 = ld4(b + ((size_t)ly.i0 * w + lx.i1) * ldl);
+        const float4 v10 = ld4(b + ((size_t)ly.i1 * w + lx.i0) * ldl), v11 = ld4(b + ((size_t)ly.i1 * w + lx.i1) * ldl);
+        v.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+        v.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+        v.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+        v.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+      }
+    }
+    st4(out + (size_t)p * ldo + 4 * t.q, v);
+  }
+}
+
+int upcat_fwd_launch(const float* skip, int lds, int csp, const float* low, int ldl, int clp, int N, int H, int W,
+                     int h, int w, float* out, hipStream_t st) {
+  const int Cv = (csp + clp) / 4;
+  const int padT = (H - 2 * h) / 2, padL = (W - 2 * w) / 2;  // F.pad(diff//2, diff - diff//2), components.py:110-115
+  if (H < 2 * h || W < 2 * w) {
+    set_error("upcat: skip smaller than upsampled input");
+    return MIMO_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(upcat_fwd_kernel, pq_grid(Cv, (int64_t)N * H * W, 4096), dim3(256), 0, st, skip, lds, csp / 4, low,
+                     ldl, clp / 4, N, H, W, h, w, padT, padL, out);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// backward gathers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float route_max(float g, float v00, float v01, float v10, float v11, int self) {
+  // first maximum in scan order (0,0),(0,1),(1,0),(1,1) receives the gradient (strict '>' update)
+  int arg = 0;
+  float m = v00;
+  if (v01 > m) { m = v01; arg = 1; }
+  if (v10 > m) { m = v10; arg = 2; }
+  if (v11 > m) { m = v11; arg = 3; }
+  return arg == self ? g : 0.f;
+}
+
+__global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int choff, const float* __restrict__ a,
+                                int lda, float* __restrict__ da, int ldda, int N, int H, int W, int Cv, int accumulate) {
+  const PQ t = pixquad(Cv);
+  if (!t.active) return;
+  const int Hp = H / 2, Wp = W / 2;
+  const int P = N * H * W;
+  for (int p = t.p; p < P; p += t.pstep) {
+    const int n = p / (H * W);
+    const int r = p - n * H * W;
+    const int y = r / W, x = r - y * W;
+    float4 v = f4zero();
+    if (y < 2 * Hp && x < 2 * Wp) {
+      const int py = y >> 1, px = x >> 1;
+      const float4 g = fold_read(dxpad, ldp, n, py, px, Hp, Wp, choff + 4 * t.q);
+      const float* src = a + (((size_t)n * H + 2 * py) * W + 2 * px) * lda + 4 * t.q;
+      const float4 v00 = ld4(src), v01 = ld4(src + lda), v10 = ld4(src + (size_t)W * lda), v11 = ld4(src + (size_t)(W + 1) * lda);
+      const int self = (y & 1) * 2 + (x & 1);
+      v.x = route_max(g.x, v00.x, v01.x, v10.x, v11.x, self);
+      v.y = route_max(g.y, v00.y, v01.y, v10.y, v11.y, self);
+      v.z = route_max(g.z, v00.z, v01.z, v10.z, v11.z, self);
+      v.w = route_max(g.w, v00.w, v01.w, v10.w, v11.w, self);
+    }
+    float* dst = da + (size_t)p * ldda + 4 * t.q;
+    if (accumulate) v = f4add(v, ld4(dst));
+    st4(dst, v);
+  }
+}
+
+int pool_bwd_launch(const float* dxpad, int ldp, int choff, const float* a, int lda, float* da, int ldda, int N, int H,
+                    int W, int Cp, int accumulate, hipStream_t st) {
+  const int Cv = Cp / 4;
+  hipLaunchKernelGGL(pool_bwd_kernel, pq_grid(Cv, (int64_t)N * H * W, 4096), dim3(256), 0, st, dxpad, ldp, choff, a, lda,
+                     da, ldda, N, H, W, Cv, accumulate);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+__global__ void fold_slice_kernel(const float* __restrict__ dxpad, int ldp, int choff, float* __restrict__ da, int ldda,
+                                  int N, int H, int W, int Cv, int accumulate) {
+  const PQ t = pixquad(Cv);
+  if (!t.active) return;
+  const int P = N * H * W;
+  for (int p = t.p; p < P; p += t.pstep) {
+    const int n = p / (H * W);
+    const int r = p - n * H * W;
+    const int y = r / W, x = r - y * W;
+    float4 v = fold_read(dxpad, ldp, n, y, x, H, W, choff + 4 * t.q);
+    float* dst = da + (size_t)p * ldda + 4 * t.q;
+    if (accumulate) v = f4add(v, ld4(dst));
+    st4(dst, v);
+  }
+}
+
+int fold_slice_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, int N, int H, int W, int Cp,
+                      int accumulate, hipStream_t st) {
+  const int Cv = Cp / 4;
+  hipLaunchKernelGGL(fold_slice_kernel, pq_grid(Cv, (int64_t)N * H * W, 4096), dim3(256), 0, st, dxpad, ldp, choff, da,
+                     ldda, N, H, W, Cv, accumulate);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// weight with which output index o (of an x2 align_corners upsample of `in` samples) reads input i
+__device__ __forceinline__ float lerp_weight(int o, int i, int in) {
+  const Lerp l = lerp_src(o, in, 2 * in);
+  return (l.i0 == i ? l.l0 : 0.f) + (l.i1 == i ? l.l1 : 0.f);
+}
+
+__global__ void up_bwd_kernel(const float* __restrict__ dxpad, int ldp, int choff, float* __restrict__ da, int ldda,
+                              int N, int H, int W, int h, int w, int padT, int padL, int Cv, int accumulate) {
+  const PQ t = pixquad(Cv);
+  if (!t.active) return;
+  const int P = N * h * w;
+  for (int p = t.p; p < P; p += t.pstep) {
+    const int n = p / (h * w);
+    const int r = p - n * h * w;
+    const int iy = r / w, ix = r - iy * w;
+    float4 v = f4zero();
+    for (int oy = max(0, 2 * iy - 2); oy <= min(2 * h - 1, 2 * iy + 2); ++oy) {
+      const float wy = lerp_weight(oy, iy, h);
+      if (wy == 0.f) continue;
+      for (int ox = max(0, 2 * ix - 2); ox <= min(2 * w - 1, 2 * ix + 2); ++ox) {
+        const float wx = lerp_weight(ox, ix, w);
+        if (wx == 0.f) continue;
+        const float4 g = fold_read(dxpad, ldp, n, oy + padT, ox + padL, H, W, choff + 4 * t.q);
+        const float ww = wy * wx;
+        v.x += ww * g.x;
+        v.y += ww * g.y;
+        v.z += ww * g.z;
+        v.w += ww * g.w;
+      }
+    }
+    float* dst = da + (size_t)p * ldda + 4 * t.q;
+    if (accumulate) v = f4add(v, ld4(dst));
+    st4(dst, v);
+  }
+}
+
+int up_bwd_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, int N, int H, int W, int h, int w,
+                  int Cp, int accumulate, hipStream_t st) {
+  const int Cv = Cp / 4;
+  const int padT = (H - 2 * h) / 2, padL = (W - 2 * w) / 2;
+  hipLaunchKernelGGL(up_bwd_kernel, pq_grid(Cv, (int64_t)N * h * w, 4096), dim3(256), 0, st, dxpad, ldp, choff, da, ldda,
+                     N, H, W, h, w, padT, padL, Cv, accumulate);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm + ReLU backward
+// ---------------------------------------------------------------------------------------
+__global__ void bnrelu_bwd_reduce_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ dxpad,
+                                         int ldp, const float* __restrict__ z, int ldz, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, const float* __restrict__ mean,
+                                         const float* __restrict__ invstd, const float* __restrict__ mask, int C, int Cv,
+                                         int N, int H, int W, float* __restrict__ dy, float* __restrict__ partial) {
+  __shared__ float4 red[256];
+  const PQ t = pixquad(Cv);
+  const int Cp = 4 * Cv;
+  float4 a1 = f4zero(), a2 = f4zero();
+  if (t.active) {
+    const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q), mu = ld4(mean + 4 * t.q), is = ld4(invstd + 4 * t.q);
+    const int P = N * H * W;
+    for (int p = t.p; p < P; p += t.pstep) {
+      float4 g;
+      const int n = p / (H * W);
+      if (da) {
+        g = ld4(da + (size_t)p * ldda + 4 * t.q);
+      } else {
+        const int r = p - n * H * W;
+        const int y = r / W, x = r - y * W;
+        g = fold_read(dxpad, ldp, n, y, x, H, W, 4 * t.q);
+      }
+      if (mask) {
+        const float4 m = mask4(mask, n, C, 4 * t.q);
+        g.x *= m.x;
+        g.y *= m.y;
+        g.z *= m.z;
+        g.w *= m.w;
+      }
+      const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
+      g.x = fmaf(v.x, sc.x, sh.x) > 0.f ? g.x : 0.f;
+      g.y = fmaf(v.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
+      g.z = fmaf(v.z, sc.z, sh.z) > 0.f ? g.z : 0.f;
+      g.w = fmaf(v.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
+      st4(dy + (size_t)p * Cp + 4 * t.q, g);
+      a1 = f4add(a1, g);
+      a2.x += g.x * (v.x - mu.x) * is.x;
+      a2.y += g.y * (v.y - mu.y) * is.y;
+      a2.z += g.z * (v.z - mu.z) * is.z;
+      a2.w += g.w * (v.w - mu.w) * is.w;
+    }
+  }
+  const float4 s1 = quad_block_sum(a1, t, red);
+  const float4 s2 = quad_block_sum(a2, t, red);
+  if (t.pl == 0 && t.q < Cv) {
+    float* row = partial + (size_t)blockIdx.x * 2 * Cp;
+    st4(row + 4 * t.q, s1);
+    st4(row + Cp + 4 * t.q, s2);
+  }
+}
+
+int bnrelu_bwd_reduce_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             const float* mask, int C, int Cp, int N, int H, int W, float* dy, float* partial,
+                             int* rows, hipStream_t st) {
+  const int Cv = Cp / 4;
+  const dim3 grid = pq_grid(Cv, (int64_t)N * H * W);
+  *rows = grid.x;
+  hipLaunchKernelGGL(bnrelu_bwd_reduce_kernel, grid, dim3(256), 0, st, da, ldda, dxpad, ldp, z, ldz, scale, shift, mean,
+                     invstd, mask, C, Cv, N, H, W, dy, partial);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int chunks, int C, int Cp, double count,
+                                       int training, float* __restrict__ c1, float* __restrict__ c2,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s1 += sums[(size_t)k * 2 * Cp + c];
+    s2 += sums[(size_t)k * 2 * Cp + Cp + c];
+  }
+  c1[c] = training ? (float)(s1 / count) : 0.f;
+  c2[c] = training ? (float)(s2 / count) : 0.f;
+  if (c < C) {
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+  }
+}
+
+int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_t count, int training, float* c1,
+                           float* c2, float* dgamma, float* dbeta, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, st, sums, chunks, C, Cp, (double)count,
+                     training, c1, c2, dgamma, dbeta);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z, int ldz,
+                                    const float* __restrict__ scale, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ c1,
+                                    const float* __restrict__ c2, int Cv, int P, float* __restrict__ dz,
+                                    float* __restrict__ partial) {
+  __shared__ float4 red[256];
+  const PQ t = pixquad(Cv);
+  const int Cp = 4 * Cv;
+  float4 acc = f4zero();
+  if (t.active) {
+    const float4 sc = ld4(scale + 4 * t.q), mu = ld4(mean + 4 * t.q), is = ld4(invstd + 4 * t.q);
+    const float4 k1 = ld4(c1 + 4 * t.q), k2 = ld4(c2 + 4 * t.q);
+    for (int p = t.p; p < P; p += t.pstep) {
+      const float4 g = ld4(dy + (size_t)p * Cp + 4 * t.q);
+      const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
+      float4 r;
+      r.x = sc.x * (g.x - k1.x - (v.x - mu.x) * is.x * k2.x);
+      r.y = sc.y * (g.y - k1.y - (v.y - mu.y) * is.y * k2.y);
+      r.z = sc.z * (g.z - k1.z - (v.z - mu.z) * is.z * k2.z);
+      r.w = sc.w * (g.w - k1.w - (v.w - mu.w) * is.w * k2.w);
+      st4(dz + (size_t)p * Cp + 4 * t.q, r);
+      acc = f4add(acc, r);
+    }
+  }
+  const float4 s = quad_block_sum(acc, t, red);
+  if (t.pl == 0 && t.q < Cv) st4(partial + (size_t)blockIdx.x * Cp + 4 * t.q, s);
+}
+
+int bn_bwd_apply_launch(const float* dy, const float* z, int ldz, const float* scale, const float* mean,
+                        const float* invstd, const float* c1, const float* c2, int Cp, int64_t P, float* dz,
+                        float* partial, int* rows, hipStream_t st) {
+  const int Cv = Cp / 4;
+  const dim3 grid = pq_grid(Cv, P);
+  *rows = grid.x;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, dy, z, ldz, scale, mean, invstd, c1, c2, Cv, (int)P, dz,
+                     partial);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// 1x1 head and the NLL losses
+// ---------------------------------------------------------------------------------------
+__global__ void head_fwd_kernel(const float* __restrict__ a, int lda, const float* __restrict__ w,
+                                const float* __restrict__ bias, int C, int Co, int N, int S, int s, int HW,
+                                float* __restrict__ out) {
+  __shared__ float ws[kMaxHeadOut * 256];
+  __shared__ float bs[kMaxHeadOut];
+  for (int i = threadIdx.x; i < Co * C; i += blockDim.x) ws[i] = w[i];
+  if (threadIdx.x < Co) bs[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int64_t P = (int64_t)N * HW;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    float acc[kMaxHeadOut];
+#pragma unroll
+    for (int co = 0; co < kMaxHeadOut; ++co) acc[co] = 0.f;
+    const float* ap = a + p * lda;
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      const float4 v = ld4(ap + c0);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < C) {
+#pragma unroll
+          for (int co = 0; co < kMaxHeadOut; ++co)
+            if (co < Co) acc[co] = fmaf(vv[j], ws[co * C + c0 + j], acc[co]);
+        }
+    }
+    const int n = (int)(p / HW);
+    const int yx = (int)(p - (int64_t)n * HW);
+#pragma unroll
+    for (int co = 0; co < kMaxHeadOut; ++co)
+      if (co < Co) out[(((int64_t)n * S + s) * Co + co) * HW + yx] = acc[co] + bs[co];
+  }
+}
+
+int head_fwd_launch(const float* a, int lda, const float* w, const float* bias, int C, int Co, int N, int S, int s,
+                    int HW, float* out, hipStream_t st) {
+  if (Co > kMaxHeadOut || C > 256) {
+    set_error("head: out_channels %d > %d or filter_base_count %d > 256 unsupported", Co, kMaxHeadOut, C);
+    return MIMO_ERR_INVALID;
+  }
+  const int64_t P = (int64_t)N * HW;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(P, 256), 4096);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, lda, w, bias, C, Co, N, S, s, HW, out);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// value and gradient of the element-wise NLL.  The clamp acts on the value only
+// (losses.py:153-155 clamps in place under no_grad), so d/dlog keeps the unclamped exp.
+__device__ __forceinline__ float nll_value(int kind, float d, float lp, float eps_min, float eps_max) {
+  const float sc = fminf(fmaxf(expf(lp), eps_min), eps_max);
+  return kind == MIMO_LOSS_LAPLACE_NLL ? logf(sc) + fabsf(d) / sc : logf(sc) + d * d / sc;
+}
+__device__ __forceinline__ void nll_grad(int kind, float d, float lp, float eps_min, float eps_max, float* gmu, float* glp) {
+  const float e = expf(lp);
+  const float sc = fminf(fmaxf(e, eps_min), eps_max);
+  if (kind == MIMO_LOSS_LAPLACE_NLL) {
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    *gmu = sgn / sc;
+    *glp = (1.f / sc - fabsf(d) / (sc * sc)) * e;
+  } else {
+    *gmu = 2.f * d / sc;
+    *glp = (1.f / sc - d * d / (sc * sc)) * e;
+  }
+}
+
+__global__ void loss_fwd_kernel(const float* __restrict__ out, const float* __restrict__ label,
+                                const float* __restrict__ mask, const int64_t* __restrict__ perm, int N, int S, int Co,
+                                int HW, int kind, float eps_min, float eps_max, float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int s = blockIdx.y;
+  const int Ct = Co / 2;
+  const int64_t total = (int64_t)N * Ct * HW;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int yx = (int)(i % HW);
+    const int64_t r = i / HW;
+    const int tch = (int)(r % Ct);
+    const int n = (int)(r / Ct);
+    const int64_t src = perm ? perm[(int64_t)s * N + n] : n;
+    const float* o = out + (((int64_t)n * S + s) * Co) * HW + yx;
+    const float mu = o[(int64_t)tch * HW], lp = o[(int64_t)(Ct + tch) * HW];
+    const float y = label[(src * Ct + tch) * HW + yx];
+    float v = nll_value(kind, mu - y, lp, eps_min, eps_max);
+    if (mask) v *= mask[src * HW + yx];
+    acc += v;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[(size_t)s * gridDim.x + blockIdx.x] = red[0];
+}
+
+int loss_fwd_launch(const float* out, const float* label, const float* mask, const int64_t* perm, int N, int S, int Co,
+                    int HW, int kind, float eps_min, float eps_max, float* partial, int* blocks, hipStream_t st) {
+  const int64_t total = (int64_t)N * (Co / 2) * HW;
+  const int nb = (int)std::min<int64_t>(ceil_div64(total, 256), 512);
+  *blocks = nb;
+  hipLaunchKernelGGL(loss_fwd_kernel, dim3(nb, S), dim3(256), 0, st, out, label, mask, perm, N, S, Co, HW, kind, eps_min,
+                     eps_max, partial);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+__global__ void loss_finalize_kernel(const float* __restrict__ partial, int S, int blocks, double count,
+                                     float* __restrict__ loss_out) {
+  __shared__ double red[256];
+  const int s = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < blocks; i += blockDim.x) acc += (double)partial[(size_t)s * blocks + i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[s] = (float)(red[0] / count);
+}
+
+int loss_finalize_launch(const float* partial, int S, int blocks, double count, float* loss_out, hipStream_t st) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(S), dim3(256), 0, st, partial, S, blocks, count, loss_out);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+__global__ void head_bwd_kernel(const float* __restrict__ a, int lda, const float* __restrict__ w, int C, int Cv, int Co,
+                                int N, int S, int s, int HW, const float* __restrict__ out,
+                                const float* __restrict__ dout, const float* __restrict__ dloss,
+                                const float* __restrict__ label, const float* __restrict__ mask,
+                                const int64_t* __restrict__ perm, int kind, float eps_min, float eps_max, float inv_count,
+                                float* __restrict__ da, float* __restrict__ partial) {
+  __shared__ float4 red[256];
+  const PQ t = pixquad(Cv);
+  const int Cp = 4 * Cv, Ct = Co / 2;
+  float4 wq[kMaxHeadOut], dwacc[kMaxHeadOut];
+  float dbacc[kMaxHeadOut];
+#pragma unroll
+  for (int co = 0; co < kMaxHeadOut; ++co) {
+    wq[co] = f4zero();
+    dwacc[co] = f4zero();
+    dbacc[co] = 0.f;
+    if (co < Co && t.active) {
+      const int c0 = 4 * t.q;
+      wq[co].x = c0 + 0 < C ? w[co * C + c0 + 0] : 0.f;
+      wq[co].y = c0 + 1 < C ? w[co * C + c0 + 1] : 0.f;
+      wq[co].z = c0 + 2 < C ? w[co * C + c0 + 2] : 0.f;
+      wq[co].w = c0 + 3 < C ? w[co * C + c0 + 3] : 0.f;
+    }
+  }
+  const float coef = dloss ? dloss[s] * inv_count : 0.f;
+  if (t.active) {
+    const int P = N * HW;
+    for (int p = t.p; p < P; p += t.pstep) {
+      const int n = p / HW;
+      const int yx = p - n * HW;
+      const int64_t obase = (((int64_t)n * S + s) * Co) * HW + yx;
+      float dl[kMaxHeadOut];
+#pragma unroll
+      for (int co = 0; co < kMaxHeadOut; ++co) dl[co] = (dout && co < Co) ? dout[obase + (int64_t)co * HW] : 0.f;
+      if (dloss) {
+        const int64_t src = perm ? perm[(int64_t)s * N + n] : n;
+        const float mk = mask ? mask[src * HW + yx] : 1.f;
+#pragma unroll
+        for (int tc = 0; tc < kMaxHeadOut / 2; ++tc)
+          if (tc < Ct) {
+            const float mu = out[obase + (int64_t)tc * HW], lp = out[obase + (int64_t)(Ct + tc) * HW];
+            const float y = label[(src * Ct + tc) * HW + yx];
+            float gm, gl;
+            nll_grad(kind, mu - y, lp, eps_min, eps_max, &gm, &gl);
+            dl[tc] += coef * mk * gm;
+            dl[Ct + tc] += coef * mk * gl;  // Ct + tc < kMaxHeadOut
+          }
+      }
+      const float4 av = ld4(a + (size_t)p * lda + 4 * t.q);
+      float4 g = f4zero();
+#pragma unroll
+      for (int co = 0; co < kMaxHeadOut; ++co)
+        if (co < Co) {
+          g.x = fmaf(dl[co], wq[co].x, g.x);
+          g.y = fmaf(dl[co], wq[co].y, g.y);
+          g.z = fmaf(dl[co], wq[co].z, g.z);
+          g.w = fmaf(dl[co], wq[co].w, g.w);
+          dwacc[co].x = fmaf(dl[co], av.x, dwacc[co].x);
+          dwacc[co].y = fmaf(dl[co], av.y, dwacc[co].y);
+          dwacc[co].z = fmaf(dl[co], av.z, dwacc[co].z);
+          dwacc[co].w = fmaf(dl[co], av.w, dwacc[co].w);
+          dbacc[co] += dl[co];
+        }
+      st4(da + (size_t)p * Cp + 4 * t.q, g);
+    }
+  }
+  // partial row: [Co][Cp] weight gradient followed by [Co] bias gradient (from quad 0 threads)
+  float* row = partial + (size_t)blockIdx.x * (Co * Cp + Co);
+  for (int co = 0; co < Co; ++co) {
+    float4 v = f4zero();
+    float b = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxHeadOut; ++k)
+      if (k == co) {
+        v = dwacc[k];
+        b = dbacc[k];
+      }
+    const float4 sw = quad_block_sum(v, t, red);
+    if (t.pl == 0 && t.q < Cv) st4(row + co * Cp + 4 * t.q, sw);
+    const float4 sb = quad_block_sum(make_float4(b, 0.f, 0.f, 0.f), t, red);
+    if (t.pl == 0 && t.q == 0) row[Co * Cp + co] = sb.x;
+  }
+}
+
+int head_bwd_launch(const float* a, int lda, const float* w, int C, int Cp, int Co, int N, int S, int s, int HW,
+                    const float* out, const float* dout, const float* dloss, const float* label, const float* mask,
+                    const int64_t* perm, int kind, float eps_min, float eps_max, float* da, float* partial, int* rows,
+                    hipStream_t st) {
+  if (Co > kMaxHeadOut || (Co & 1)) {
+    set_error("head: out_channels %d unsupported", Co);
+    return MIMO_ERR_INVALID;
+  }
+  const int Cv = Cp / 4;
+  dim3 grid = pq_grid(Cv, (int64_t)N * HW);
+  grid.y = 1;  // Cv <= 64 for the head (filter_base_count <= 256)
+  *rows = grid.x;
+  const float inv_count = 1.f / (float)((double)N * (Co / 2) * HW);
+  hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(256), 0, st, a, lda, w, C, Cv, Co, N, S, s, HW, out, dout, dloss, label,
+                     mask, perm, kind, eps_min, eps_max, inv_count, da, partial);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+__global__ void head_bwd_finalize_kernel(const double* __restrict__ sums, int chunks, int C, int Cp, int Co,
+                                         float* __restrict__ dw, float* __restrict__ db) {
+  const int cols = Co * Cp + Co;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cols) return;
+  double s = 0.0;
+  for (int k = 0; k < chunks; ++k) s += sums[(size_t)k * cols + i];
+  if (i < Co * Cp) {
+    const int co = i / Cp, c = i - co * Cp;
+    if (c < C) dw[co * C + c] = (float)s;
+  } else {
+    db[i - Co * Cp] = (float)s;
+  }
+}
+
+int head_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int Co, float* dw, float* db, hipStream_t st) {
+  const int cols = Co * Cp + Co;
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(ceil_div(cols, 64)), dim3(64), 0, st, sums, chunks, C, Cp, Co, dw, db);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+}  // namespace mimo

@@ -1,0 +1,197 @@
+// Single-operator C-ABI entry points (mimo_op_*): thin drivers around the same kernels the
+// plan runs, for the per-kernel parity tests.  They allocate temporaries and synchronise —
+// test plumbing, never on the timed path.
+#include <algorithm>
+#include <vector>
+
+#include "elementwise.h"
+
+using namespace mimo;
+
+namespace {
+
+struct Temp {
+  std::vector<void*> ptrs;
+  ~Temp() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  T* get(size_t count) {
+    void* q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    (void)hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(T));
+    ptrs.push_back(q);
+    return static_cast<T*>(q);
+  }
+  int* ints(const std::vector<int>& v) {
+    int* p = get<int>(v.size());
+    if (p) (void)hipMemcpy(p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+    return p;
+  }
+};
+
+std::vector<int> ident_map(int padded, int logical) {
+  std::vector<int> m(padded);
+  for (int i = 0; i < padded; ++i) m[i] = i < logical ? i : -1;
+  return m;
+}
+
+__global__ void colsum_naive_kernel(const float* __restrict__ x, int64_t rows, int ld, int C, float* __restrict__ out) {
+  const int c = blockIdx.x;
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t r = threadIdx.x; r < rows; r += blockDim.x) s += (double)x[r * ld + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && c < C) out[c] = (float)red[0];
+}
+
+__global__ void sums_to_stats_kernel(const double* __restrict__ sums, int chunks, int cout_pad, int cout,
+                                     double* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cout) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s1 += sums[(size_t)k * 2 * cout_pad + c];
+    s2 += sums[(size_t)k * 2 * cout_pad + cout_pad + c];
+  }
+  stats[c] = s1;
+  stats[cout + c] = s2;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, float* z, double* stats, int32_t n,
+                            int32_t h, int32_t wd, int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p,
+                            mimo_stream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Temp t;
+  const int cout_pad = conv3x3_cout_pad(cout);
+  float* wf = t.get<float>((size_t)9 * cout_pad * cin_p);
+  float* bp = t.get<float>(cout_pad);
+  int* rm = t.ints(ident_map(cout_pad, cout));
+  int* cm = t.ints(ident_map(cin_p, cin));
+  const int rows_cap = conv3x3_stat_rows(n, h, wd);
+  float* partial = t.get<float>((size_t)rows_cap * 2 * cout_pad);
+  double* sums = t.get<double>((size_t)kMaxChunks * 2 * cout_pad);
+  if (!wf || !bp || !rm || !cm || !partial || !sums) {
+    set_error("mimo_op_conv3x3_forward: allocation failed");
+    return MIMO_ERR_HIP;
+  }
+  MIMO_TRY(pack_weights_launch(w, wf, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
+  if (bias) MIMO_HIP_CHECK(hipMemcpyAsync(bp, bias, cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+  ConvLaunch a;
+  a.x = x;
+  a.y = z;
+  a.w = wf;
+  a.bias = bp;
+  a.stats = stats ? partial : nullptr;
+  a.N = n;
+  a.Hi = a.Ho = h;
+  a.Wi = a.Wo = wd;
+  a.ldx = cin_p;
+  a.cin_p = cin_p;
+  a.ldy = cout_p;
+  a.cout_pad = cout_pad;
+  a.cout_store = cout_p;
+  a.off = 1;
+  int rows = 0;
+  MIMO_TRY(conv3x3_launch(a, &rows, st));
+  if (stats) {
+    int chunks = 0;
+    MIMO_TRY(rowsum_launch(partial, rows, 2 * cout_pad, sums, &chunks, st));
+    hipLaunchKernelGGL(sums_to_stats_kernel, dim3(ceil_div(cout, 64)), dim3(64), 0, st, sums, chunks, cout_pad, cout, stats);
+    MIMO_KERNEL_CHECK();
+  }
+  MIMO_HIP_CHECK(hipStreamSynchronize(st));
+  return MIMO_OK;
+}
+
+int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n, int32_t h, int32_t wd, int32_t cin,
+                          int32_t cin_p, int32_t cout, int32_t cout_p, mimo_stream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Temp t;
+  const int rows_pad = conv3x3_cout_pad(cin_p);
+  float* wdp = t.get<float>((size_t)9 * rows_pad * cout_p);
+  int* rm = t.ints(ident_map(rows_pad, cin));
+  int* cm = t.ints(ident_map(cout_p, cout));
+  float* dxpad = t.get<float>((size_t)n * (h + 2) * (wd + 2) * cin_p);
+  if (!wdp || !rm || !cm || !dxpad) {
+    set_error("mimo_op_conv3x3_dgrad: allocation failed");
+    return MIMO_ERR_HIP;
+  }
+  MIMO_TRY(pack_weights_launch(w, wdp, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
+  ConvLaunch a;
+  a.x = dz;
+  a.y = dxpad;
+  a.w = wdp;
+  a.bias = nullptr;
+  a.stats = nullptr;
+  a.N = n;
+  a.Hi = h;
+  a.Wi = wd;
+  a.ldx = cout_p;
+  a.cin_p = cout_p;
+  a.Ho = h + 2;
+  a.Wo = wd + 2;
+  a.ldy = cin_p;
+  a.cout_pad = rows_pad;
+  a.cout_store = cin_p;
+  a.off = 2;
+  MIMO_TRY(conv3x3_launch(a, nullptr, st));
+  MIMO_TRY(fold_slice_launch(dxpad, cin_p, 0, dx, cin_p, n, h, wd, cin_p, 0, st));
+  MIMO_HIP_CHECK(hipStreamSynchronize(st));
+  return MIMO_OK;
+}
+
+int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbias, int32_t n, int32_t h, int32_t wd,
+                          int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p, mimo_stream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Temp t;
+  WgradLaunch a;
+  a.x = x;
+  a.dz = dz;
+  a.N = n;
+  a.H = h;
+  a.W = wd;
+  a.ldx = cin_p;
+  a.lddz = cout_p;
+  a.cin_p = cin_p;
+  a.cout_p = cout_p;
+  a.cin_pad = round_up(cin_p, 32);
+  a.cout_pad = round_up(cout_p, 32);
+  a.splits = wgrad_pick_splits(n, h, wd, a.cin_pad, a.cout_pad);
+  a.partial = t.get<float>((size_t)a.splits * 9 * a.cin_pad * a.cout_pad);
+  int* cm = t.ints(ident_map(cin_p, cin));
+  if (!a.partial || !cm) {
+    set_error("mimo_op_conv3x3_wgrad: allocation failed");
+    return MIMO_ERR_HIP;
+  }
+  MIMO_TRY(wgrad_launch(a, st));
+  MIMO_TRY(wgrad_reduce_launch(a.partial, a.splits, a.cin_pad, a.cout_pad, cm, cin_p, cin, cout, dw, st));
+  if (dbias) {
+    hipLaunchKernelGGL(colsum_naive_kernel, dim3(cout), dim3(256), 0, st, dz, (int64_t)n * h * wd, cout_p, cout, dbias);
+    MIMO_KERNEL_CHECK();
+  }
+  MIMO_HIP_CHECK(hipStreamSynchronize(st));
+  return MIMO_OK;
+}
+
+int mimo_op_maxpool2x2(const float* x, float* y, int32_t n, int32_t h, int32_t w, int32_t c_p, mimo_stream stream) {
+  MIMO_TRY(maxpool_fwd_launch(x, c_p, n, h, w, c_p, y, c_p, (hipStream_t)stream));
+  return MIMO_OK;
+}
+
+int mimo_op_upsample_cat(const float* skip, const float* low, float* out, int32_t n, int32_t hs, int32_t ws, int32_t cs_p,
+                         int32_t hl, int32_t wl, int32_t cl_p, mimo_stream stream) {
+  MIMO_TRY(upcat_fwd_launch(skip, cs_p, cs_p, low, cl_p, cl_p, n, hs, ws, hl, wl, out, (hipStream_t)stream));
+  return MIMO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// Fused flat-buffer Adam and the subnetwork-axis uncertainty reduction (gfx950, HBM-bound).
+//
+// Replaces: torch.optim.Adam.step as configured by mimo/models/mimo_unet.py:186-190
+//           (betas .9/.999, eps 1e-8, L2 weight decay folded into the gradient, not AdamW);
+//           compute_uncertainties, mimo/models/utils.py:76-101.
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+namespace mimo {
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+                            float bc1, float bc2_sqrt, float grad_scale) {
+  const int64_t n4 = n / 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pa = &pp.x;
+    float* ga = &gg.x;
+    float* ma = &mm.x;
+    float* va = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gr = ga[j] * grad_scale;
+      if (wd != 0.f) gr = fmaf(wd, pa[j], gr);
+      ma[j] = beta1 * ma[j] + (1.f - beta1) * gr;
+      va[j] = beta2 * va[j] + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(va[j]) / bc2_sqrt + eps;
+      pa[j] -= (lr / bc1) * (ma[j] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // tail (n not a multiple of 4)
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gr = g[i] * grad_scale;
+    if (wd != 0.f) gr = fmaf(wd, p[i], gr);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gr;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+
+__global__ void uncertainty_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int N, int S, int64_t chw,
+                                   int kind, float* __restrict__ mean, float* __restrict__ alea, float* __restrict__ epi) {
+  const int64_t total = (int64_t)N * chw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / chw, r = i - n * chw;
+    const float* a = p1 + n * S * chw + r;
+    const float* b = p2 + n * S * chw + r;
+    float sm = 0.f, sa = 0.f;
+    for (int s = 0; s < S; ++s) {
+      sm += a[s * chw];
+      // std^2: Laplace (exp(ls)*sqrt2)^2, Gaussian (exp(lv)^0.5)^2  (losses.py:82-84,166-167)
+      const float e = expf(b[s * chw]);
+      const float sd = kind == MIMO_LOSS_LAPLACE_NLL ? e * 1.41421356237309515f : sqrtf(e);
+      sa += sd * sd;
+    }
+    const float mu = sm / (float)S;
+    float se = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float d = a[s * chw] - mu;
+      se += d * d;
+    }
+    mean[i] = mu;
+    alea[i] = sa / (float)S;
+    epi[i] = S > 1 ? se / (float)(S - 1) : 0.f;
+  }
+}
+
+}  // namespace mimo
+
+extern "C" int mimo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                              mimo_stream stream) {
+  using namespace mimo;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) {
+    set_error("mimo_adam_step: invalid argument");
+    return MIMO_ERR_INVALID;
+  }
+  if (n == 0) return MIMO_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int blocks = (int)std::min<int64_t>(ceil_div64(n / 4 + 1, 256), 2048);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
+                     lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_uncertainties(const float* p1, const float* p2, int32_t n, int32_t s, int32_t c, int64_t hw,
+                                  int32_t loss_kind, float* mean, float* aleatoric, float* epistemic, mimo_stream stream) {
+  using namespace mimo;
+  if (!p1 || !p2 || !mean || !aleatoric || !epistemic || n < 1 || s < 1 || c < 1 || hw < 1) {
+    set_error("mimo_uncertainties: invalid argument");
+    return MIMO_ERR_INVALID;
+  }
+  const int64_t total = (int64_t)n * c * hw;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 4096);
+  hipLaunchKernelGGL(uncertainty_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p1, p2, n, s, (int64_t)c * hw,
+                     loss_kind, mean, aleatoric, epistemic);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}

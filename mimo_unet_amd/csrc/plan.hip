@@ -1,0 +1,721 @@
+// mimo_plan: the MIMO U-Net network executor behind the C ABI.  Owns packed weights, saved
+// activations, BatchNorm statistics and scratch; sequences the HIP kernels of conv3x3.hip /
+// elementwise.hip for forward, loss and backward on the caller's stream.
+//
+// Topology restated from the reference (relative to /root/reference):
+//   MimoUNet.forward ........... mimo/models/mimo_components/model.py:94-117
+//   SubnetworkEncoder .......... model.py:119-175   (S private DoubleConv + Down)
+//   SubnetworkCore ............. model.py:178-243   (down2..4, up1..3 on the channel concat)
+//   SubnetworkDecoder .......... model.py:246-297   (S private Up + OutConv, stacked)
+//   DoubleConv / Down / Up ..... mimo/models/mimo_components/components.py:8-120
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "elementwise.h"
+
+namespace mimo {
+
+static thread_local char g_error[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_error; }
+
+namespace {
+
+struct TensorInfo {
+  std::string name;
+  int ndim;
+  int64_t shape[4];
+  int kind;  // 0 parameter, 1 BN buffer
+  int64_t offset;
+};
+
+// An activation tensor as seen by consumers: pointer (possibly a channel slice of a wider
+// concat buffer), pixel pitch, padded channel count, gradient buffer, and the map from padded
+// channel index to the logical channel index inside this tensor (-1 = zero padding).
+struct Act {
+  float* a = nullptr;
+  int ld = 0;
+  float* da = nullptr;
+  int ldda = 0;
+  int Cp = 0, C = 0;
+  int N = 0, H = 0, W = 0;
+  std::vector<int> chmap;
+  int grad_writes = 0;  // run-time counter: first writer assigns, later writers accumulate
+};
+
+struct ConvBN {
+  std::string conv_name, bn_name;
+  int Cin = 0, Cout = 0, cin_p = 0, cout_p = 0;
+  int cout_pad = 0;             // forward packed rows
+  int dg_rows = 0;              // dgrad packed rows (covers cin_p)
+  int wg_cin_pad = 0, wg_cout_pad = 0, wg_splits = 1;
+  int N = 0, H = 0, W = 0;
+  int64_t off_w = 0, off_b = 0, off_gamma = 0, off_beta = 0, off_rm = 0, off_rv = 0;
+  float *wf = nullptr, *wd = nullptr, *bias_p = nullptr;
+  int *cin_map = nullptr, *fwd_row_map = nullptr, *dg_row_map = nullptr, *dg_col_map = nullptr;
+  float* z = nullptr;
+  float *mean = nullptr, *invstd = nullptr, *scale = nullptr, *shift = nullptr, *c1 = nullptr, *c2 = nullptr;
+  const float* in = nullptr;
+  int ld_in = 0;
+  float* a = nullptr;  // output activation
+  int ld_a = 0;
+};
+
+enum InputKind { IN_IMAGE = 0, IN_POOL = 1, IN_UPCAT = 2 };
+
+struct DoubleConv {
+  std::string prefix;
+  ConvBN c1, c2;
+  InputKind kind = IN_IMAGE;
+  int subnet = -1;       // for IN_IMAGE
+  Act* src0 = nullptr;   // IN_POOL: pooled tensor; IN_UPCAT: skip
+  Act* src1 = nullptr;   // IN_UPCAT: low-resolution tensor
+  float* in_buf = nullptr;  // materialised input (packed image / pooled / concat)
+  int in_ld = 0;
+  float* mid = nullptr;  // a1
+  Act out;               // a2 (+ gradient)
+  float drop_p = 0.f;
+  const float* mask = nullptr;  // set per forward call
+};
+
+struct Head {
+  int s = 0;
+  int64_t off_w = 0, off_b = 0;
+};
+
+}  // namespace
+}  // namespace mimo
+
+using namespace mimo;
+
+struct mimo_plan {
+  mimo_config cfg;
+  int S, f, N, H, W, Ci, Co, Ci_p;
+  std::vector<TensorInfo> tensors;
+  int64_t param_floats = 0, buffer_floats = 0;
+  float *params = nullptr, *grads = nullptr, *bnbuf = nullptr;
+  std::vector<void*> allocs;
+  size_t bytes = 0;
+
+  std::vector<std::unique_ptr<DoubleConv>> dcs;  // forward order == oracle double_conv_specs
+  std::vector<DoubleConv*> enc_in, down1, up4;
+  DoubleConv *down2 = nullptr, *down3 = nullptr, *down4 = nullptr, *up1 = nullptr, *up2 = nullptr, *up3 = nullptr;
+  Act x2cat;  // concat of the S encoder outputs (model.py:113)
+  std::vector<Head> heads;
+
+  // scratch
+  float *s_dy = nullptr, *s_dz = nullptr, *s_dxpadA = nullptr, *s_dxpadB = nullptr, *s_wslab = nullptr,
+        *s_partial = nullptr, *s_losspart = nullptr;
+  double* s_sums = nullptr;
+  size_t cap_act = 0, cap_pad = 0, cap_slab = 0, cap_partial = 0, cap_sums = 0;
+
+  // per-call state
+  bool fwd_done = false, fwd_training = false, had_perm = false, loss_done = false;
+  float* out = nullptr;
+  const float *label = nullptr, *lmask = nullptr;
+  const int64_t* lperm = nullptr;
+
+  ~mimo_plan() {
+    for (void* p : allocs) (void)hipFree(p);
+  }
+
+  template <typename T>
+  int dalloc(T** p, size_t count) {
+    void* q = nullptr;
+    const size_t nbytes = std::max<size_t>(count, 1) * sizeof(T);
+    MIMO_HIP_CHECK(hipMalloc(&q, nbytes));
+    MIMO_HIP_CHECK(hipMemset(q, 0, nbytes));
+    allocs.push_back(q);
+    bytes += nbytes;
+    *p = static_cast<T*>(q);
+    return MIMO_OK;
+  }
+  int upload_ints(int** p, const std::vector<int>& v) {
+    MIMO_TRY(dalloc(p, v.size()));
+    MIMO_HIP_CHECK(hipMemcpy(*p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+    return MIMO_OK;
+  }
+
+  int64_t add_tensor(const std::string& name, std::vector<int64_t> shape, int kind) {
+    TensorInfo t;
+    t.name = name;
+    t.ndim = (int)shape.size();
+    int64_t n = 1;
+    for (int i = 0; i < 4; ++i) {
+      t.shape[i] = i < t.ndim ? shape[i] : 1;
+      n *= t.shape[i];
+    }
+    t.kind = kind;
+    int64_t& cur = kind == 0 ? param_floats : buffer_floats;
+    t.offset = cur;
+    cur += (n + 3) / 4 * 4;  // keep every tensor 16-byte aligned inside the flat buffers
+    tensors.push_back(t);
+    return t.offset;
+  }
+
+  int init_convbn(ConvBN& L, const std::string& prefix, int conv_idx, int bn_idx, int Cin, int Cout,
+                  const std::vector<int>& in_chmap, int n, int h, int w) {
+    L.conv_name = prefix + "." + std::to_string(conv_idx);
+    L.bn_name = prefix + "." + std::to_string(bn_idx);
+    L.Cin = Cin;
+    L.Cout = Cout;
+    L.cin_p = (int)in_chmap.size();
+    L.cout_p = pad_channels(Cout);
+    L.cout_pad = conv3x3_cout_pad(Cout);
+    L.dg_rows = conv3x3_cout_pad(L.cin_p);
+    L.wg_cin_pad = round_up(L.cin_p, 32);
+    L.wg_cout_pad = round_up(L.cout_p, 32);
+    L.N = n;
+    L.H = h;
+    L.W = w;
+    L.wg_splits = wgrad_pick_splits(n, h, w, L.wg_cin_pad, L.wg_cout_pad);
+    L.off_w = add_tensor(L.conv_name + ".weight", {Cout, Cin, 3, 3}, 0);
+    L.off_b = add_tensor(L.conv_name + ".bias", {Cout}, 0);
+    L.off_gamma = add_tensor(L.bn_name + ".weight", {Cout}, 0);
+    L.off_beta = add_tensor(L.bn_name + ".bias", {Cout}, 0);
+    L.off_rm = add_tensor(L.bn_name + ".running_mean", {Cout}, 1);
+    L.off_rv = add_tensor(L.bn_name + ".running_var", {Cout}, 1);
+    MIMO_TRY(dalloc(&L.wf, (size_t)9 * L.cout_pad * L.cin_p));
+    MIMO_TRY(dalloc(&L.wd, (size_t)9 * L.dg_rows * L.cout_p));
+    MIMO_TRY(dalloc(&L.bias_p, L.cout_pad));
+    MIMO_TRY(upload_ints(&L.cin_map, in_chmap));
+    std::vector<int> frm(L.cout_pad), drm(L.dg_rows), dcm(L.cout_p);
+    for (int i = 0; i < L.cout_pad; ++i) frm[i] = i < Cout ? i : -1;
+    for (int i = 0; i < L.dg_rows; ++i) drm[i] = i < L.cin_p ? in_chmap[i] : -1;
+    for (int i = 0; i < L.cout_p; ++i) dcm[i] = i < Cout ? i : -1;
+    MIMO_TRY(upload_ints(&L.fwd_row_map, frm));
+    MIMO_TRY(upload_ints(&L.dg_row_map, drm));
+    MIMO_TRY(upload_ints(&L.dg_col_map, dcm));
+    MIMO_TRY(dalloc(&L.z, (size_t)n * h * w * L.cout_p));
+    MIMO_TRY(dalloc(&L.mean, L.cout_p));
+    MIMO_TRY(dalloc(&L.invstd, L.cout_p));
+    MIMO_TRY(dalloc(&L.scale, L.cout_p));
+    MIMO_TRY(dalloc(&L.shift, L.cout_p));
+    MIMO_TRY(dalloc(&L.c1, L.cout_p));
+    MIMO_TRY(dalloc(&L.c2, L.cout_p));
+    const size_t act = (size_t)n * h * w * L.cout_p;
+    const size_t padv = (size_t)n * (h + 2) * (w + 2) * L.cin_p;
+    cap_act = std::max(cap_act, act);
+    cap_pad = std::max(cap_pad, padv);
+    cap_slab = std::max(cap_slab, (size_t)L.wg_splits * 9 * L.wg_cin_pad * L.wg_cout_pad);
+    const size_t stat_rows = conv3x3_stat_rows(n, h, w);
+    cap_partial = std::max(cap_partial, stat_rows * 2 * L.cout_pad);
+    cap_partial = std::max(cap_partial, (size_t)kEwMaxBlocks * 2 * L.cout_p);
+    cap_sums = std::max(cap_sums, (size_t)kMaxChunks * 2 * std::max(L.cout_pad, L.cout_p));
+    return MIMO_OK;
+  }
+
+  // Create a DoubleConv whose input has channel map in_chmap at resolution (h, w).
+  int make_dc(DoubleConv** outp, const std::string& prefix, const std::vector<int>& in_chmap, int Cin, int Cmid,
+              int Cout, int h, int w, float drop_p, float* out_a, int out_ld, float* out_da, int out_ldda) {
+    auto dc = std::make_unique<DoubleConv>();
+    dc->prefix = prefix;
+    dc->drop_p = drop_p;
+    MIMO_TRY(init_convbn(dc->c1, prefix, 0, 1, Cin, Cmid, in_chmap, N, h, w));
+    std::vector<int> midmap(pad_channels(Cmid));
+    for (size_t i = 0; i < midmap.size(); ++i) midmap[i] = (int)i < Cmid ? (int)i : -1;
+    MIMO_TRY(init_convbn(dc->c2, prefix, 3, 4, Cmid, Cout, midmap, N, h, w));
+    MIMO_TRY(dalloc(&dc->mid, (size_t)N * h * w * dc->c1.cout_p));
+    Act& o = dc->out;
+    o.N = N;
+    o.H = h;
+    o.W = w;
+    o.C = Cout;
+    o.Cp = dc->c2.cout_p;
+    o.chmap.resize(o.Cp);
+    for (int i = 0; i < o.Cp; ++i) o.chmap[i] = i < Cout ? i : -1;
+    if (out_a) {
+      o.a = out_a;
+      o.ld = out_ld;
+      o.da = out_da;
+      o.ldda = out_ldda;
+    } else {
+      MIMO_TRY(dalloc(&o.a, (size_t)N * h * w * o.Cp));
+      MIMO_TRY(dalloc(&o.da, (size_t)N * h * w * o.Cp));
+      o.ld = o.ldda = o.Cp;
+    }
+    dc->c1.a = dc->mid;
+    dc->c1.ld_a = dc->c1.cout_p;
+    dc->c2.in = dc->mid;
+    dc->c2.ld_in = dc->c1.cout_p;
+    dc->c2.a = o.a;
+    dc->c2.ld_a = o.ld;
+    *outp = dc.get();
+    dcs.push_back(std::move(dc));
+    return MIMO_OK;
+  }
+
+  int set_input(DoubleConv* dc, InputKind kind, Act* s0, Act* s1, int in_cp, int h, int w) {
+    dc->kind = kind;
+    dc->src0 = s0;
+    dc->src1 = s1;
+    MIMO_TRY(dalloc(&dc->in_buf, (size_t)N * h * w * in_cp));
+    dc->in_ld = in_cp;
+    dc->c1.in = dc->in_buf;
+    dc->c1.ld_in = in_cp;
+    return MIMO_OK;
+  }
+
+  static std::vector<int> cat_map(const Act& a, const Act& b) {
+    std::vector<int> m = a.chmap;
+    for (int v : b.chmap) m.push_back(v < 0 ? -1 : v + a.C);
+    return m;
+  }
+
+  int build() {
+    S = cfg.num_subnetworks;
+    f = cfg.filter_base_count;
+    N = cfg.batch;
+    H = cfg.height;
+    W = cfg.width;
+    Ci = cfg.in_channels;
+    Co = cfg.out_channels;
+    Ci_p = round_up(Ci, 4);
+    if (S < 1 || f < 1 || N < 1 || Ci < 1 || Co < 2 || (Co & 1) || Co > kMaxHeadOut || f > 256) {
+      set_error("unsupported configuration S=%d f=%d N=%d Ci=%d Co=%d", S, f, N, Ci, Co);
+      return MIMO_ERR_INVALID;
+    }
+    if ((H >> 4) < 2 || (W >> 4) < 2) {
+      set_error("input %dx%d too small: reflect padding needs >= 2 pixels at 1/16 resolution", H, W);
+      return MIMO_ERR_INVALID;
+    }
+    const int H1 = H, W1 = W, H2 = H / 2, W2 = W / 2, H3 = H2 / 2, W3 = W2 / 2, H4 = H3 / 2, W4 = W3 / 2, H5 = H4 / 2,
+              W5 = W4 / 2;
+    std::vector<int> imgmap(Ci_p);
+    for (int i = 0; i < Ci_p; ++i) imgmap[i] = i < Ci ? i : -1;
+
+    // ---- encoder (model.py:150-175) ----
+    for (int s = 0; s < S; ++s) {
+      DoubleConv* dc;
+      MIMO_TRY(make_dc(&dc, "encoder.in_convs." + std::to_string(s) + ".double_conv", imgmap, Ci, f, f, H1, W1,
+                       cfg.encoder_dropout_rate, nullptr, 0, nullptr, 0));
+      MIMO_TRY(set_input(dc, IN_IMAGE, nullptr, nullptr, Ci_p, H1, W1));
+      dc->subnet = s;
+      enc_in.push_back(dc);
+    }
+    const int c2p = pad_channels(2 * f);
+    x2cat.N = N;
+    x2cat.H = H2;
+    x2cat.W = W2;
+    x2cat.C = 2 * f * S;
+    x2cat.Cp = c2p * S;
+    x2cat.ld = x2cat.ldda = x2cat.Cp;
+    MIMO_TRY(dalloc(&x2cat.a, (size_t)N * H2 * W2 * x2cat.Cp));
+    MIMO_TRY(dalloc(&x2cat.da, (size_t)N * H2 * W2 * x2cat.Cp));
+    x2cat.chmap.assign(x2cat.Cp, -1);
+    for (int s = 0; s < S; ++s)
+      for (int c = 0; c < 2 * f; ++c) x2cat.chmap[s * c2p + c] = s * 2 * f + c;
+    for (int s = 0; s < S; ++s) {
+      DoubleConv* dc;
+      MIMO_TRY(make_dc(&dc, "encoder.down1s." + std::to_string(s) + ".conv.double_conv", enc_in[s]->out.chmap, f, 2 * f,
+                       2 * f, H2, W2, cfg.encoder_dropout_rate, x2cat.a + s * c2p, x2cat.Cp, x2cat.da + s * c2p,
+                       x2cat.Cp));
+      MIMO_TRY(set_input(dc, IN_POOL, &enc_in[s]->out, nullptr, enc_in[s]->out.Cp, H2, W2));
+      down1.push_back(dc);
+    }
+    // ---- core (model.py:190-243) ----
+    const float pc = cfg.core_dropout_rate;
+    MIMO_TRY(make_dc(&down2, "core.down2.conv.double_conv", x2cat.chmap, 2 * f * S, 4 * f * S, 4 * f * S, H3, W3, pc,
+                     nullptr, 0, nullptr, 0));
+    MIMO_TRY(set_input(down2, IN_POOL, &x2cat, nullptr, x2cat.Cp, H3, W3));
+    MIMO_TRY(make_dc(&down3, "core.down3.conv.double_conv", down2->out.chmap, 4 * f * S, 8 * f * S, 8 * f * S, H4, W4, pc,
+                     nullptr, 0, nullptr, 0));
+    MIMO_TRY(set_input(down3, IN_POOL, &down2->out, nullptr, down2->out.Cp, H4, W4));
+    MIMO_TRY(make_dc(&down4, "core.down4.conv.double_conv", down3->out.chmap, 8 * f * S, 8 * f * S, 8 * f * S, H5, W5, pc,
+                     nullptr, 0, nullptr, 0));
+    MIMO_TRY(set_input(down4, IN_POOL, &down3->out, nullptr, down3->out.Cp, H5, W5));
+    {
+      std::vector<int> m = cat_map(down3->out, down4->out);
+      MIMO_TRY(make_dc(&up1, "core.up1.conv.double_conv", m, 16 * f * S, 8 * f * S, 4 * f * S, H4, W4, pc, nullptr, 0,
+                       nullptr, 0));
+      MIMO_TRY(set_input(up1, IN_UPCAT, &down3->out, &down4->out, (int)m.size(), H4, W4));
+    }
+    {
+      std::vector<int> m = cat_map(down2->out, up1->out);
+      MIMO_TRY(make_dc(&up2, "core.up2.conv.double_conv", m, 8 * f * S, 4 * f * S, 2 * f * S, H3, W3, pc, nullptr, 0,
+                       nullptr, 0));
+      MIMO_TRY(set_input(up2, IN_UPCAT, &down2->out, &up1->out, (int)m.size(), H3, W3));
+    }
+    {
+      std::vector<int> m = cat_map(x2cat, up2->out);
+      MIMO_TRY(make_dc(&up3, "core.up3.conv.double_conv", m, 4 * f * S, 2 * f * S, f * S, H2, W2, pc, nullptr, 0, nullptr,
+                       0));
+      MIMO_TRY(set_input(up3, IN_UPCAT, &x2cat, &up2->out, (int)m.size(), H2, W2));
+    }
+    // ---- decoder (model.py:260-297) ----
+    const int cin_dec = f * S + f;
+    for (int s = 0; s < S; ++s) {
+      std::vector<int> m = cat_map(enc_in[s]->out, up3->out);
+      DoubleConv* dc;
+      MIMO_TRY(make_dc(&dc, "decoder.up4s." + std::to_string(s) + ".conv.double_conv", m, cin_dec, cin_dec / 2, f, H1, W1,
+                       cfg.decoder_dropout_rate, nullptr, 0, nullptr, 0));
+      MIMO_TRY(set_input(dc, IN_UPCAT, &enc_in[s]->out, &up3->out, (int)m.size(), H1, W1));
+      up4.push_back(dc);
+    }
+    for (int s = 0; s < S; ++s) {
+      Head h;
+      h.s = s;
+      const std::string p = "decoder.outcs." + std::to_string(s) + ".conv";
+      h.off_w = add_tensor(p + ".weight", {Co, f, 1, 1}, 0);
+      h.off_b = add_tensor(p + ".bias", {Co}, 0);
+      heads.push_back(h);
+    }
+    // reorder dcs into the oracle's forward-spec order: enc_in[*], down1[*], core..., up4[*]
+    // (make_dc pushed them in exactly that order already).
+
+    // ---- scratch ----
+    const int fp = pad_channels(f);
+    cap_partial = std::max(cap_partial, (size_t)kEwMaxBlocks * (Co * fp + Co));
+    cap_sums = std::max(cap_sums, (size_t)kMaxChunks * (Co * fp + Co));
+    MIMO_TRY(dalloc(&s_dy, cap_act));
+    MIMO_TRY(dalloc(&s_dz, cap_act));
+    MIMO_TRY(dalloc(&s_dxpadA, cap_pad));
+    MIMO_TRY(dalloc(&s_dxpadB, cap_pad));
+    MIMO_TRY(dalloc(&s_wslab, cap_slab));
+    MIMO_TRY(dalloc(&s_partial, cap_partial));
+    MIMO_TRY(dalloc(&s_sums, cap_sums));
+    MIMO_TRY(dalloc(&s_losspart, (size_t)S * 512));
+    return MIMO_OK;
+  }
+
+  // ------------------------------------------------------------------ forward ------------
+  int pack_layer(ConvBN& L, bool with_dgrad, hipStream_t st) {
+    const float* w = params + L.off_w;
+    MIMO_TRY(pack_weights_launch(w, L.wf, L.Cout, L.Cin, L.cout_pad, L.cin_p, L.fwd_row_map, L.cin_map, 0, st));
+    if (with_dgrad)
+      MIMO_TRY(pack_weights_launch(w, L.wd, L.Cout, L.Cin, L.dg_rows, L.cout_p, L.dg_row_map, L.dg_col_map, 1, st));
+    MIMO_HIP_CHECK(hipMemcpyAsync(L.bias_p, params + L.off_b, L.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return MIMO_OK;
+  }
+
+  int convbn_forward(ConvBN& L, bool training, const float* mask, hipStream_t st) {
+    ConvLaunch a;
+    a.x = L.in;
+    a.y = L.z;
+    a.w = L.wf;
+    a.bias = L.bias_p;
+    a.stats = training ? s_partial : nullptr;
+    a.N = L.N;
+    a.Hi = a.Ho = L.H;
+    a.Wi = a.Wo = L.W;
+    a.ldx = L.ld_in;
+    a.cin_p = L.cin_p;
+    a.ldy = L.cout_p;
+    a.cout_pad = L.cout_pad;
+    a.cout_store = L.cout_p;
+    a.off = 1;
+    int rows = 0;
+    MIMO_TRY(conv3x3_launch(a, &rows, st));
+    const int64_t P = (int64_t)L.N * L.H * L.W;
+    if (training) {
+      int chunks = 0;
+      MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_pad, s_sums, &chunks, st));
+      MIMO_TRY(bn_fwd_finalize_launch(s_sums, chunks, L.cout_pad, L.Cout, L.cout_p, P, params + L.off_gamma,
+                                      params + L.off_beta, bnbuf + L.off_rm, bnbuf + L.off_rv, cfg.bn_momentum,
+                                      cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
+    } else {
+      MIMO_TRY(bn_eval_prepare_launch(L.Cout, L.cout_p, params + L.off_gamma, params + L.off_beta, bnbuf + L.off_rm,
+                                      bnbuf + L.off_rv, cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
+    }
+    MIMO_TRY(bn_relu_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, P, L.H * L.W, st));
+    return MIMO_OK;
+  }
+
+  int dc_forward(DoubleConv* dc, bool training, hipStream_t st) {
+    const int h = dc->c1.H, w = dc->c1.W;
+    if (dc->kind == IN_POOL) {
+      Act* s = dc->src0;
+      MIMO_TRY(maxpool_fwd_launch(s->a, s->ld, N, s->H, s->W, s->Cp, dc->in_buf, dc->in_ld, st));
+    } else if (dc->kind == IN_UPCAT) {
+      Act *sk = dc->src0, *lo = dc->src1;
+      MIMO_TRY(upcat_fwd_launch(sk->a, sk->ld, sk->Cp, lo->a, lo->ld, lo->Cp, N, h, w, lo->H, lo->W, dc->in_buf, st));
+    }
+    MIMO_TRY(pack_layer(dc->c1, training, st));
+    MIMO_TRY(pack_layer(dc->c2, training, st));
+    MIMO_TRY(convbn_forward(dc->c1, training, nullptr, st));
+    MIMO_TRY(convbn_forward(dc->c2, training, dc->mask, st));
+    return MIMO_OK;
+  }
+
+  int forward(const mimo_forward_args* args, hipStream_t st) {
+    if (!params || !bnbuf) {
+      set_error("mimo_forward: parameters not bound (mimo_plan_bind)");
+      return MIMO_ERR_STATE;
+    }
+    if (!args || !args->x || !args->out) {
+      set_error("mimo_forward: null argument");
+      return MIMO_ERR_INVALID;
+    }
+    const bool training = args->training != 0;
+    for (size_t i = 0; i < dcs.size(); ++i) dcs[i]->mask = args->drop_masks ? args->drop_masks[i] : nullptr;
+    for (int s = 0; s < S; ++s)
+      MIMO_TRY(pack_input_launch(args->x, args->stride_n, args->stride_s, args->perm, s, N, Ci, H, W, enc_in[s]->in_buf,
+                                 Ci_p, st));
+    for (int s = 0; s < S; ++s) MIMO_TRY(dc_forward(enc_in[s], training, st));
+    for (int s = 0; s < S; ++s) MIMO_TRY(dc_forward(down1[s], training, st));
+    MIMO_TRY(dc_forward(down2, training, st));
+    MIMO_TRY(dc_forward(down3, training, st));
+    MIMO_TRY(dc_forward(down4, training, st));
+    MIMO_TRY(dc_forward(up1, training, st));
+    MIMO_TRY(dc_forward(up2, training, st));
+    MIMO_TRY(dc_forward(up3, training, st));
+    for (int s = 0; s < S; ++s) {
+      MIMO_TRY(dc_forward(up4[s], training, st));
+      const Act& o = up4[s]->out;
+      MIMO_TRY(head_fwd_launch(o.a, o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co, N, S, s, H * W,
+                               args->out, st));
+    }
+    out = args->out;
+    fwd_done = true;
+    fwd_training = training;
+    had_perm = args->perm != nullptr;
+    loss_done = false;
+    return MIMO_OK;
+  }
+
+  int loss_forward(const float* label_, const float* mask_, const int64_t* perm_, float* loss_out, hipStream_t st) {
+    if (!fwd_done) {
+      set_error("mimo_loss_forward: call mimo_forward first");
+      return MIMO_ERR_STATE;
+    }
+    if (!label_ || !loss_out) {
+      set_error("mimo_loss_forward: null argument");
+      return MIMO_ERR_INVALID;
+    }
+    int blocks = 0;
+    MIMO_TRY(loss_fwd_launch(out, label_, mask_, perm_, N, S, Co, H * W, cfg.loss_kind, cfg.eps_min, cfg.eps_max,
+                             s_losspart, &blocks, st));
+    MIMO_TRY(loss_finalize_launch(s_losspart, S, blocks, (double)N * (Co / 2) * H * W, loss_out, st));
+    label = label_;
+    lmask = mask_;
+    lperm = perm_;
+    loss_done = true;
+    return MIMO_OK;
+  }
+
+  // ------------------------------------------------------------------ backward -----------
+  // gradient arriving at an activation: first writer assigns, later writers accumulate
+  static int acc_flag(Act* t) { return t->grad_writes++ > 0 ? 1 : 0; }
+
+  int convbn_backward(ConvBN& L, const float* da, int ldda, const float* dxpad_src, const float* mask, bool need_dgrad,
+                      float* dxpad_out, hipStream_t st) {
+    int rows = 0, chunks = 0;
+    const int64_t P = (int64_t)L.N * L.H * L.W;
+    MIMO_TRY(bnrelu_bwd_reduce_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd,
+                                      mask, L.Cout, L.cout_p, L.N, L.H, L.W, s_dy, s_partial, &rows, st));
+    MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_p, s_sums, &chunks, st));
+    MIMO_TRY(bn_bwd_finalize_launch(s_sums, chunks, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
+                                    grads + L.off_gamma, grads + L.off_beta, st));
+    MIMO_TRY(bn_bwd_apply_launch(s_dy, L.z, L.cout_p, L.scale, L.mean, L.invstd, L.c1, L.c2, L.cout_p, P, s_dz, s_partial,
+                                 &rows, st));
+    MIMO_TRY(rowsum_launch(s_partial, rows, L.cout_p, s_sums, &chunks, st));
+    MIMO_TRY(vec_finalize_launch(s_sums, chunks, L.cout_p, L.Cout, grads + L.off_b, st));
+    WgradLaunch wg;
+    wg.x = L.in;
+    wg.dz = s_dz;
+    wg.partial = s_wslab;
+    wg.N = L.N;
+    wg.H = L.H;
+    wg.W = L.W;
+    wg.ldx = L.ld_in;
+    wg.lddz = L.cout_p;
+    wg.cin_p = L.cin_p;
+    wg.cout_p = L.cout_p;
+    wg.cin_pad = L.wg_cin_pad;
+    wg.cout_pad = L.wg_cout_pad;
+    wg.splits = L.wg_splits;
+    MIMO_TRY(wgrad_launch(wg, st));
+    MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
+                                 grads + L.off_w, st));
+    if (need_dgrad) {
+      ConvLaunch a;
+      a.x = s_dz;
+      a.y = dxpad_out;
+      a.w = L.wd;
+      a.bias = nullptr;
+      a.stats = nullptr;
+      a.N = L.N;
+      a.Hi = L.H;
+      a.Wi = L.W;
+      a.ldx = L.cout_p;
+      a.cin_p = L.cout_p;
+      a.Ho = L.H + 2;
+      a.Wo = L.W + 2;
+      a.ldy = L.cin_p;
+      a.cout_pad = L.dg_rows;
+      a.cout_store = L.cin_p;
+      a.off = 2;
+      MIMO_TRY(conv3x3_launch(a, nullptr, st));
+    }
+    return MIMO_OK;
+  }
+
+  int dc_backward(DoubleConv* dc, bool need_input_grad, hipStream_t st) {
+    MIMO_TRY(convbn_backward(dc->c2, dc->out.da, dc->out.ldda, nullptr, dc->mask, true, s_dxpadA, st));
+    MIMO_TRY(convbn_backward(dc->c1, nullptr, 0, s_dxpadA, nullptr, need_input_grad, s_dxpadB, st));
+    if (!need_input_grad) return MIMO_OK;
+    const int h = dc->c1.H, w = dc->c1.W, ldp = dc->c1.cin_p;
+    if (dc->kind == IN_POOL) {
+      Act* s = dc->src0;
+      MIMO_TRY(pool_bwd_launch(s_dxpadB, ldp, 0, s->a, s->ld, s->da, s->ldda, N, s->H, s->W, s->Cp, acc_flag(s), st));
+    } else if (dc->kind == IN_UPCAT) {
+      Act *sk = dc->src0, *lo = dc->src1;
+      MIMO_TRY(fold_slice_launch(s_dxpadB, ldp, 0, sk->da, sk->ldda, N, h, w, sk->Cp, acc_flag(sk), st));
+      MIMO_TRY(up_bwd_launch(s_dxpadB, ldp, sk->Cp, lo->da, lo->ldda, N, h, w, lo->H, lo->W, lo->Cp, acc_flag(lo), st));
+    }
+    return MIMO_OK;
+  }
+
+  int backward(const float* dout, const float* dloss, float* dx, hipStream_t st) {
+    if (!fwd_done) {
+      set_error("mimo_backward: call mimo_forward first");
+      return MIMO_ERR_STATE;
+    }
+    if (!grads) {
+      set_error("mimo_backward: gradient buffer not bound");
+      return MIMO_ERR_STATE;
+    }
+    if (!dout && !dloss) {
+      set_error("mimo_backward: need dout and/or dloss");
+      return MIMO_ERR_INVALID;
+    }
+    if (dloss && !loss_done) {
+      set_error("mimo_backward: dloss given but mimo_loss_forward was not called");
+      return MIMO_ERR_STATE;
+    }
+    if (dx && had_perm) {
+      set_error("mimo_backward: dx requires a forward without perm");
+      return MIMO_ERR_INVALID;
+    }
+    for (auto& dc : dcs) dc->out.grad_writes = 0;
+    x2cat.grad_writes = 0;
+    if (!fwd_training) {  // eval-mode forward skipped the dgrad weight packing
+      for (auto& dc : dcs) {
+        MIMO_TRY(pack_layer(dc->c1, true, st));
+        MIMO_TRY(pack_layer(dc->c2, true, st));
+      }
+    }
+    const int fp = pad_channels(f);
+    for (int s = S - 1; s >= 0; --s) {
+      DoubleConv* dc = up4[s];
+      int rows = 0, chunks = 0;
+      MIMO_TRY(head_bwd_launch(dc->out.a, dc->out.ld, params + heads[s].off_w, f, fp, Co, N, S, s, H * W, out, dout, dloss,
+                               label, lmask, lperm, cfg.loss_kind, cfg.eps_min, cfg.eps_max, dc->out.da, s_partial, &rows,
+                               st));
+      MIMO_TRY(rowsum_launch(s_partial, rows, Co * fp + Co, s_sums, &chunks, st));
+      MIMO_TRY(head_bwd_finalize_launch(s_sums, chunks, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, st));
+      MIMO_TRY(dc_backward(dc, true, st));
+    }
+    MIMO_TRY(dc_backward(up3, true, st));
+    MIMO_TRY(dc_backward(up2, true, st));
+    MIMO_TRY(dc_backward(up1, true, st));
+    MIMO_TRY(dc_backward(down4, true, st));
+    MIMO_TRY(dc_backward(down3, true, st));
+    MIMO_TRY(dc_backward(down2, true, st));
+    for (int s = S - 1; s >= 0; --s) MIMO_TRY(dc_backward(down1[s], true, st));
+    for (int s = S - 1; s >= 0; --s) {
+      MIMO_TRY(dc_backward(enc_in[s], dx != nullptr, st));
+      if (dx) MIMO_TRY(unpack_dx_launch(s_dxpadB, Ci_p, N, S, s, Ci, H, W, dx, st));
+    }
+    return MIMO_OK;
+  }
+};
+
+// ======================================================================= C ABI ==========
+extern "C" {
+
+const char* mimo_last_error(void) { return mimo::last_error(); }
+int mimo_version(void) { return 1; }
+
+int mimo_plan_create(const mimo_config* cfg, mimo_plan** out) {
+  if (!cfg || !out) {
+    set_error("mimo_plan_create: null argument");
+    return MIMO_ERR_INVALID;
+  }
+  MIMO_HIP_CHECK(hipSetDevice(cfg->device));
+  auto p = std::make_unique<mimo_plan>();
+  p->cfg = *cfg;
+  const int rc = p->build();
+  if (rc != MIMO_OK) return rc;
+  MIMO_HIP_CHECK(hipDeviceSynchronize());
+  *out = p.release();
+  return MIMO_OK;
+}
+
+void mimo_plan_destroy(mimo_plan* plan) { delete plan; }
+size_t mimo_plan_workspace_bytes(const mimo_plan* plan) { return plan ? plan->bytes : 0; }
+int mimo_plan_num_tensors(const mimo_plan* plan) { return plan ? (int)plan->tensors.size() : 0; }
+int64_t mimo_plan_param_floats(const mimo_plan* plan) { return plan ? plan->param_floats : 0; }
+int64_t mimo_plan_buffer_floats(const mimo_plan* plan) { return plan ? plan->buffer_floats : 0; }
+int mimo_plan_num_double_convs(const mimo_plan* plan) { return plan ? (int)plan->dcs.size() : 0; }
+int mimo_plan_double_conv_channels(const mimo_plan* plan, int index) {
+  if (!plan || index < 0 || index >= (int)plan->dcs.size()) return -1;
+  return plan->dcs[index]->c2.Cout;
+}
+
+int mimo_plan_tensor_info(const mimo_plan* plan, int index, char* name, int name_cap, int64_t shape[4], int* ndim,
+                          int* kind, int64_t* offset) {
+  if (!plan || index < 0 || index >= (int)plan->tensors.size()) {
+    set_error("mimo_plan_tensor_info: bad index");
+    return MIMO_ERR_INVALID;
+  }
+  const TensorInfo& t = plan->tensors[index];
+  if (name && name_cap > 0) {
+    strncpy(name, t.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (shape)
+    for (int i = 0; i < 4; ++i) shape[i] = t.shape[i];
+  if (ndim) *ndim = t.ndim;
+  if (kind) *kind = t.kind;
+  if (offset) *offset = t.offset;
+  return MIMO_OK;
+}
+
+int mimo_plan_bind(mimo_plan* plan, float* params, float* grads, float* bn_buffers) {
+  if (!plan || !params || !bn_buffers) {
+    set_error("mimo_plan_bind: null argument");
+    return MIMO_ERR_INVALID;
+  }
+  plan->params = params;
+  plan->grads = grads;
+  plan->bnbuf = bn_buffers;
+  return MIMO_OK;
+}
+
+int mimo_forward(mimo_plan* plan, const mimo_forward_args* args, mimo_stream stream) {
+  if (!plan) {
+    set_error("mimo_forward: null plan");
+    return MIMO_ERR_INVALID;
+  }
+  return plan->forward(args, (hipStream_t)stream);
+}
+
+int mimo_loss_forward(mimo_plan* plan, const float* label, const float* mask, const int64_t* perm, float* loss_out,
+                      mimo_stream stream) {
+  if (!plan) {
+    set_error("mimo_loss_forward: null plan");
+    return MIMO_ERR_INVALID;
+  }
+  return plan->loss_forward(label, mask, perm, loss_out, (hipStream_t)stream);
+}
+
+int mimo_backward(mimo_plan* plan, const float* dout, const float* dloss, float* dx, mimo_stream stream) {
+  if (!plan) {
+    set_error("mimo_backward: null plan");
+    return MIMO_ERR_INVALID;
+  }
+  return plan->backward(dout, dloss, dx, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+"""Host-side handle on a `mimo_plan` (include/mimo_hip.h): geometry-specialised network
+executor living in libmimo_hip.so.  PyTorch is used here only as the owner of device
+memory and of the HIP stream; every computation is a C-ABI call."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+@dataclass(frozen=True)
+class TensorSpec:
+    name: str
+    shape: Tuple[int, ...]
+    kind: int  # 0 parameter, 1 BatchNorm running buffer
+    offset: int  # floats, into the flat parameter / buffer storage
+
+    @property
+    def numel(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+@dataclass(frozen=True)
+class NetGeometry:
+    in_channels: int
+    out_channels: int
+    num_subnetworks: int
+    filter_base_count: int
+    encoder_dropout_rate: float = 0.0
+    core_dropout_rate: float = 0.0
+    decoder_dropout_rate: float = 0.0
+    loss: str = "laplace_nll"
+
+
+class Plan:
+    """One plan per (network geometry, batch, height, width, device)."""
+
+    def __init__(self, geom: NetGeometry, batch: int, height: int, width: int, device: torch.device):
+        if device.type != "cuda":
+            raise L.MimoHipError("the MIMO U-Net engine runs on an AMD GPU only (no CPU fallback); got " + str(device))
+        self.lib = L.load()
+        self.geom, self.batch, self.height, self.width, self.device = geom, batch, height, width, device
+        cfg = L.MimoConfig(
+            geom.in_channels, geom.out_channels, geom.num_subnetworks, geom.filter_base_count, batch, height, width,
+            geom.encoder_dropout_rate, geom.core_dropout_rate, geom.decoder_dropout_rate,
+            1e-5, 0.1, L.LOSS_KINDS[geom.loss], 1e-5, 1e3, device.index or 0)
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            L.check(self.lib.mimo_plan_create(C.byref(cfg), C.byref(handle)), "mimo_plan_create")
+        self.handle = handle
+        self.specs = self._read_specs()
+        self.param_floats = int(self.lib.mimo_plan_param_floats(handle))
+        self.buffer_floats = int(self.lib.mimo_plan_buffer_floats(handle))
+        self.num_double_convs = int(self.lib.mimo_plan_num_double_convs(handle))
+        self.double_conv_channels = [int(self.lib.mimo_plan_double_conv_channels(handle, i))
+                                     for i in range(self.num_double_convs)]
+        self._bound = None
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                self.lib.mimo_plan_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+    def _read_specs(self) -> List[TensorSpec]:
+        out = []
+        n = self.lib.mimo_plan_num_tensors(self.handle)
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        ndim, kind, off = C.c_int(), C.c_int(), C.c_int64()
+        for i in range(n):
+            L.check(self.lib.mimo_plan_tensor_info(self.handle, i, name, 256, shape, C.byref(ndim), C.byref(kind),
+                                                   C.byref(off)), "mimo_plan_tensor_info")
+            out.append(TensorSpec(name.value.decode(), tuple(int(shape[j]) for j in range(ndim.value)), kind.value,
+                                  int(off.value)))
+        return out
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mimo_plan_workspace_bytes(self.handle))
+
+    def bind(self, params: torch.Tensor, grads: Optional[torch.Tensor], buffers: torch.Tensor) -> None:
+        key = (params.data_ptr(), 0 if grads is None else grads.data_ptr(), buffers.data_ptr())
+        if key == self._bound:
+            return
+        assert params.numel() >= self.param_floats and buffers.numel() >= self.buffer_floats
+        L.check(self.lib.mimo_plan_bind(self.handle, params.data_ptr(), L.ptr(grads), buffers.data_ptr()), "mimo_plan_bind")
+        self._bound = key
+
+    def forward(self, x: torch.Tensor, out: torch.Tensor, *, training: bool, perm: Optional[torch.Tensor] = None,
+                masks: Optional[Sequence[Optional[torch.Tensor]]] = None, broadcast_subnetworks: bool = False) -> None:
+        """x: [N,S,Ci,H,W] (or [N,Ci,H,W] with perm / broadcast) contiguous fp32 on the plan's device."""
+        g = self.geom
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        if x.dim() == 5:
+            stride_n, stride_s = x.stride(0), x.stride(1)
+        else:
+            assert perm is not None or broadcast_subnetworks or g.num_subnetworks == 1
+            stride_n, stride_s = x.stride(0), 0
+        mask_arr = None
+        if masks is not None and any(m is not None for m in masks):
+            assert len(masks) == self.num_double_convs
+            mask_arr = (C.c_void_p * self.num_double_convs)(*[L.ptr(m) or None for m in masks])
+        args = L.ForwardArgs(x.data_ptr(), stride_n, stride_s, L.ptr(perm) or None, int(training),
+                             C.cast(mask_arr, C.POINTER(C.c_void_p)) if mask_arr is not None else None, out.data_ptr())
+        L.check(self.lib.mimo_forward(self.handle, C.byref(args), L.current_stream()), "mimo_forward")
+
+    def loss_forward(self, label: torch.Tensor, mask: Optional[torch.Tensor], perm: Optional[torch.Tensor],
+                     loss_out: torch.Tensor) -> None:
+        L.check(self.lib.mimo_loss_forward(self.handle, label.data_ptr(), L.ptr(mask) or None, L.ptr(perm) or None,
+                                           loss_out.data_ptr(), L.current_stream()), "mimo_loss_forward")
+
+    def backward(self, dout: Optional[torch.Tensor], dloss: Optional[torch.Tensor], dx: Optional[torch.Tensor]) -> None:
+        L.check(self.lib.mimo_backward(self.handle, L.ptr(dout) or None, L.ptr(dloss) or None, L.ptr(dx) or None,
+                                       L.current_stream()), "mimo_backward")
+
+
+def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
+              betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, step: int, grad_scale: float = 1.0) -> None:
+    lib = L.load()
+    L.check(lib.mimo_adam_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                               params.numel(), lr, betas[0], betas[1], eps, weight_decay, step, grad_scale,
+                               L.current_stream()), "mimo_adam_step")
+
+
+def uncertainties(p1: torch.Tensor, p2: torch.Tensor, loss: str = "laplace_nll"):
+    """[N,S,C,H,W] x2 -> (mean, aleatoric_var, epistemic_var) each [N,C,H,W], on device."""
+    lib = L.load()
+    p1, p2 = p1.contiguous(), p2.contiguous()
+    n, s, c, h, w = p1.shape
+    outs = [torch.empty(n, c, h, w, device=p1.device, dtype=torch.float32) for _ in range(3)]
+    L.check(lib.mimo_uncertainties(p1.data_ptr(), p2.data_ptr(), n, s, c, h * w, L.LOSS_KINDS[loss], outs[0].data_ptr(),
+                                   outs[1].data_ptr(), outs[2].data_ptr(), L.current_stream()), "mimo_uncertainties")
+    return tuple(outs)

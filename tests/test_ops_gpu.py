@@ -1,0 +1,161 @@
+"""Per-kernel parity: HIP kernels (through the C ABI's mimo_op_* entry points) against the
+CPU oracle's leaf operators on the same seeded inputs.  Needs an MI355X."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mimo_oracle as O
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5  # fp32 implicit-GEMM vs fp32 direct conv: accumulation order only
+
+
+def _lib():
+    from mimo_unet_amd import _lib
+    return _lib
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def to_nhwc(x, cp):
+    n, c, h, w = x.shape
+    t = torch.zeros(n, h, w, cp, dtype=torch.float32)
+    t[..., :c] = x.permute(0, 2, 3, 1)
+    return t.cuda().contiguous()
+
+
+def from_nhwc(t, c):
+    return t[..., :c].permute(0, 3, 1, 2).contiguous().cpu()
+
+
+CONV_CASES = [
+    # (N, H, W, Cin, Cout)
+    (2, 32, 32, 2, 30), (2, 32, 32, 3, 21), (1, 64, 64, 30, 30), (2, 16, 16, 45, 30), (1, 32, 48, 90, 45),
+    (1, 16, 16, 120, 240), (2, 20, 12, 21, 42), (1, 50, 70, 8, 8), (3, 6, 7, 16, 33), (1, 2, 2, 8, 16),
+    (1, 3, 5, 4, 4), (1, 128, 128, 4, 60),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_forward_dgrad_wgrad(case):
+    L = _lib()
+    lib = L.load()
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3.0 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    dz = torch.randn(N, Co, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    z_ref = O.conv3x3_reflect(xr, wr, br)
+    z_ref.backward(dz)
+    cip, cop = (Ci + 3) // 4 * 4 if Ci <= 4 else pad8(Ci), pad8(Co)
+    st = L.current_stream()
+    xd, wd_, bd = to_nhwc(x, cip), w.cuda().contiguous(), b.cuda()
+    zd = torch.full((N, H, W, cop), float("nan"), device="cuda")
+    stats = torch.zeros(2, Co, dtype=torch.float64, device="cuda")
+    L.check(lib.mimo_op_conv3x3_forward(xd.data_ptr(), wd_.data_ptr(), bd.data_ptr(), zd.data_ptr(), stats.data_ptr(),
+                                        N, H, W, Ci, cip, Co, cop, st), "conv fwd")
+    torch.cuda.synchronize()
+    z = from_nhwc(zd, Co)
+    errs = {"fwd": rel_err(z, z_ref.detach())}
+    assert torch.all(zd[..., Co:] == 0), "padding channels of z must be exactly zero"
+    zr64 = z_ref.detach().double()
+    errs["sum"] = rel_err(stats[0].cpu(), zr64.sum(dim=(0, 2, 3))) if H * W > 4 else 0.0
+    errs["sumsq"] = rel_err(stats[1].cpu(), (zr64 * zr64).sum(dim=(0, 2, 3)))
+    # data gradient (transposed conv + fold of the reflect border)
+    dzd = to_nhwc(dz, cop)
+    dxd = torch.full((N, H, W, cip), float("nan"), device="cuda")
+    L.check(lib.mimo_op_conv3x3_dgrad(dzd.data_ptr(), wd_.data_ptr(), dxd.data_ptr(), N, H, W, Ci, cip, Co, cop, st),
+            "conv dgrad")
+    errs["dgrad"] = rel_err(from_nhwc(dxd, Ci), xr.grad)
+    # weight / bias gradient
+    dwd = torch.full((Co, Ci, 3, 3), float("nan"), device="cuda")
+    dbd = torch.full((Co,), float("nan"), device="cuda")
+    L.check(lib.mimo_op_conv3x3_wgrad(xd.data_ptr(), dzd.data_ptr(), dwd.data_ptr(), dbd.data_ptr(), N, H, W, Ci, cip,
+                                      Co, cop, st), "conv wgrad")
+    errs["wgrad"] = rel_err(dwd.cpu(), wr.grad)
+    errs["bgrad"] = rel_err(dbd.cpu(), br.grad)
+    print("conv", case, {k: f"{v:.2e}" for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 32, 32), (1, 8, 25, 51), (1, 24, 6, 6), (2, 8, 3, 2)])
+def test_maxpool(shape):
+    L = _lib()
+    lib = L.load()
+    N, Cc, H, W = shape
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(5))
+    cp = pad8(Cc)
+    xd = to_nhwc(x, cp)
+    yd = torch.full((N, H // 2, W // 2, cp), float("nan"), device="cuda")
+    L.check(lib.mimo_op_maxpool2x2(xd.data_ptr(), yd.data_ptr(), N, H, W, cp, L.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(yd, Cc), F.max_pool2d(x, 2))
+
+
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 16, 8, 8), (1, 8, 24, 25, 35, 12, 17), (1, 16, 8, 6, 7, 3, 3),
+                                  (1, 8, 8, 100, 100, 50, 50)])
+def test_upsample_cat(case):
+    L = _lib()
+    lib = L.load()
+    N, Cs, Cl, Hs, Ws, Hl, Wl = case
+    g = torch.Generator().manual_seed(9)
+    skip = torch.randn(N, Cs, Hs, Ws, generator=g)
+    low = torch.randn(N, Cl, Hl, Wl, generator=g)
+    ref = O.up_cat(low, skip)
+    sd, ld_ = to_nhwc(skip, Cs), to_nhwc(low, Cl)
+    od = torch.full((N, Hs, Ws, Cs + Cl), float("nan"), device="cuda")
+    L.check(lib.mimo_op_upsample_cat(sd.data_ptr(), ld_.data_ptr(), od.data_ptr(), N, Hs, Ws, Cs, Hl, Wl, Cl,
+                                     L.current_stream()))
+    torch.cuda.synchronize()
+    e = rel_err(from_nhwc(od, Cs + Cl), ref)
+    print("upcat", case, f"{e:.2e}")
+    assert e < 1e-6
+
+
+def test_adam_matches_torch():
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(1)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-3, weight_decay=1e-2)
+    p, m, v = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g)
+        p_ref.grad = grad.clone()
+        opt.step()
+        gd = grad.cuda()
+        L.check(lib.mimo_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8,
+                                   1e-2, step, 1.0, L.current_stream()))
+    torch.cuda.synchronize()
+    assert rel_err(p.cpu(), p_ref.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("S", [1, 2, 16])
+@pytest.mark.parametrize("kind", ["laplace_nll", "gaussian_nll"])
+def test_uncertainties(S, kind):
+    L = _lib()
+    lib = L.load()
+    g = torch.Generator().manual_seed(S)
+    p1 = torch.randn(3, S, 2, 9, 7, generator=g)
+    p2 = torch.randn(3, S, 2, 9, 7, generator=g)
+    ref = O.compute_uncertainties(kind, p1, p2)
+    a, b = p1.cuda(), p2.cuda()
+    outs = [torch.empty(3, 2, 9, 7, device="cuda") for _ in range(3)]
+    L.check(lib.mimo_uncertainties(a.data_ptr(), b.data_ptr(), 3, S, 2, 63, L.LOSS_KINDS[kind], outs[0].data_ptr(),
+                                   outs[1].data_ptr(), outs[2].data_ptr(), L.current_stream()))
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref):
+        assert rel_err(o.cpu(), r) < 1e-5
