@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MIMO U-Net training throughput (images/s) at 256x256, S=2, fbc=30.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = what Lightning runs per batch for the reference's `MimoUnetModel`
+(mimo/models/mimo_unet.py:115-144 + backward + Adam): draw the S batch permutations,
+forward (gather fused into the first kernel), Laplace NLL, loss-buffer weighting, backward,
+[gradient all-reduce over RCCL when N>1], fused Adam.  Synthetic U[0,1) inputs, PyTorch
+default random init, fp32 end to end.  Weak scaling: the per-GPU batch is fixed (32, the
+reference README's SEN12TP batch size; Lightning DDP semantics = per-device batch).
+
+Prints ONE JSON line on rank 0 with the throughput, the roofline of the dominant kernel class
+(device time from HIP events recorded around every launch inside the timed region) and — at
+N=1 — the CPU oracle timed on this box's host cores for the same workload shape.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[2] geometry; per-GPU batch 32 (README: --batch_size 32)
+    "cfg3": dict(name="cfg3: SEN12TP-shape synthetic 2->1 ch, 256x256, S=2, fbc=30, laplace_nll, batch 32 per GPU",
+                 Ci=2, Co=2, S=2, f=30, H=256, W=256, batch=32),
+    # BASELINE.json configs[1]
+    "cfg2": dict(name="cfg2: NYUv2-shape synthetic 3->1 ch, 256x256, S=2, fbc=21, laplace_nll, batch 64 per GPU",
+                 Ci=3, Co=2, S=2, f=21, H=256, W=256, batch=64),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the vector rate
+HBM_PEAK_GBS = 8000.0
+
+
+def make_model(c):
+    from mimo.models.mimo_unet import MimoUnetModel
+    return MimoUnetModel(in_channels=c["Ci"], out_channels=c["Co"], num_subnetworks=c["S"], filter_base_count=c["f"],
+                         center_dropout_rate=0.0, final_dropout_rate=0.0, encoder_dropout_rate=0.0, core_dropout_rate=0.0,
+                         decoder_dropout_rate=0.0, loss="laplace_nll", weight_decay=0.0, learning_rate=1e-3, seed=1,
+                         loss_buffer_size=10, loss_buffer_temperature=0.3)
+
+
+def cpu_baseline(c, batch=4, steps=2, threads=None):
+    """The CPU oracle (restatement of the reference's step, pinned to reference goldens) on the
+    host cores of this box: same network shape, bounded sample.  Thread count: torch's CPU
+    convolutions stop scaling (and collapse when oversubscribed) well below this box's core
+    count (measured on the 256-core GPU box: 8 thr 2.6, 16 thr 3.4, 32 thr 3.0, 64 thr 1.7, 128 thr 0.8
+    images/s), so the run uses min(cores, MIMO_BENCH_CPU_THREADS or 16) threads and reports that."""
+    from oracle import mimo_oracle as O
+    threads = threads or min(os.cpu_count() or 1, int(os.environ.get("MIMO_BENCH_CPU_THREADS", "16")))
+    torch.set_num_threads(threads)
+    cfg = O.NetConfig(c["Ci"], c["Co"], c["S"], c["f"])
+    ts = O.TrainState(cfg=cfg, st=O.init_state(cfg, 1), loss_buffer=O.LossBuffer(c["S"], 0.3, 10))
+    g = torch.Generator().manual_seed(1)
+    image = torch.rand(batch, c["Ci"], c["H"], c["W"], generator=g)
+    label = torch.rand(batch, c["Co"] // 2, c["H"], c["W"], generator=g)
+    times = []
+    for i in range(steps + 1):
+        perms = O.draw_perms(batch, c["S"], generator=g)
+        t0 = time.perf_counter()
+        O.train_step(ts, image, label, None, perms)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / steps
+    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed steps (1 warm-up) of the same network shape at batch {batch}, fp32, "
+                      f"torch {torch.__version__} CPU, {dt * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    c = dict(CONFIGS[args.config])
+    if args.batch:
+        c["batch"] = args.batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    torch.manual_seed(1)
+    model = make_model(c).cuda()
+    model.train()
+    opt = model.configure_optimizers()["optimizer"]
+    opt.grad_scale = 1.0 / world
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    B = c["batch"]
+    image = torch.rand(B, c["Ci"], c["H"], c["W"], device="cuda", generator=g)
+    label = torch.rand(B, c["Co"] // 2, c["H"], c["W"], device="cuda", generator=g)
+    batch = {"image": image, "label": label}
+
+    def step(i):
+        opt.zero_grad()
+        out = model.training_step(batch, i)
+        out["loss"].backward()
+        if world > 1:
+            dist.all_reduce(model.model.flat_gradients())  # sum; FlatAdam scales by 1/world
+        opt.step()
+        return out["loss"]
+
+    for i in range(args.warmup):
+        step(i)
+    plan = next(iter(model.model._plans.values()))
+    plan.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = plan.profile_read()
+    plan.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    kernels = {}
+    for name, r in prof.items():
+        if r["launches"] == 0:
+            continue
+        sec = r["ms"] * 1e-3
+        kernels[name] = {"avg_us": round(r["ms"] * 1e3 / r["launches"], 2), "launches_per_step": r["launches"] // args.steps,
+                         "ms_per_step": round(r["ms"] / args.steps, 3), "tflops": round(r["flops"] / sec / 1e12, 2),
+                         "algorithmic_gbs": round(r["bytes"] / sec / 1e9, 1)}
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "hbm_frac_algorithmic": round(kernels[dom]["algorithmic_gbs"] / HBM_PEAK_GBS, 4),
+                "conv_ms_per_step": round(sum(k["ms_per_step"] for k in kernels.values()), 2), "kernels": kernels}
+    line = {
+        "metric": "train images/sec at 256x256, S=2, fbc=30" if args.config == "cfg3" else f"train images/sec ({args.config})",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": c["name"], "global_batch": world * B, "per_gpu_batch": B, "image": [c["H"], c["W"]],
+                   "parallelism": f"dp{world}", "optimizer": "adam(lr=1e-3) fused", "final_loss": round(float(loss.detach()), 5)},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(c)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

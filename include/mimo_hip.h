@@ -106,6 +106,15 @@ int mimo_loss_forward(mimo_plan* plan, const float* label, const float* mask, co
  * Parameter gradients are written (not accumulated) into the bound flat grads buffer. */
 int mimo_backward(mimo_plan* plan, const float* dout, const float* dloss, float* dx, mimo_stream stream);
 
+/* ---- measurement (no reference counterpart): per-kernel-class device time from HIP events
+ * recorded on the launch stream around every 3x3 convolution launch, with the ALGORITHMIC
+ * flops (2*9*Cin*Cout*N*H*W, logical channels) and bytes ((Cin+Cout)*N*H*W*4) of those
+ * launches.  mimo_plan_profile(plan, 1) resets and arms; reads synchronise on the events. */
+enum mimo_prof_kind { MIMO_PROF_CONV_FWD = 0, MIMO_PROF_CONV_DGRAD = 1, MIMO_PROF_CONV_WGRAD = 2, MIMO_PROF_KINDS = 3 };
+int mimo_plan_profile(mimo_plan* plan, int enable);
+int mimo_plan_profile_read(mimo_plan* plan, int kind, double* total_ms, int64_t* launches, double* flops,
+                           double* bytes);
+
 /* ---- optimiser: replaces torch.optim.Adam.step (mimo_unet.py:186-190; L2-in-grad) ------ */
 int mimo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,

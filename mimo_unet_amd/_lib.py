@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must be imported before libmimo_hip.so is dlopen'ed: the PyTorch-ROCm wheel bundles its own
+# libamdhip64.so.7; loading ours first would bind the process to /opt/rocm's copy (same SONAME) and
+# leave torch and the engine on mismatched HIP runtimes ("no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmimo_hip.so")
 
@@ -55,6 +60,9 @@ _SIGNATURES = {
     "mimo_forward": (C.c_int, [_P, C.POINTER(ForwardArgs), _P]),
     "mimo_loss_forward": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "mimo_backward": (C.c_int, [_P, _P, _P, _P, _P]),
+    "mimo_plan_profile": (C.c_int, [_P, C.c_int]),
+    "mimo_plan_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double)]),
     "mimo_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "mimo_uncertainties": (C.c_int, [_P, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P]),
     "mimo_op_conv3x3_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

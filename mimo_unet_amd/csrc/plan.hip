@@ -119,6 +119,51 @@ struct mimo_plan {
   double* s_sums = nullptr;
   size_t cap_act = 0, cap_pad = 0, cap_slab = 0, cap_partial = 0, cap_sums = 0;
 
+  // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
+  struct ProfRec {
+    hipEvent_t a, b;
+    int kind;
+  };
+  bool prof_on = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+  double prof_ms[MIMO_PROF_KINDS] = {0, 0, 0}, prof_flops[MIMO_PROF_KINDS] = {0, 0, 0}, prof_bytes[MIMO_PROF_KINDS] = {0, 0, 0};
+  int64_t prof_launches[MIMO_PROF_KINDS] = {0, 0, 0};
+
+  void prof_begin(int kind, hipStream_t st) {
+    if (!prof_on) return;
+    ProfRec r;
+    if (!prof_pool.empty()) {
+      r.a = prof_pool.back().first;
+      r.b = prof_pool.back().second;
+      prof_pool.pop_back();
+    } else {
+      (void)hipEventCreate(&r.a);
+      (void)hipEventCreate(&r.b);
+    }
+    r.kind = kind;
+    (void)hipEventRecord(r.a, st);
+    prof_recs.push_back(r);
+  }
+  void prof_end(int kind, double flops, double bytes, hipStream_t st) {
+    if (!prof_on) return;
+    (void)hipEventRecord(prof_recs.back().b, st);
+    prof_flops[kind] += flops;
+    prof_bytes[kind] += bytes;
+    prof_launches[kind] += 1;
+  }
+  int prof_collect() {
+    for (auto& r : prof_recs) {
+      MIMO_HIP_CHECK(hipEventSynchronize(r.b));
+      float ms = 0.f;
+      MIMO_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+      prof_ms[r.kind] += ms;
+      prof_pool.emplace_back(r.a, r.b);
+    }
+    prof_recs.clear();
+    return MIMO_OK;
+  }
+
   // per-call state
   bool fwd_done = false, fwd_training = false, had_perm = false, loss_done = false;
   float* out = nullptr;
@@ -127,6 +172,14 @@ struct mimo_plan {
 
   ~mimo_plan() {
     for (void* p : allocs) (void)hipFree(p);
+    for (auto& r : prof_recs) {
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    for (auto& e : prof_pool) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
   }
 
   template <typename T>
@@ -415,8 +468,10 @@ struct mimo_plan {
     a.cout_store = L.cout_p;
     a.off = 1;
     int rows = 0;
-    MIMO_TRY(conv3x3_launch(a, &rows, st));
     const int64_t P = (int64_t)L.N * L.H * L.W;
+    prof_begin(MIMO_PROF_CONV_FWD, st);
+    MIMO_TRY(conv3x3_launch(a, &rows, st));
+    prof_end(MIMO_PROF_CONV_FWD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     if (training) {
       int chunks = 0;
       MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_pad, s_sums, &chunks, st));
@@ -534,7 +589,9 @@ struct mimo_plan {
     wg.cin_pad = L.wg_cin_pad;
     wg.cout_pad = L.wg_cout_pad;
     wg.splits = L.wg_splits;
+    prof_begin(MIMO_PROF_CONV_WGRAD, st);
     MIMO_TRY(wgrad_launch(wg, st));
+    prof_end(MIMO_PROF_CONV_WGRAD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
                                  grads + L.off_w, st));
     if (need_dgrad) {
@@ -555,7 +612,9 @@ struct mimo_plan {
       a.cout_pad = L.dg_rows;
       a.cout_store = L.cin_p;
       a.off = 2;
+      prof_begin(MIMO_PROF_CONV_DGRAD, st);
       MIMO_TRY(conv3x3_launch(a, nullptr, st));
+      prof_end(MIMO_PROF_CONV_DGRAD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     }
     return MIMO_OK;
   }
@@ -690,6 +749,35 @@ int mimo_plan_bind(mimo_plan* plan, float* params, float* grads, float* bn_buffe
   plan->params = params;
   plan->grads = grads;
   plan->bnbuf = bn_buffers;
+  return MIMO_OK;
+}
+
+int mimo_plan_profile(mimo_plan* plan, int enable) {
+  if (!plan) {
+    set_error("mimo_plan_profile: null plan");
+    return MIMO_ERR_INVALID;
+  }
+  MIMO_TRY(plan->prof_collect());
+  plan->prof_on = enable != 0;
+  if (enable) {
+    for (int k = 0; k < MIMO_PROF_KINDS; ++k) {
+      plan->prof_ms[k] = plan->prof_flops[k] = plan->prof_bytes[k] = 0.0;
+      plan->prof_launches[k] = 0;
+    }
+  }
+  return MIMO_OK;
+}
+
+int mimo_plan_profile_read(mimo_plan* plan, int kind, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+  if (!plan || kind < 0 || kind >= MIMO_PROF_KINDS) {
+    set_error("mimo_plan_profile_read: bad argument");
+    return MIMO_ERR_INVALID;
+  }
+  MIMO_TRY(plan->prof_collect());
+  if (total_ms) *total_ms = plan->prof_ms[kind];
+  if (launches) *launches = plan->prof_launches[kind];
+  if (flops) *flops = plan->prof_flops[kind];
+  if (bytes) *bytes = plan->prof_bytes[kind];
   return MIMO_OK;
 }
 

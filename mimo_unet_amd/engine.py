@@ -125,6 +125,21 @@ class Plan:
                                        L.current_stream()), "mimo_backward")
 
 
+    PROF_KINDS = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")
+
+    def profile(self, enable: bool) -> None:
+        L.check(self.lib.mimo_plan_profile(self.handle, int(enable)), "mimo_plan_profile")
+
+    def profile_read(self) -> Dict[str, Dict[str, float]]:
+        res = {}
+        for k, name in enumerate(self.PROF_KINDS):
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            L.check(self.lib.mimo_plan_profile_read(self.handle, k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)),
+                    "mimo_plan_profile_read")
+            res[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return res
+
+
 def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, step: int, grad_scale: float = 1.0) -> None:
     lib = L.load()

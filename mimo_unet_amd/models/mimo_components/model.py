@@ -1,0 +1,320 @@
+"""`MimoUNet` with the reference's constructor, tensor contract and state_dict, executed by
+libmimo_hip.so.
+
+Interface mirrored: ``mimo/models/mimo_components/model.py:26-117`` (``MimoUNet``) of the
+reference — ``forward([B,S,C_in,H,W]) -> [B,S,C_out,H,W]``, ``parameters()``,
+``state_dict()`` with the reference's names and OIHW shapes, ``modules()`` exposing the
+``Dropout*`` children that ``EnsembleModule._activate_mc_dropout`` toggles
+(``mimo/models/ensemble.py:54-66``).
+
+The nn.Module tree below only *holds* parameters (stock torch layers used as named
+containers, constructed in the reference's order so a given seed yields the same
+initial values); no torch layer is ever called.  Execution: parameters live in one flat
+device buffer bound to a `mimo_plan`; forward / backward are single C-ABI calls wrapped
+in a `torch.autograd.Function`."""
+from __future__ import annotations
+
+import logging
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from ... import _lib as L
+from ...engine import NetGeometry, Plan
+
+logger = logging.getLogger(__name__)
+
+
+# ----------------------------------------------------------------------------------------
+# parameter holders (names == reference state_dict names)
+# ----------------------------------------------------------------------------------------
+def _conv_bn_relu(cin: int, cout: int) -> List[nn.Module]:
+    return [nn.Conv2d(cin, cout, kernel_size=3, padding=1, padding_mode="reflect"), nn.BatchNorm2d(cout),
+            nn.ReLU(inplace=True)]
+
+
+class DoubleConv(nn.Module):
+    """Holder for (conv3x3 reflect -> BN -> ReLU) x 2 -> Dropout2d."""
+
+    def __init__(self, in_channels: int, out_channels: int, dropout_rate: float = 0.0, mid_channels: Optional[int] = None):
+        super().__init__()
+        mid = mid_channels or out_channels
+        self.double_conv = nn.Sequential(*_conv_bn_relu(in_channels, mid), *_conv_bn_relu(mid, out_channels),
+                                         nn.Dropout2d(dropout_rate))
+
+    @property
+    def dropout(self) -> nn.Dropout2d:
+        return self.double_conv[6]
+
+    @property
+    def norm(self) -> nn.BatchNorm2d:
+        return self.double_conv[1]
+
+
+class Down(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, dropout_rate: float = 0.0):
+        super().__init__()
+        self.conv = DoubleConv(in_channels, out_channels, dropout_rate=dropout_rate)
+
+
+class Up(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, dropout_rate: float = 0.0):
+        super().__init__()
+        self.conv = DoubleConv(in_channels, out_channels, dropout_rate=dropout_rate, mid_channels=in_channels // 2)
+
+
+class OutConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+
+class SubnetworkEncoder(nn.Module):
+    def __init__(self, S: int, in_channels: int, f: int, p: float):
+        super().__init__()
+        self.in_convs = nn.ModuleList([DoubleConv(in_channels, f, dropout_rate=p) for _ in range(S)])
+        self.down1s = nn.ModuleList([Down(f, 2 * f, dropout_rate=p) for _ in range(S)])
+
+
+class SubnetworkCore(nn.Module):
+    def __init__(self, S: int, f: int, p: float, center_p: float):
+        super().__init__()
+        w = f * S
+        self.down2 = Down(2 * w, 4 * w, dropout_rate=p)
+        self.down3 = Down(4 * w, 8 * w, dropout_rate=p)
+        self.down4 = Down(8 * w, 8 * w, dropout_rate=p)
+        self.center_dropout = nn.Dropout(p=center_p)
+        self.up1 = Up(16 * w, 4 * w, dropout_rate=p)
+        self.up2 = Up(8 * w, 2 * w, dropout_rate=p)
+        self.up3 = Up(4 * w, w, dropout_rate=p)
+
+
+class SubnetworkDecoder(nn.Module):
+    def __init__(self, S: int, f: int, out_channels: int, p: float, final_p: float):
+        super().__init__()
+        self.up4s = nn.ModuleList([Up(f * S + f, f, dropout_rate=p) for _ in range(S)])
+        self.final_dropouts = nn.ModuleList([nn.Dropout(p=final_p) for _ in range(S)])
+        self.outcs = nn.ModuleList([OutConv(f, out_channels) for _ in range(S)])
+
+
+# ----------------------------------------------------------------------------------------
+# autograd bridge
+# ----------------------------------------------------------------------------------------
+class _NetFunction(torch.autograd.Function):
+    """out (and optionally the per-subnetwork loss vector) = net(x); gradients through the C ABI."""
+
+    @staticmethod
+    def forward(ctx, net: "MimoUNet", x, label, lmask, perm, masks, bn_training, *params):
+        ctx.set_materialize_grads(False)
+        plan = net._plan_for(x, perm)
+        n = plan.batch
+        S, Co = net.num_subnetworks, net.out_channels
+        out = torch.empty(n, S, Co, plan.height, plan.width, device=x.device, dtype=torch.float32)
+        plan.bind(net._flat_params, net._flat_grads, net._flat_buffers)
+        plan.forward(x, out, training=bn_training, perm=perm, masks=masks)
+        if label is not None:
+            loss = torch.empty(S, device=x.device, dtype=torch.float32)
+            plan.loss_forward(label, lmask, perm, loss)
+        else:
+            loss = torch.zeros(0, device=x.device, dtype=torch.float32)
+        plan.generation += 1
+        ctx.net, ctx.plan, ctx.generation = net, plan, plan.generation
+        ctx.keep = (x, label, lmask, perm, masks, out)  # device memory the plan still points at
+        ctx.x_shape = x.shape
+        ctx.has_loss = label is not None
+        ctx.mark_non_differentiable(*[])
+        return out, loss
+
+    @staticmethod
+    def backward(ctx, dout, dloss):
+        net, plan = ctx.net, ctx.plan
+        n_in = 7 + len(net._param_list)
+        if dout is None and (dloss is None or not ctx.has_loss):
+            return (None,) * n_in
+        if plan.generation != ctx.generation:
+            raise RuntimeError("MimoUNet: backward() after a newer forward() of the same shape — the engine keeps one "
+                               "set of saved activations per input geometry")
+        x = ctx.keep[0]
+        dx = None
+        if ctx.needs_input_grad[1]:
+            if ctx.keep[3] is not None or x.dim() != 5:
+                raise RuntimeError("MimoUNet: input gradients need the [B,S,C,H,W] forward without a fused permutation")
+            dx = torch.empty(ctx.x_shape, device=x.device, dtype=torch.float32)
+        dout_c = None if dout is None else dout.contiguous().float()
+        dloss_c = None if (dloss is None or not ctx.has_loss) else dloss.contiguous().float()
+        net._run_backward(plan, dout_c, dloss_c, dx)
+        return (None, dx, None, None, None, None, None) + (None,) * len(net._param_list)
+
+
+class MimoUNet(nn.Module):
+    """Multiple-input multiple-output U-Net: S private encoders -> shared core on the channel
+    concat -> S private decoders/heads.  Same constructor as the reference's class."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_subnetworks: int, filter_base_count: int = 30,
+                 center_dropout_rate: float = 0.0, final_dropout_rate: float = 0.0, encoder_dropout_rate: float = 0.0,
+                 core_dropout_rate: float = 0.0, decoder_dropout_rate: float = 0.0, bilinear: bool = True,
+                 use_pooling_indices: bool = False, loss: str = "laplace_nll"):
+        spatial = encoder_dropout_rate > 0.0 or core_dropout_rate > 0.0 or decoder_dropout_rate > 0.0
+        if spatial and (center_dropout_rate > 0.0 or final_dropout_rate > 0.0):
+            raise ValueError("Do not specify spatial_dropout together with center_dropout_rate or final_dropout_rate!")
+        if not bilinear or use_pooling_indices:
+            raise NotImplementedError("only bilinear=True, use_pooling_indices=False (what MimoUnetModel hard-wires)")
+        if center_dropout_rate > 0.0 or final_dropout_rate > 0.0:
+            raise NotImplementedError("element-wise center/final dropout is not implemented in the HIP engine yet")
+        super().__init__()
+        logger.info("Creating MimoUNet(HIP): in=%d out=%d S=%d f=%d dropout enc/core/dec=%g/%g/%g", in_channels, out_channels,
+                    num_subnetworks, filter_base_count, encoder_dropout_rate, core_dropout_rate, decoder_dropout_rate)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_subnetworks, self.filter_base_count = num_subnetworks, filter_base_count
+        S, f = num_subnetworks, filter_base_count
+        self.encoder = SubnetworkEncoder(S, in_channels, f, encoder_dropout_rate)
+        self.core = SubnetworkCore(S, f, core_dropout_rate, center_dropout_rate)
+        self.decoder = SubnetworkDecoder(S, f, out_channels, decoder_dropout_rate, final_dropout_rate)
+        self._geom = NetGeometry(in_channels, out_channels, S, f, encoder_dropout_rate, core_dropout_rate,
+                                 decoder_dropout_rate, loss)
+        self._plans: Dict[tuple, Plan] = {}
+        self._flat_params = self._flat_grads = self._flat_buffers = None
+        self._param_list: List[nn.Parameter] = []
+        self._flat_device = None
+        self.mask_override: Optional[Dict[int, torch.Tensor]] = None  # tests: {double-conv index: [N,C] multipliers}
+
+    # ---- execution order of the DoubleConvs == mimo_plan's (engine) order -----------------
+    def double_convs(self) -> List[DoubleConv]:
+        c = self.core
+        return ([m for m in self.encoder.in_convs] + [d.conv for d in self.encoder.down1s]
+                + [c.down2.conv, c.down3.conv, c.down4.conv, c.up1.conv, c.up2.conv, c.up3.conv]
+                + [u.conv for u in self.decoder.up4s])
+
+    def set_loss(self, loss: str) -> None:
+        if loss != self._geom.loss:
+            self._geom = NetGeometry(**{**self._geom.__dict__, "loss": loss})
+            self._plans.clear()
+
+    # ---- flat storage ---------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._flat_params = None  # .to()/.cuda() re-created the tensors: re-flatten lazily
+        self._plans = {}
+        return r
+
+    def _ensure_flat(self, plan: Plan, device) -> None:
+        named_p = dict(self.named_parameters())
+        named_b = dict(self.named_buffers())
+        first = plan.specs[0]
+        ok = (self._flat_params is not None and self._flat_device == device
+              and named_p[first.name].data_ptr() == self._flat_params.data_ptr() + 4 * first.offset)
+        if ok:
+            return
+        fp = torch.zeros(plan.param_floats, device=device, dtype=torch.float32)
+        fb = torch.zeros(plan.buffer_floats, device=device, dtype=torch.float32)
+        plist = []
+        for sp in plan.specs:
+            src = named_p[sp.name] if sp.kind == 0 else named_b[sp.name]
+            if tuple(src.shape) != sp.shape:
+                raise RuntimeError(f"{sp.name}: shape {tuple(src.shape)} != engine shape {sp.shape}")
+            flat = fp if sp.kind == 0 else fb
+            view = flat[sp.offset: sp.offset + sp.numel].view(sp.shape)
+            view.copy_(src.data)
+            src.data = view
+            if sp.kind == 0:
+                plist.append(src)
+        missing = set(named_p) - {sp.name for sp in plan.specs}
+        if missing:
+            raise RuntimeError(f"parameters unknown to the engine: {sorted(missing)[:4]}")
+        self._flat_params, self._flat_buffers = fp, fb
+        self._flat_grads = torch.zeros_like(fp)
+        self._param_list = plist
+        self._param_views = [(p, self._flat_grads[sp.offset: sp.offset + sp.numel].view(sp.shape))
+                             for p, sp in zip(plist, [s for s in plan.specs if s.kind == 0])]
+        self._flat_device = device
+
+    def _plan_for(self, x: torch.Tensor, perm: Optional[torch.Tensor]) -> Plan:
+        if not x.is_cuda:
+            raise L.MimoHipError("MimoUNet runs on an AMD GPU through libmimo_hip.so; move the module and its inputs "
+                                 "to cuda (there is no CPU execution path)")
+        n = perm.shape[1] if perm is not None else x.shape[0]
+        key = (n, x.shape[-2], x.shape[-1], x.device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = Plan(self._geom, n, x.shape[-2], x.shape[-1], x.device)
+            plan.generation = 0
+            self._plans[key] = plan
+        self._ensure_flat(plan, x.device)
+        return plan
+
+    # ---- dropout masks (Dropout2d: one Bernoulli per (sample, channel), components.py:29) --
+    def _dropout_masks(self, n: int, device) -> Optional[List[Optional[torch.Tensor]]]:
+        masks, any_mask = [], False
+        for i, dc in enumerate(self.double_convs()):
+            d = dc.dropout
+            m = None
+            if self.mask_override is not None and i in self.mask_override:
+                m = self.mask_override[i].to(device=device, dtype=torch.float32).contiguous()
+            elif d.p > 0.0 and d.training:
+                c = dc.double_conv[3].out_channels
+                m = torch.bernoulli(torch.full((n, c), 1.0 - d.p, device=device)).div_(1.0 - d.p)
+            any_mask |= m is not None
+            masks.append(m)
+        return masks if any_mask else None
+
+    def _bn_training(self) -> bool:
+        return self.encoder.in_convs[0].norm.training
+
+    def _bump_batch_counters(self) -> None:
+        for dc in self.double_convs():
+            dc.double_conv[1].num_batches_tracked += 1
+            dc.double_conv[4].num_batches_tracked += 1
+
+    # ---- forward ----------------------------------------------------------------------------
+    def _call(self, x, label, lmask, perm):
+        x = x.contiguous().float()
+        n = perm.shape[1] if perm is not None else x.shape[0]
+        bn_training = self._bn_training()
+        masks = self._dropout_masks(n, x.device)
+        # make sure the flat storage exists before the parameters are handed to autograd
+        self._plan_for(x, perm)
+        out, loss = _NetFunction.apply(self, x, label, lmask, perm, masks, bn_training, *self._param_list)
+        if bn_training:
+            self._bump_batch_counters()
+        return out, loss
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B,S,C_in,H,W] -> predictions [B,S,C_out,H,W]."""
+        if x.dim() != 5 or x.shape[1] != self.num_subnetworks or x.shape[2] != self.in_channels:
+            raise ValueError(f"expected [B,{self.num_subnetworks},{self.in_channels},H,W], got {tuple(x.shape)}")
+        return self._call(x, None, None, None)[0]
+
+    def forward_with_loss(self, image: torch.Tensor, label: torch.Tensor, mask: Optional[torch.Tensor],
+                          perms: Optional[torch.Tensor]):
+        """Fused training entry: `image` [B,C,H,W] gathered per subnetwork through `perms` [S,B'] inside
+        the first kernel (or [B,S,C,H,W] with perms=None), plus the per-subnetwork mean NLL [S]."""
+        label = label.contiguous().float()
+        mask = None if mask is None else mask.contiguous().float()
+        perms = None if perms is None else perms.to(device=image.device, dtype=torch.int64).contiguous()
+        return self._call(image, label, mask, perms)
+
+    def _run_backward(self, plan: Plan, dout, dloss, dx) -> None:
+        g = self._flat_grads
+        views = self._param_views
+        # torch semantics: gradients accumulate until zero_grad().  The engine overwrites the flat
+        # buffer, so keep a copy when a live .grad still aliases it.
+        aliased = any(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in views)
+        saved = g.clone() if aliased else None
+        plan.bind(self._flat_params, g, self._flat_buffers)
+        plan.backward(dout, dloss, dx)
+        for p, v in views:
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() == v.data_ptr():
+                off = (v.data_ptr() - g.data_ptr()) // 4
+                v.add_(saved[off: off + v.numel()].view(v.shape))
+            else:
+                p.grad.add_(v)
+
+    # flat views for the fused optimiser / gradient all-reduce
+    def flat_parameters(self) -> torch.Tensor:
+        return self._flat_params
+
+    def flat_gradients(self) -> torch.Tensor:
+        return self._flat_grads
