@@ -108,12 +108,15 @@ def main():
     label = torch.rand(B, c["Co"] // 2, c["H"], c["W"], device="cuda", generator=g)
     batch = {"image": image, "label": label}
 
+    from mimo_unet_amd.ddp import FlatGradientAllReducer
+    reducer = FlatGradientAllReducer() if world > 1 else None
+
     def step(i):
         opt.zero_grad()
         out = model.training_step(batch, i)
         out["loss"].backward()
-        if world > 1:
-            dist.all_reduce(model.model.flat_gradients())  # sum; FlatAdam scales by 1/world
+        if reducer is not None:
+            reducer.all_reduce(model.model.flat_gradients())  # bucketed sum over RCCL; FlatAdam scales by 1/world
         opt.step()
         return out["loss"]
 

@@ -1,0 +1,172 @@
+"""CPU-side checks of the host mirror and of the C-ABI library (no GPU needed): interface
+parity with the reference's module surface, golden-pinned host arithmetic, exported symbols,
+and the data-parallel plumbing over gloo with world_size 2."""
+import argparse
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_npz
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mimo_unet_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "mimo_hip.h")).read()
+    declared = set(re.findall(r"\b(mimo_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mimo_plan"}  # typedef
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libmimo_hip.so does not export {name}"
+    assert set(_lib.EXPORTED_SYMBOLS) <= declared
+    assert lib.mimo_version() >= 1
+
+
+def test_no_cpu_execution_path():
+    from mimo.models.mimo_components.model import MimoUNet
+    from mimo_unet_amd._lib import MimoHipError
+    net = MimoUNet(3, 2, 1, 4)
+    with pytest.raises(MimoHipError):
+        net(torch.zeros(1, 1, 3, 32, 32))
+
+
+def test_seeded_init_and_state_dict_match_reference():
+    from mimo.models.mimo_components.model import MimoUNet
+    for name in ("cfg1_step.npz", "mini_s2_step.npz"):
+        fx = load_npz(name)
+        Ci, Co, S, f = (int(v) for v in fx["meta"][:4])
+        torch.manual_seed(1 if name.startswith("cfg1") else 2)
+        net = MimoUNet(Ci, Co, S, f)
+        sd = net.state_dict()
+        ref = {k[len("init/"):]: v for k, v in fx.items() if k.startswith("init/")}
+        assert list(sd.keys()) == list(ref.keys())  # same names, same order as the reference's state_dict
+        for k, v in ref.items():
+            assert np.array_equal(sd[k].numpy(), v), k
+
+
+def test_constructor_contract():
+    from mimo.models.mimo_components.model import MimoUNet
+    with pytest.raises(ValueError):
+        MimoUNet(3, 2, 2, 4, encoder_dropout_rate=0.1, center_dropout_rate=0.1)
+    net = MimoUNet(3, 2, 2, 4, encoder_dropout_rate=0.1, core_dropout_rate=0.1, decoder_dropout_rate=0.1)
+    drops = [m for m in net.modules() if m.__class__.__name__.startswith("Dropout")]
+    assert len(drops) == len(net.double_convs()) + 1 + 2  # + center_dropout + S final_dropouts
+
+
+def test_loss_classes_match_reference_golden():
+    from mimo.losses import GaussianNLL, LaplaceNLL, UncertaintyLoss
+    fx = load_npz("losses.npz")
+    mu, y, ls, mask = (torch.from_numpy(fx[k]) for k in ("mu", "y", "ls", "mask"))
+    for kind, crit in (("laplace", LaplaceNLL()), ("gaussian", GaussianNLL())):
+        a, b = mu.clone().requires_grad_(True), ls.clone().requires_grad_(True)
+        raw = crit.forward(a, b, y, reduce_mean=False, mask=mask)
+        raw.sum().backward()
+        np.testing.assert_allclose(raw.detach().numpy(), fx[kind + "/raw"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(a.grad.numpy(), fx[kind + "/dmu"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(b.grad.numpy(), fx[kind + "/dls"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(crit.forward(mu, ls, y).numpy(), fx[kind + "/mean"], rtol=1e-6)
+        np.testing.assert_allclose(crit.std(mu, ls).numpy(), fx[kind + "/std"], rtol=1e-6)
+        np.testing.assert_allclose(crit.calculate_dist_param(crit.std(mu, ls), log=True).numpy(),
+                                   fx[kind + "/dist_param_log"], rtol=1e-5, atol=1e-6)
+        assert crit.num_distribution_params == 2 and crit.mode(mu, ls) is mu
+    assert isinstance(UncertaintyLoss.from_name("laplace_nll"), LaplaceNLL)
+    with pytest.raises(ValueError):
+        UncertaintyLoss.from_name("huber")
+
+
+def test_loss_buffer_matches_reference_golden():
+    from mimo.models.mimo_components.loss_buffer import LossBuffer
+    fx = load_npz("losses.npz")
+    lb = LossBuffer(subnetworks=3, temperature=0.3, buffer_size=10)
+    for i, row in enumerate(torch.from_numpy(fx["lossbuf/seq"])):
+        np.testing.assert_allclose(lb.get_weights().numpy(), fx["lossbuf/weights"][i], rtol=1e-6)
+        lb.add(row)
+    np.testing.assert_allclose(lb.buffer.numpy(), fx["lossbuf/final"])
+    lb0 = LossBuffer(subnetworks=2, temperature=1.0, buffer_size=0)
+    lb0.add(torch.ones(2))
+    np.testing.assert_allclose(lb0.get_weights().numpy(), fx["lossbuf/size0_weights"])
+
+
+def test_permutation_draw_replays_reference():
+    from mimo.models.utils import apply_input_transform, flatten_subnetwork_dimension, repeat_subnetworks
+    from mimo_unet_amd.models.utils import draw_subnetwork_permutations
+    fx = load_npz("mini_s2_step.npz")
+    torch.manual_seed(1000 + 2)
+    perms = draw_subnetwork_permutations(3, 2)
+    assert np.array_equal(perms.numpy(), fx["s0/perms"])  # same RNG consumption as utils.py:27-36
+    img = torch.from_numpy(fx["s0/image"])
+    torch.manual_seed(1000 + 2)
+    xt, yt, mt = apply_input_transform(img, torch.from_numpy(fx["s0/label"]), None, num_subnetworks=2)
+    assert torch.equal(xt, torch.stack([img[perms[s]] for s in range(2)], 1)) and mt is None
+    assert repeat_subnetworks(img, 4).shape == (3, 4, 2, 32, 32)
+    assert flatten_subnetwork_dimension(xt).shape == (6, 2, 32, 32)
+    torch.manual_seed(0)
+    p = draw_subnetwork_permutations(4, 3, input_repetition_probability=0.5, batch_repetitions=2)
+    assert p.shape == (3, 8) and torch.equal(p[0, 4:], p[1, 4:]) and torch.equal(p[0, 4:], p[2, 4:])
+
+
+def test_lightning_surface_and_checkpoint_roundtrip(tmp_path):
+    from mimo.models.mimo_unet import MimoUnetModel
+    parser = MimoUnetModel.add_model_specific_args(argparse.ArgumentParser())
+    a = parser.parse_args([])
+    assert (a.num_subnetworks, a.filter_base_count, a.loss, a.learning_rate, a.loss_buffer_size,
+            a.loss_buffer_temperature, a.scheduler_step_size, a.scheduler_gamma) == (3, 32, "laplace_nll", 1e-3, 10, 1.0, 20, 0.5)
+    kw = dict(in_channels=3, out_channels=2, num_subnetworks=2, filter_base_count=4, center_dropout_rate=0.0,
+              final_dropout_rate=0.0, encoder_dropout_rate=0.0, core_dropout_rate=0.0, decoder_dropout_rate=0.0,
+              loss="laplace_nll", weight_decay=0.0, learning_rate=1e-3, seed=1, loss_buffer_size=10,
+              loss_buffer_temperature=0.3)
+    m = MimoUnetModel(**kw)
+    assert m.hparams["trainable_params"] == sum(p.numel() for p in m.model.parameters())
+    assert m.hparams["loss"] == "laplace_nll" and m.compile() is m
+    cfgd = m.configure_optimizers()
+    assert set(cfgd) == {"optimizer", "lr_scheduler", "monitor"} and cfgd["monitor"] == "val_loss"
+    assert isinstance(cfgd["lr_scheduler"], torch.optim.lr_scheduler.StepLR)
+    path = os.path.join(tmp_path, "m.ckpt")
+    ck = m.checkpoint_dict() if hasattr(m, "checkpoint_dict") else {"state_dict": m.state_dict(), "hyper_parameters": dict(m.hparams)}
+    ck["state_dict"] = {k.replace("model.", "model._orig_mod.", 1): v for k, v in ck["state_dict"].items()}  # compiled-reference ckpt
+    torch.save(ck, path)
+    m2 = MimoUnetModel.load_from_checkpoint(path)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from mimo_unet_amd.ddp import FlatGradientAllReducer, shard_batch
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    full = {"image": torch.rand(8, 2, 4, 4, generator=g), "label": torch.rand(8, 1, 4, 4, generator=g), "mask": None}
+    shard = shard_batch(full, rank, world)
+    # stand-in per-rank "gradient": a deterministic function of the shard, 1000 floats
+    flat = torch.cat([shard["image"].flatten(), shard["label"].flatten()]).repeat(7)[:1000].clone()
+    local = flat.clone()
+    red = FlatGradientAllReducer(bucket_bytes=256 * 4)  # 4 buckets
+    red.start(flat, 0, 500)
+    red.start(flat, 500)
+    red.finish()
+    q.put((rank, local, flat.clone(), red.scale, shard["image"].shape[0]))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 500
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, r0, s0, n0), (_, l1, r1, s1, n1) = res
+    assert n0 == n1 == 4 and s0 == s1 == 0.5
+    assert torch.allclose(r0, l0 + l1) and torch.equal(r0, r1)          # every rank holds the sum
+    assert torch.allclose(r0 * s0, (l0 + l1) / 2)                        # optimiser sees the mean of the shard grads
