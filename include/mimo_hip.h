@@ -30,6 +30,14 @@ enum mimo_status {
   MIMO_ERR_STATE = -3    /* call order violated (e.g. backward before forward) */
 };
 
+/* Arithmetic of the 3x3 convolutions (storage, BatchNorm statistics and the loss are always fp32).
+ * MIMO_PREC_FP32: f32-input MFMA everywhere (bit-exact fp32 fma chains).
+ * MIMO_PREC_SPLIT16: each fp32 operand is split into a 16-bit hi + lo pair and every product block
+ *   is three 16-bit MFMAs with fp32 accumulation: fp16 pairs in the forward convolution (~2^-22 per
+ *   product: fp32-class outputs), bf16 pairs (fp32 exponent range, ~1e-5 per product) in the data
+ *   and weight gradients. */
+enum mimo_precision { MIMO_PREC_FP32 = 0, MIMO_PREC_SPLIT16 = 1 };
+
 enum mimo_loss_kind { MIMO_LOSS_LAPLACE_NLL = 0, MIMO_LOSS_GAUSSIAN_NLL = 1 };
 
 /* Constructor arguments of mimo.models.mimo_components.model.MimoUNet (model.py:31-44) plus
@@ -46,6 +54,7 @@ typedef struct mimo_config {
   int32_t loss_kind;         /* mimo_loss_kind; mimo/losses.py:39,124 */
   float eps_min, eps_max;    /* clamp of the scale/variance, losses.py:42-45,127-130: 1e-5, 1e3 */
   int32_t device;            /* HIP device ordinal */
+  int32_t precision;         /* mimo_precision: arithmetic of the 3x3 forward / data-gradient convolutions */
 } mimo_config;
 
 const char* mimo_last_error(void);
@@ -129,11 +138,12 @@ int mimo_uncertainties(const float* p1, const float* p2, int32_t n, int32_t s, i
  * They run the same kernels the plan runs.  x [N,H,W,cin_p], w OIHW [cout][cin][3][3]. */
 int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, float* z, double* stats,
                             int32_t n, int32_t h, int32_t wd, int32_t cin, int32_t cin_p, int32_t cout,
-                            int32_t cout_p, mimo_stream stream);
+                            int32_t cout_p, int32_t precision, mimo_stream stream);
 int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n, int32_t h, int32_t wd,
-                          int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p, mimo_stream stream);
+                          int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p, int32_t precision,
+                          mimo_stream stream);
 int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbias, int32_t n, int32_t h,
-                          int32_t wd, int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p,
+                          int32_t wd, int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p, int32_t precision,
                           mimo_stream stream);
 int mimo_op_maxpool2x2(const float* x, float* y, int32_t n, int32_t h, int32_t w, int32_t c_p, mimo_stream stream);
 int mimo_op_upsample_cat(const float* skip, const float* low, float* out, int32_t n, int32_t hs, int32_t ws,

@@ -27,7 +27,7 @@ class MimoConfig(C.Structure):
         ("filter_base_count", C.c_int32), ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
         ("encoder_dropout_rate", C.c_float), ("core_dropout_rate", C.c_float), ("decoder_dropout_rate", C.c_float),
         ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("loss_kind", C.c_int32),
-        ("eps_min", C.c_float), ("eps_max", C.c_float), ("device", C.c_int32),
+        ("eps_min", C.c_float), ("eps_max", C.c_float), ("device", C.c_int32), ("precision", C.c_int32),
     ]
 
 
@@ -39,6 +39,7 @@ class ForwardArgs(C.Structure):
 
 
 LOSS_KINDS = {"laplace_nll": 0, "gaussian_nll": 1}
+PRECISIONS = {"fp32": 0, "split16": 1}
 
 _lib = None
 
@@ -65,9 +66,9 @@ _SIGNATURES = {
                                          C.POINTER(C.c_double)]),
     "mimo_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "mimo_uncertainties": (C.c_int, [_P, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P]),
-    "mimo_op_conv3x3_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "mimo_op_conv3x3_dgrad": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "mimo_op_conv3x3_wgrad": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mimo_op_conv3x3_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mimo_op_conv3x3_dgrad": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mimo_op_conv3x3_wgrad": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mimo_op_maxpool2x2": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "mimo_op_upsample_cat": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
 }

@@ -42,7 +42,8 @@ constexpr int kWave = 64;
 struct ConvLaunch {
   const float* x;
   float* y;
-  const float* w;     // packed [9][cout_pad][cin_p]
+  const float* w;     // fp32 kernel: packed [9][cout_pad][cin_p]
+  const void* wpk = nullptr;  // split kernel: packed [chunk][tap][cout_pad][hi 32 | lo 32] fp16/bf16
   const float* bias;  // [cout_pad] or nullptr
   float* stats;       // per-block partial sums [blocks][2][cout_pad] or nullptr
   int N, Hi, Wi, ldx, cin_p;
@@ -51,6 +52,11 @@ struct ConvLaunch {
 };
 // returns number of partial-stat rows (spatial blocks) through *rows when stats != nullptr
 int conv3x3_launch(const ConvLaunch& a, int* rows, hipStream_t stream);
+// split 16-bit variant (conv_bf16x3.hip): same ConvLaunch, reads a.wpk instead of a.w.
+// f16 = 1: fp16 hi/lo (forward, fp32-class products); f16 = 0: bf16 hi/lo (gradients)
+int conv3x3_bf16x3_launch(const ConvLaunch& a, int f16, int* rows, hipStream_t stream);
+int pack_weights_bf16x3_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
+                               const int* row_map, const int* col_map, int transposed, hipStream_t stream);
 int conv3x3_pick_nfrag(int cout);            // fragments (of 16 output channels) per workgroup
 int conv3x3_cout_pad(int cout);              // packed weight rows for that choice
 int conv3x3_stat_rows(int N, int Ho, int Wo);  // spatial workgroups == partial-stat rows
@@ -65,6 +71,10 @@ struct WgradLaunch {
   int splits;
 };
 int wgrad_launch(const WgradLaunch& a, hipStream_t stream);
+// split-bf16 variant (wgrad_split.hip): cin_pad / cout_pad must be multiples of its (CI, CO) tile
+void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO);
+int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO);
+int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream);
 int wgrad_pick_splits(int N, int H, int W, int cin_pad, int cout_pad);
 // dW[co][ci][kh][kw] (torch OIHW) = sum over splits of partial[..][tap][cin_map^-1(ci)][co]
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map,

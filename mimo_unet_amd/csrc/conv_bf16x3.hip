@@ -1,0 +1,415 @@
+// 3x3 convolution (forward / data gradient) on the 16-bit MFMA with split operands:
+//   a = a_hi + a_lo + eps,  a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi   (fp32 accumulate)
+// Three v_mfma_f32_16x16x32_{f16,bf16} per product block = 16/3 = 5.3x the rate of the f32-input
+// MFMA that bounds conv3x3.hip.  Two element types, chosen by what the operand tolerates:
+//   * F16 = true  (forward): fp16 hi/lo carry 11+11 mantissa bits -> ~2^-22 per product, i.e.
+//     fp32-class outputs.  That matters: a 5e-5 forward error (bf16 hi/lo) flips enough ReLU /
+//     max-pool masks to move small-network gradients by tens of percent (measured on CPU by
+//     emulation).  Weights are pre-scaled by 2^8 (kept out of the fp16 subnormal range; undone
+//     exactly in the epilogue); activations below 0.125 keep >= 3e-8 absolute precision.
+//   * F16 = false (data gradient): bf16 hi/lo keep fp32's exponent range for the tiny dz values;
+//     ~1e-5 per product on the gradient side is harmless (gradient error 2e-5, same emulation).
+//
+// Same implicit GEMM as conv3x3.hip (M = TRxTC output pixels of one image, N = output channels,
+// K = 9 taps x input channels) with a deeper structure:
+//   * workgroup = 512 threads = 8 waves, one per-SIMD pair; tile = 8*MF fragments of 16 pixels
+//     (256 or 512 pixels) x NF*16 output channels; MF x NF accumulator fragments per wave
+//   * K is walked in 32-channel chunks x 3 tap rows ("phases").  The input halo tile of a chunk is
+//     staged once (fp32 -> hi/lo bf16 split on the way into LDS); the weights of one tap row
+//     (3 taps x NB x 32 ch, pre-split by the packer) are double-buffered in LDS
+//   * every phase first ISSUES the global loads of the next phase's weights (and, in the first
+//     phase of a chunk, of the next chunk's input tile) into registers, then runs its MFMAs, then
+//     writes the prefetched registers to LDS: global latency hides under the MFMA work
+//   * LDS rows are 64 bf16 (32 hi | 32 lo) + 16 B pad = 144 B: ds_read_b128 fragment reads with
+//     compile-time offsets, 16 consecutive pixels land on distinct bank quads
+#include "common.h"
+
+namespace mimo {
+
+template <bool F16>
+struct Elem;
+template <>
+struct Elem<false> {
+  typedef __bf16 T;
+  typedef __attribute__((ext_vector_type(8))) __bf16 V8;
+  typedef __attribute__((ext_vector_type(4))) __bf16 V4;
+};
+template <>
+struct Elem<true> {
+  typedef _Float16 T;
+  typedef __attribute__((ext_vector_type(8))) _Float16 V8;
+  typedef __attribute__((ext_vector_type(4))) _Float16 V4;
+};
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_ mfma16(Elem<false>::V8 a, Elem<false>::V8 b, f32x4_ c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_ mfma16(Elem<true>::V8 a, Elem<true>::V8 b, f32x4_ c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+constexpr float kF16WeightScale = 256.f;  // 2^8, exact
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kPitchB = 144;  // bytes per LDS row (pixel or weight row)
+
+static void pick_tile_n(int Ho, int Wo, int npix, int maxpix, int* TR, int* TC) {
+  double best_eff = -1.0;
+  int best_tr = 1, best_tc = 4, best_pix = 1 << 30;
+  for (int k = 1; k <= Wo; ++k) {
+    int tc = ceil_div(Wo, k);
+    if (tc > npix) continue;
+    int tr = npix / tc;
+    if (tr > Ho) tr = Ho;
+    while (tr > 1 && (tr + 2) * (tc + 2) > maxpix) --tr;
+    if (tr < 1 || (tr + 2) * (tc + 2) > maxpix) continue;
+    double eff = double(Ho) * Wo / (double(ceil_div(Ho, tr)) * ceil_div(Wo, tc) * npix);
+    int pix = (tr + 2) * (tc + 2);
+    if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && pix < best_pix)) {
+      best_eff = eff;
+      best_tr = tr;
+      best_tc = tc;
+      best_pix = pix;
+    }
+    if (tc <= 4) break;
+  }
+  *TR = best_tr;
+  *TC = best_tc;
+}
+
+template <int MF>
+struct TileCfg {
+  static constexpr int NPIX = 8 * MF * 16;
+  static constexpr int MAXPIX = MF == 4 ? 640 : 360;
+};
+
+template <int MF, int NF, bool F16>
+__global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX) {
+  typedef typename Elem<F16>::T ET;
+  typedef typename Elem<F16>::V8 bf16x8;
+  typedef typename Elem<F16>::V4 bf16x4;
+  constexpr int NB = NF * 16;
+  constexpr int MAXPIX = TileCfg<MF>::MAXPIX;
+  constexpr int XU = (MAXPIX * 8 + 511) / 512;      // float4 units of the input tile per thread
+  constexpr int WUNITS = 3 * NB * 8;                 // 16-byte units of one weight tap row
+  constexpr int WU = (WUNITS + 511) / 512;
+  constexpr int WROWB = 3 * NB * kPitchB;            // bytes of one weight row buffer
+  __shared__ __attribute__((aligned(16))) unsigned char xs[MAXPIX * kPitchB];
+  __shared__ __attribute__((aligned(16))) unsigned char ws[2 * WROWB];
+  __shared__ int goff[MAXPIX];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int TCP = TC + 2, TRP = TR + 2;
+  const int npix_lds = TRP * TCP;
+  const int npix_out = TR * TC;
+
+  int bx = blockIdx.x;
+  const int tx = bx % tilesX;
+  bx /= tilesX;
+  const int ty = bx % tilesY;
+  const int n = bx / tilesY;
+  const int y0 = ty * TR, x0 = tx * TC;
+  const int co0 = blockIdx.y * NB;
+
+  for (int p = tid; p < npix_lds; p += 512) {
+    const int tr = p / TCP, tc = p - tr * TCP;
+    int iy = y0 - a.off + tr, ix = x0 - a.off + tc;
+    int o;
+    if (a.off == 1) {
+      iy = iy < 0 ? -iy : iy;
+      iy = iy >= a.Hi ? 2 * a.Hi - 2 - iy : iy;
+      ix = ix < 0 ? -ix : ix;
+      ix = ix >= a.Wi ? 2 * a.Wi - 2 - ix : ix;
+      iy = min(max(iy, 0), a.Hi - 1);
+      ix = min(max(ix, 0), a.Wi - 1);
+      o = (iy * a.Wi + ix) * a.ldx;
+    } else {
+      o = (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi) ? (iy * a.Wi + ix) * a.ldx : -1;
+    }
+    goff[p] = o;
+  }
+  __syncthreads();
+
+  const float* ximg = a.x + (size_t)n * a.Hi * a.Wi * a.ldx;
+  const int nchunks = (a.cin_p + 31) / 32;
+  const u32x4* wpk = reinterpret_cast<const u32x4*>(a.wpk);
+
+  // ---- staging helpers (plain unrolled code: the prefetch arrays must stay in registers) ------
+  f32x4 xreg[XU];
+  u32x4 wreg[WU];
+#define MIMO_LOAD_X(CHUNK)                                                                      \
+  _Pragma("unroll") for (int k_ = 0; k_ < XU; ++k_) {                                           \
+    const int u_ = tid + k_ * 512;                                                              \
+    const int p_ = min(u_ >> 3, npix_lds - 1), q_ = u_ & 7;                                     \
+    const int o_ = goff[p_];                                                                    \
+    const int ch_ = (CHUNK) * 32 + 4 * q_;                                                      \
+    const bool ok_ = o_ >= 0 && ch_ < a.cin_p;                                                  \
+    const f32x4 v_ = *reinterpret_cast<const f32x4*>(ximg + (ok_ ? o_ + ch_ : 0));              \
+    xreg[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                            \
+  }
+#define MIMO_STORE_X()                                                                          \
+  _Pragma("unroll") for (int k_ = 0; k_ < XU; ++k_) {                                           \
+    const int u_ = tid + k_ * 512;                                                              \
+    const int p_ = u_ >> 3, q_ = u_ & 7;                                                        \
+    if (p_ < npix_lds) {                                                                        \
+      const f32x4 v_ = xreg[k_];                                                                \
+      bf16x4 hi_, lo_;                                                                          \
+      hi_[0] = (ET)v_[0];                                                                       \
+      hi_[1] = (ET)v_[1];                                                                       \
+      hi_[2] = (ET)v_[2];                                                                       \
+      hi_[3] = (ET)v_[3];                                                                       \
+      lo_[0] = (ET)(v_[0] - (float)hi_[0]);                                                     \
+      lo_[1] = (ET)(v_[1] - (float)hi_[1]);                                                     \
+      lo_[2] = (ET)(v_[2] - (float)hi_[2]);                                                     \
+      lo_[3] = (ET)(v_[3] - (float)hi_[3]);                                                     \
+      unsigned char* d_ = xs + p_ * kPitchB + q_ * 8;                                           \
+      *reinterpret_cast<bf16x4*>(d_) = hi_;                                                     \
+      *reinterpret_cast<bf16x4*>(d_ + 64) = lo_;                                                \
+    }                                                                                           \
+  }
+  // weights of chunk CHUNK, tap row ROW: global [chunk][tap][cout_pad][8 x 16 B]
+#define MIMO_LOAD_W(CHUNK, ROW)                                                                 \
+  _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                           \
+    const int u_ = min(tid + k_ * 512, WUNITS - 1);                                             \
+    const int t_ = u_ / (NB * 8);                                                               \
+    const int rem_ = u_ - t_ * (NB * 8);                                                        \
+    wreg[k_] = wpk[(((size_t)(CHUNK) * 9 + ((ROW) * 3 + t_)) * a.cout_pad + co0 + (rem_ >> 3)) * 8 + (rem_ & 7)]; \
+  }
+#define MIMO_STORE_W(BUF)                                                                       \
+  _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                           \
+    const int u_ = tid + k_ * 512;                                                              \
+    if (u_ < WUNITS) {                                                                          \
+      const int t_ = u_ / (NB * 8);                                                             \
+      const int rem_ = u_ - t_ * (NB * 8);                                                      \
+      *reinterpret_cast<u32x4*>(ws + (BUF) * WROWB + (t_ * NB + (rem_ >> 3)) * kPitchB + (rem_ & 7) * 16) = wreg[k_]; \
+    }                                                                                           \
+  }
+
+  // ---- per-lane fragment bases -----------------------------------------------------------
+  int pbase[MF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m) {
+    int idx = (wave * MF + m) * 16 + lr;
+    if (idx >= npix_out) idx = 0;
+    const int r = idx / TC, c = idx - r * TC;
+    pbase[m] = (r * TCP + c) * kPitchB + g * 16;
+  }
+  const int wbase = lr * kPitchB + g * 16;
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) acc[m][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: chunk 0, tap row 0
+  MIMO_LOAD_X(0)
+  MIMO_LOAD_W(0, 0)
+  MIMO_STORE_X()
+  MIMO_STORE_W(0)
+  __syncthreads();
+
+  int buf = 0;
+  for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const bool last = (c == nchunks - 1) && (r == 2);
+      if (!last) {
+        const int nc = r < 2 ? c : c + 1, nr = r < 2 ? r + 1 : 0;
+        MIMO_LOAD_W(nc, nr)
+      }
+      if (r == 0 && c + 1 < nchunks) {
+        MIMO_LOAD_X(c + 1)
+      }
+      const unsigned char* wb = ws + buf * WROWB + wbase;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int toff = (r * TCP + kw) * kPitchB;
+        bf16x8 bh[NF], bl[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          bh[nf] = *reinterpret_cast<const bf16x8*>(wb + (kw * NB + nf * 16) * kPitchB);
+          bl[nf] = *reinterpret_cast<const bf16x8*>(wb + (kw * NB + nf * 16) * kPitchB + 64);
+        }
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xs + pbase[m] + toff);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(xs + pbase[m] + toff + 64);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            acc[m][nf] = mfma16(al, bh[nf], acc[m][nf]);
+            acc[m][nf] = mfma16(ah, bl[nf], acc[m][nf]);
+            acc[m][nf] = mfma16(ah, bh[nf], acc[m][nf]);
+          }
+        }
+      }
+      if (!last) {  // other buffer: last read one phase ago, behind a barrier
+        MIMO_STORE_W(buf ^ 1)
+      }
+      if (r == 2 && c + 1 < nchunks) {
+        __syncthreads();  // every wave is done reading this chunk's input tile
+        MIMO_STORE_X()
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue: bias, store, BatchNorm partial sums -----------------------------------------
+  float bv[NF], s1[NF], s2[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    bv[nf] = a.bias ? a.bias[co0 + nf * 16 + lr] : 0.f;
+    s1[nf] = 0.f;
+    s2[nf] = 0.f;
+  }
+  float* yimg = a.y + (size_t)n * a.Ho * a.Wo * a.ldy;
+#pragma unroll
+  for (int m = 0; m < MF; ++m) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int idx = (wave * MF + m) * 16 + g * 4 + r4;
+      const int orow = idx / TC, ocol = idx - orow * TC;
+      const int oy = y0 + orow, ox = x0 + ocol;
+      if (idx < npix_out && oy < a.Ho && ox < a.Wo) {
+        float* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy + co0 + lr;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const float v = acc[m][nf][r4] * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];
+          if (co0 + nf * 16 + lr < a.cout_store) yp[nf * 16] = v;
+          s1[nf] += v;
+          s2[nf] += v * v;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      s1[nf] += __shfl_xor(s1[nf], 16);
+      s1[nf] += __shfl_xor(s1[nf], 32);
+      s2[nf] += __shfl_xor(s2[nf], 16);
+      s2[nf] += __shfl_xor(s2[nf], 32);
+    }
+    float* red = reinterpret_cast<float*>(ws);  // [8 waves][2][NB]; the main loop ended on a barrier
+    if (g == 0) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        red[(wave * 2 + 0) * NB + nf * 16 + lr] = s1[nf];
+        red[(wave * 2 + 1) * NB + nf * 16 + lr] = s2[nf];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * NB) {
+      const int which = tid / NB, c = tid - which * NB;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[(w * 2 + which) * NB + c];
+      a.stats[((size_t)blockIdx.x * 2 + which) * a.cout_pad + co0 + c] = v;
+    }
+  }
+}
+
+#undef MIMO_LOAD_X
+#undef MIMO_STORE_X
+#undef MIMO_LOAD_W
+#undef MIMO_STORE_W
+
+template <int MF, int NF, bool F16>
+static int launch_bf16x3(const ConvLaunch& a, int* rows, hipStream_t stream) {
+  int TR, TC;
+  pick_tile_n(a.Ho, a.Wo, TileCfg<MF>::NPIX, TileCfg<MF>::MAXPIX, &TR, &TC);
+  const int tilesY = ceil_div(a.Ho, TR), tilesX = ceil_div(a.Wo, TC);
+  if (rows) *rows = a.N * tilesY * tilesX;
+  dim3 grid(a.N * tilesY * tilesX, a.cout_pad / (NF * 16));
+  hipLaunchKernelGGL((conv3x3_bf16x3_kernel<MF, NF, F16>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// MF = 4 (512-pixel tiles) when the image is large enough to fill them, else 2.
+static bool use_big_tile(int Ho, int Wo) { return Ho * Wo >= 1024; }
+
+template <bool F16>
+static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t stream) {
+  const int nfr = a.cout_pad / 16;
+  int nf = 4;
+  while (nfr % nf != 0) --nf;
+  if (use_big_tile(a.Ho, a.Wo)) {
+    switch (nf) {
+      case 4: return launch_bf16x3<4, 4, F16>(a, rows, stream);
+      case 3: return launch_bf16x3<4, 3, F16>(a, rows, stream);
+      case 2: return launch_bf16x3<4, 2, F16>(a, rows, stream);
+      default: return launch_bf16x3<4, 1, F16>(a, rows, stream);
+    }
+  }
+  switch (nf) {
+    case 4: return launch_bf16x3<2, 4, F16>(a, rows, stream);
+    case 3: return launch_bf16x3<2, 3, F16>(a, rows, stream);
+    case 2: return launch_bf16x3<2, 2, F16>(a, rows, stream);
+    default: return launch_bf16x3<2, 1, F16>(a, rows, stream);
+  }
+}
+
+// f16 != 0: fp16 hi/lo (forward; weights packed with f16 = 1); else bf16 hi/lo (data gradient)
+int conv3x3_bf16x3_launch(const ConvLaunch& a, int f16, int* rows, hipStream_t stream) {
+  if (!a.wpk || a.ldx % 4 != 0 || a.cout_pad % 16 != 0 || a.Hi < 2 || a.Wi < 2) {
+    set_error("conv3x3 split: bad geometry");
+    return MIMO_ERR_INVALID;
+  }
+  return f16 ? conv3x3_split_dispatch<true>(a, rows, stream) : conv3x3_split_dispatch<false>(a, rows, stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// weight packing for the split kernel: torch OIHW -> [chunk][tap][row][hi 32 | lo 32] bf16
+// (row/col maps and the transposed flag as in pack_weights_kernel, conv3x3.hip)
+// ---------------------------------------------------------------------------------------
+template <bool F16>
+__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, typename Elem<F16>::T* __restrict__ dst, int cout,
+                                           int cin, int rows_pad, int cols, int nchunks, const int* __restrict__ row_map,
+                                           const int* __restrict__ col_map, int transposed) {
+  typedef typename Elem<F16>::T ET;
+  const int total = nchunks * 9 * rows_pad * 32;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = i & 31;
+    int rest = i >> 5;
+    const int row = rest % rows_pad;
+    rest /= rows_pad;
+    const int tap = rest % 9, chunk = rest / 9;
+    const int col = chunk * 32 + k;
+    float v = 0.f;
+    if (col < cols) {
+      const int rm = row_map[row], cm = col_map[col];
+      if (rm >= 0 && cm >= 0) {
+        const int co = transposed ? cm : rm, ci = transposed ? rm : cm;
+        const int kh = transposed ? 2 - tap / 3 : tap / 3, kw = transposed ? 2 - tap % 3 : tap % 3;
+        v = w[(((size_t)co * cin + ci) * 3 + kh) * 3 + kw];
+      }
+    }
+    if (F16) v *= kF16WeightScale;
+    const ET hi = (ET)v;
+    const ET lo = (ET)(v - (float)hi);
+    ET* d = dst + (((size_t)chunk * 9 + tap) * rows_pad + row) * 64;
+    d[k] = hi;
+    d[32 + k] = lo;
+  }
+}
+
+int pack_weights_bf16x3_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
+                               const int* row_map, const int* col_map, int transposed, hipStream_t stream) {
+  const int nchunks = ceil_div(cols, 32);
+  const int total = nchunks * 9 * rows_pad * 32;
+  const int blocks = min(ceil_div(total, 256), 4096);
+  if (f16)
+    hipLaunchKernelGGL(pack_weights_bf16x3_kernel<true>, dim3(blocks), dim3(256), 0, stream, w,
+                       reinterpret_cast<_Float16*>(dst), cout, cin, rows_pad, cols, nchunks, row_map, col_map, transposed);
+  else
+    hipLaunchKernelGGL(pack_weights_bf16x3_kernel<false>, dim3(blocks), dim3(256), 0, stream, w,
+                       reinterpret_cast<__bf16*>(dst), cout, cin, rows_pad, cols, nchunks, row_map, col_map, transposed);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+}  // namespace mimo

@@ -69,11 +69,13 @@ extern "C" {
 
 int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, float* z, double* stats, int32_t n,
                             int32_t h, int32_t wd, int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p,
-                            mimo_stream stream) {
+                            int32_t precision, mimo_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   Temp t;
   const int cout_pad = conv3x3_cout_pad(cout);
+  const bool split = precision == MIMO_PREC_SPLIT16;
   float* wf = t.get<float>((size_t)9 * cout_pad * cin_p);
+  void* wpk = t.get<uint16_t>((size_t)ceil_div(cin_p, 32) * 9 * cout_pad * 64);
   float* bp = t.get<float>(cout_pad);
   int* rm = t.ints(ident_map(cout_pad, cout));
   int* cm = t.ints(ident_map(cin_p, cin));
@@ -85,6 +87,7 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
     return MIMO_ERR_HIP;
   }
   MIMO_TRY(pack_weights_launch(w, wf, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
+  if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, 1, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
   if (bias) MIMO_HIP_CHECK(hipMemcpyAsync(bp, bias, cout * sizeof(float), hipMemcpyDeviceToDevice, st));
   ConvLaunch a;
   a.x = x;
@@ -101,8 +104,12 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   a.cout_pad = cout_pad;
   a.cout_store = cout_p;
   a.off = 1;
+  a.wpk = wpk;
   int rows = 0;
-  MIMO_TRY(conv3x3_launch(a, &rows, st));
+  if (split)
+    MIMO_TRY(conv3x3_bf16x3_launch(a, 1, &rows, st));
+  else
+    MIMO_TRY(conv3x3_launch(a, &rows, st));
   if (stats) {
     int chunks = 0;
     MIMO_TRY(rowsum_launch(partial, rows, 2 * cout_pad, sums, &chunks, st));
@@ -114,11 +121,13 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
 }
 
 int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n, int32_t h, int32_t wd, int32_t cin,
-                          int32_t cin_p, int32_t cout, int32_t cout_p, mimo_stream stream) {
+                          int32_t cin_p, int32_t cout, int32_t cout_p, int32_t precision, mimo_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   Temp t;
   const int rows_pad = conv3x3_cout_pad(cin_p);
+  const bool split = precision == MIMO_PREC_SPLIT16;
   float* wdp = t.get<float>((size_t)9 * rows_pad * cout_p);
+  void* wpk = t.get<uint16_t>((size_t)ceil_div(cout_p, 32) * 9 * rows_pad * 64);
   int* rm = t.ints(ident_map(rows_pad, cin));
   int* cm = t.ints(ident_map(cout_p, cout));
   float* dxpad = t.get<float>((size_t)n * (h + 2) * (wd + 2) * cin_p);
@@ -127,6 +136,7 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
     return MIMO_ERR_HIP;
   }
   MIMO_TRY(pack_weights_launch(w, wdp, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
+  if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, 0, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
   ConvLaunch a;
   a.x = dz;
   a.y = dxpad;
@@ -144,16 +154,22 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
   a.cout_pad = rows_pad;
   a.cout_store = cin_p;
   a.off = 2;
-  MIMO_TRY(conv3x3_launch(a, nullptr, st));
+  a.wpk = wpk;
+  if (split)
+    MIMO_TRY(conv3x3_bf16x3_launch(a, 0, nullptr, st));
+  else
+    MIMO_TRY(conv3x3_launch(a, nullptr, st));
   MIMO_TRY(fold_slice_launch(dxpad, cin_p, 0, dx, cin_p, n, h, wd, cin_p, 0, st));
   MIMO_HIP_CHECK(hipStreamSynchronize(st));
   return MIMO_OK;
 }
 
 int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbias, int32_t n, int32_t h, int32_t wd,
-                          int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p, mimo_stream stream) {
+                          int32_t cin, int32_t cin_p, int32_t cout, int32_t cout_p, int32_t precision,
+                          mimo_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   Temp t;
+  const bool split = precision == MIMO_PREC_SPLIT16 && cin_p >= 16;
   WgradLaunch a;
   a.x = x;
   a.dz = dz;
@@ -164,16 +180,27 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
   a.lddz = cout_p;
   a.cin_p = cin_p;
   a.cout_p = cout_p;
-  a.cin_pad = round_up(cin_p, 32);
-  a.cout_pad = round_up(cout_p, 32);
-  a.splits = wgrad_pick_splits(n, h, wd, a.cin_pad, a.cout_pad);
+  if (split) {
+    int CI, CO;
+    wgrad_split_tiles(cin_p, cout_p, &CI, &CO);
+    a.cin_pad = round_up(cin_p, CI);
+    a.cout_pad = round_up(cout_p, CO);
+    a.splits = wgrad_split_pick_splits(n, h, wd, a.cin_pad, a.cout_pad, CI, CO);
+  } else {
+    a.cin_pad = round_up(cin_p, 32);
+    a.cout_pad = round_up(cout_p, 32);
+    a.splits = wgrad_pick_splits(n, h, wd, a.cin_pad, a.cout_pad);
+  }
   a.partial = t.get<float>((size_t)a.splits * 9 * a.cin_pad * a.cout_pad);
   int* cm = t.ints(ident_map(cin_p, cin));
   if (!a.partial || !cm) {
     set_error("mimo_op_conv3x3_wgrad: allocation failed");
     return MIMO_ERR_HIP;
   }
-  MIMO_TRY(wgrad_launch(a, st));
+  if (split)
+    MIMO_TRY(wgrad_split_launch(a, st));
+  else
+    MIMO_TRY(wgrad_launch(a, st));
   MIMO_TRY(wgrad_reduce_launch(a.partial, a.splits, a.cin_pad, a.cout_pad, cm, cin_p, cin, cout, dw, st));
   if (dbias) {
     hipLaunchKernelGGL(colsum_naive_kernel, dim3(cout), dim3(256), 0, st, dz, (int64_t)n * h * wd, cout_p, cout, dbias);

@@ -62,6 +62,8 @@ struct ConvBN {
   int N = 0, H = 0, W = 0;
   int64_t off_w = 0, off_b = 0, off_gamma = 0, off_beta = 0, off_rm = 0, off_rv = 0;
   float *wf = nullptr, *wd = nullptr, *bias_p = nullptr;
+  void *wf16 = nullptr, *wd16 = nullptr;  // split-bf16 packed weights (MIMO_PREC_SPLIT16)
+  bool fwd_split = false, dg_split = false, wg_split = false;
   int *cin_map = nullptr, *fwd_row_map = nullptr, *dg_row_map = nullptr, *dg_col_map = nullptr;
   float* z = nullptr;
   float *mean = nullptr, *invstd = nullptr, *scale = nullptr, *shift = nullptr, *c1 = nullptr, *c2 = nullptr;
@@ -226,12 +228,21 @@ struct mimo_plan {
     L.cout_p = pad_channels(Cout);
     L.cout_pad = conv3x3_cout_pad(Cout);
     L.dg_rows = conv3x3_cout_pad(L.cin_p);
-    L.wg_cin_pad = round_up(L.cin_p, 32);
-    L.wg_cout_pad = round_up(L.cout_p, 32);
     L.N = n;
     L.H = h;
     L.W = w;
-    L.wg_splits = wgrad_pick_splits(n, h, w, L.wg_cin_pad, L.wg_cout_pad);
+    L.wg_split = cfg.precision == MIMO_PREC_SPLIT16 && L.cin_p >= 16;
+    if (L.wg_split) {
+      int CI, CO;
+      wgrad_split_tiles(L.cin_p, L.cout_p, &CI, &CO);
+      L.wg_cin_pad = round_up(L.cin_p, CI);
+      L.wg_cout_pad = round_up(L.cout_p, CO);
+      L.wg_splits = wgrad_split_pick_splits(n, h, w, L.wg_cin_pad, L.wg_cout_pad, CI, CO);
+    } else {
+      L.wg_cin_pad = round_up(L.cin_p, 32);
+      L.wg_cout_pad = round_up(L.cout_p, 32);
+      L.wg_splits = wgrad_pick_splits(n, h, w, L.wg_cin_pad, L.wg_cout_pad);
+    }
     L.off_w = add_tensor(L.conv_name + ".weight", {Cout, Cin, 3, 3}, 0);
     L.off_b = add_tensor(L.conv_name + ".bias", {Cout}, 0);
     L.off_gamma = add_tensor(L.bn_name + ".weight", {Cout}, 0);
@@ -241,6 +252,19 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&L.wf, (size_t)9 * L.cout_pad * L.cin_p));
     MIMO_TRY(dalloc(&L.wd, (size_t)9 * L.dg_rows * L.cout_p));
     MIMO_TRY(dalloc(&L.bias_p, L.cout_pad));
+    // split-bf16 MFMA needs a K chunk of 32 channels; the 2..4-channel image conv stays on the fp32 kernel
+    L.fwd_split = cfg.precision == MIMO_PREC_SPLIT16 && L.cin_p >= 16;
+    L.dg_split = cfg.precision == MIMO_PREC_SPLIT16 && L.cout_p >= 16;
+    if (L.fwd_split) {
+      uint16_t* q = nullptr;
+      MIMO_TRY(dalloc(&q, (size_t)ceil_div(L.cin_p, 32) * 9 * L.cout_pad * 64));
+      L.wf16 = q;
+    }
+    if (L.dg_split) {
+      uint16_t* q = nullptr;
+      MIMO_TRY(dalloc(&q, (size_t)ceil_div(L.cout_p, 32) * 9 * L.dg_rows * 64));
+      L.wd16 = q;
+    }
     MIMO_TRY(upload_ints(&L.cin_map, in_chmap));
     std::vector<int> frm(L.cout_pad), drm(L.dg_rows), dcm(L.cout_p);
     for (int i = 0; i < L.cout_pad; ++i) frm[i] = i < Cout ? i : -1;
@@ -444,9 +468,16 @@ struct mimo_plan {
   // ------------------------------------------------------------------ forward ------------
   int pack_layer(ConvBN& L, bool with_dgrad, hipStream_t st) {
     const float* w = params + L.off_w;
-    MIMO_TRY(pack_weights_launch(w, L.wf, L.Cout, L.Cin, L.cout_pad, L.cin_p, L.fwd_row_map, L.cin_map, 0, st));
-    if (with_dgrad)
-      MIMO_TRY(pack_weights_launch(w, L.wd, L.Cout, L.Cin, L.dg_rows, L.cout_p, L.dg_row_map, L.dg_col_map, 1, st));
+    if (L.fwd_split)
+      MIMO_TRY(pack_weights_bf16x3_launch(w, L.wf16, 1, L.Cout, L.Cin, L.cout_pad, L.cin_p, L.fwd_row_map, L.cin_map, 0, st));
+    else
+      MIMO_TRY(pack_weights_launch(w, L.wf, L.Cout, L.Cin, L.cout_pad, L.cin_p, L.fwd_row_map, L.cin_map, 0, st));
+    if (with_dgrad) {
+      if (L.dg_split)
+        MIMO_TRY(pack_weights_bf16x3_launch(w, L.wd16, 0, L.Cout, L.Cin, L.dg_rows, L.cout_p, L.dg_row_map, L.dg_col_map, 1, st));
+      else
+        MIMO_TRY(pack_weights_launch(w, L.wd, L.Cout, L.Cin, L.dg_rows, L.cout_p, L.dg_row_map, L.dg_col_map, 1, st));
+    }
     MIMO_HIP_CHECK(hipMemcpyAsync(L.bias_p, params + L.off_b, L.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
     return MIMO_OK;
   }
@@ -469,8 +500,12 @@ struct mimo_plan {
     a.off = 1;
     int rows = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
+    a.wpk = L.wf16;
     prof_begin(MIMO_PROF_CONV_FWD, st);
-    MIMO_TRY(conv3x3_launch(a, &rows, st));
+    if (L.fwd_split)
+      MIMO_TRY(conv3x3_bf16x3_launch(a, 1, &rows, st));
+    else
+      MIMO_TRY(conv3x3_launch(a, &rows, st));
     prof_end(MIMO_PROF_CONV_FWD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     if (training) {
       int chunks = 0;
@@ -590,7 +625,10 @@ struct mimo_plan {
     wg.cout_pad = L.wg_cout_pad;
     wg.splits = L.wg_splits;
     prof_begin(MIMO_PROF_CONV_WGRAD, st);
-    MIMO_TRY(wgrad_launch(wg, st));
+    if (L.wg_split)
+      MIMO_TRY(wgrad_split_launch(wg, st));
+    else
+      MIMO_TRY(wgrad_launch(wg, st));
     prof_end(MIMO_PROF_CONV_WGRAD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
                                  grads + L.off_w, st));
@@ -612,8 +650,12 @@ struct mimo_plan {
       a.cout_pad = L.dg_rows;
       a.cout_store = L.cin_p;
       a.off = 2;
+      a.wpk = L.wd16;
       prof_begin(MIMO_PROF_CONV_DGRAD, st);
-      MIMO_TRY(conv3x3_launch(a, nullptr, st));
+      if (L.dg_split)
+        MIMO_TRY(conv3x3_bf16x3_launch(a, 0, nullptr, st));
+      else
+        MIMO_TRY(conv3x3_launch(a, nullptr, st));
       prof_end(MIMO_PROF_CONV_DGRAD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     }
     return MIMO_OK;

@@ -1,0 +1,274 @@
+// Weight gradient of the 3x3 convolution on the bf16 MFMA with split operands (see
+// conv_bf16x3.hip for the arithmetic: a = hi + lo, three MFMAs per product block, fp32
+// accumulate, ~1e-5 per product — harmless on the gradient side).
+//
+//   dW[tap][ci][co] = sum_pixels A(pixel + tap, ci) * dz(pixel, co)      (components.py:23,26 autograd)
+//
+// GEMM view: M = input channels, N = output channels, K = pixels (32 per v_mfma_f32_16x16x32_bf16).
+// Both operands are stored in LDS the way they sit in HBM — pixel-major NHWC rows, split into
+// [hi C x bf16 | lo C x bf16] — and are read with ds_read_b64_tr_b16, the hardware transposed
+// read, which hands every lane 4 consecutive K (pixels) of its own channel: a tap shift is then
+// a whole-row offset (always aligned), with no transposing write pass.
+//   * LDS row pitch = 32*m bytes with m = 2 (mod 4) and rows whose index has bit 3 set shifted
+//     by one 32-byte block: the 8 rows a half-wave touches (R..R+3, R+8..R+11) fall on 8 distinct
+//     bank octets -> conflict-free transposed reads at any tap offset
+//   * workgroup = 4 waves, one per SIMD (__launch_bounds__(256,1): the full 512-register file per
+//     lane): each wave owns a 32x32 (ci,co) tile for all 9 taps (144 accumulator registers) and the
+//     next spatial tile is prefetched into registers while the current one is multiplied
+//   * waves are arranged WM x WN over (ci,co) and WK over K (tile rows); WK > 1 partial sums
+//     are combined through LDS once, at the end
+#include "common.h"
+
+namespace mimo {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr int kWgTR = 4, kWgTC = 32, kWgTCP = 34;
+constexpr int kWgAPix = (kWgTR + 2) * kWgTCP;  // 204 halo-tile pixels
+constexpr int kWgDPix = kWgTR * kWgTC;         // 128 pixels
+
+// smallest pitch = 32*m bytes, m = 2 (mod 4), holding 4*C data bytes + one 32-byte shift block
+constexpr int wg_pitch(int C) {
+  int m = (4 * C + 32 + 31) / 32;
+  while (m % 4 != 2) ++m;
+  return 32 * m;
+}
+
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
+  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int MI, int NI, int WM, int WN, int WK>
+__global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
+  static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+  constexpr int CI = 16 * MI * WM, CO = 16 * NI * WN;
+  constexpr int PA = wg_pitch(CI), PD = wg_pitch(CO);
+  constexpr int QA = CI / 4, QD = CO / 4;                       // float4 units per pixel
+  constexpr int XA = (kWgAPix * QA + 255) / 256, XD = (kWgDPix * QD + 255) / 256;
+  constexpr int ABYTES = kWgAPix * PA, DBYTES = kWgDPix * PD;
+  constexpr int REDBYTES = 4 * MI * NI * 256 * 4;               // cross-wave reduction scratch
+  constexpr int LDSBYTES = ABYTES + DBYTES > REDBYTES ? ABYTES + DBYTES : REDBYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDSBYTES];
+  unsigned char* as_ = smem;
+  unsigned char* ds_ = smem + ABYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int q = lr >> 2, p4 = lr & 3;
+  const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+  const int coTiles = a.cout_pad / CO;
+  const int ciT = blockIdx.x / coTiles, coT = blockIdx.x - ciT * coTiles;
+  const int ci0 = ciT * CI, co0 = coT * CO;
+
+  f32x4 acc[9][MI][NI];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[t][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 xa[XA], xd[XD];
+#define WG_LOAD(TILE)                                                                               \
+  {                                                                                                 \
+    int t_ = (TILE);                                                                                \
+    const int tx_ = t_ % tilesX;                                                                    \
+    t_ /= tilesX;                                                                                   \
+    const int ty_ = t_ % tilesY;                                                                    \
+    const int n_ = t_ / tilesY;                                                                     \
+    const int y0_ = ty_ * kWgTR, x0_ = tx_ * kWgTC;                                                 \
+    const float* ximg_ = a.x + (size_t)n_ * a.H * a.W * a.ldx;                                      \
+    const float* dimg_ = a.dz + (size_t)n_ * a.H * a.W * a.lddz;                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < XA; ++k_) {                                             \
+      const int u_ = min(tid + k_ * 256, kWgAPix * QA - 1);                                         \
+      const int pix_ = u_ / QA, qq_ = u_ - pix_ * QA;                                               \
+      const int tr_ = pix_ / kWgTCP, tc_ = pix_ - tr_ * kWgTCP;                                     \
+      int iy_ = y0_ - 1 + tr_, ix_ = x0_ - 1 + tc_;                                                 \
+      iy_ = iy_ < 0 ? -iy_ : iy_;                                                                   \
+      iy_ = iy_ >= a.H ? 2 * a.H - 2 - iy_ : iy_;                                                   \
+      ix_ = ix_ < 0 ? -ix_ : ix_;                                                                   \
+      ix_ = ix_ >= a.W ? 2 * a.W - 2 - ix_ : ix_;                                                   \
+      iy_ = min(max(iy_, 0), a.H - 1);                                                              \
+      ix_ = min(max(ix_, 0), a.W - 1);                                                              \
+      const bool ok_ = ci0 + 4 * qq_ < a.cin_p;                                                     \
+      const f32x4 v_ = *reinterpret_cast<const f32x4*>(ximg_ + ((size_t)iy_ * a.W + ix_) * a.ldx + (ok_ ? ci0 + 4 * qq_ : 0)); \
+      xa[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+    }                                                                                               \
+    _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
+      const int u_ = tid + k_ * 256;                                                                \
+      const int pix_ = u_ / QD, qq_ = u_ - pix_ * QD;                                               \
+      const int r_ = pix_ / kWgTC, c_ = pix_ - r_ * kWgTC;                                          \
+      const int y_ = y0_ + r_, x_ = x0_ + c_;                                                       \
+      const bool ok_ = pix_ < kWgDPix && y_ < a.H && x_ < a.W && co0 + 4 * qq_ < a.cout_p;          \
+      const f32x4 v_ = *reinterpret_cast<const f32x4*>(dimg_ + (ok_ ? ((size_t)y_ * a.W + x_) * a.lddz + co0 + 4 * qq_ : 0)); \
+      xd[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+    }                                                                                               \
+  }
+#define WG_SPLIT_STORE(V, DST, CCH)                                                                 \
+  {                                                                                                 \
+    bf16x4 hi_, lo_;                                                                                \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                              \
+      hi_[e_] = (__bf16)(V)[e_];                                                                    \
+      lo_[e_] = (__bf16)((V)[e_] - (float)hi_[e_]);                                                 \
+    }                                                                                               \
+    *reinterpret_cast<bf16x4*>(DST) = hi_;                                                          \
+    *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                                            \
+  }
+#define WG_STORE()                                                                                  \
+  {                                                                                                 \
+    _Pragma("unroll") for (int k_ = 0; k_ < XA; ++k_) {                                             \
+      const int u_ = tid + k_ * 256;                                                                \
+      const int pix_ = u_ / QA, qq_ = u_ - pix_ * QA;                                               \
+      if (pix_ < kWgAPix) {                                                                         \
+        unsigned char* d_ = as_ + pix_ * PA + ((pix_ >> 3) & 1) * 32 + qq_ * 8;                     \
+        WG_SPLIT_STORE(xa[k_], d_, CI)                                                              \
+      }                                                                                             \
+    }                                                                                               \
+    _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
+      const int u_ = tid + k_ * 256;                                                                \
+      const int pix_ = u_ / QD, qq_ = u_ - pix_ * QD;                                               \
+      if (pix_ < kWgDPix) {                                                                         \
+        unsigned char* d_ = ds_ + pix_ * PD + ((pix_ >> 3) & 1) * 32 + qq_ * 8;                     \
+        WG_SPLIT_STORE(xd[k_], d_, CO)                                                              \
+      }                                                                                             \
+    }                                                                                               \
+  }
+
+  int tile = blockIdx.y;
+  if (tile < numTiles) {
+    WG_LOAD(tile)
+    WG_STORE()
+  }
+  __syncthreads();
+  // per-lane row / column constants of the transposed reads
+  const int rowk = 8 * g + q;                          // K index (pixel column inside the tile row), first half
+  const int dcol = (wn * NI) * 32 + 8 * p4 + 32 * (g & 1);  // dz: rows r*32 + rowk (+4): bit 3 == g & 1
+  const int acol = (wm * MI) * 32 + 8 * p4;
+
+  for (; tile < numTiles; tile += gridDim.y) {
+    const int next = tile + gridDim.y;
+    if (next < numTiles) WG_LOAD(next)
+#pragma unroll
+    for (int rr = 0; rr < kWgTR / WK; ++rr) {
+      const int r = wk + rr * WK;
+      bf16x8 bh[NI], bl[NI];
+      const unsigned char* d0 = ds_ + (r * kWgTC + rowk) * PD + dcol;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        bh[ni] = tr_read8(d0 + ni * 32, d0 + ni * 32 + 4 * PD);
+        bl[ni] = tr_read8(d0 + ni * 32 + 2 * CO, d0 + ni * 32 + 2 * CO + 4 * PD);
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int row0 = (r + kh) * kWgTCP + rowk + kw, row1 = row0 + 4;
+          const unsigned char* a0 = as_ + row0 * PA + ((row0 >> 3) & 1) * 32 + acol;
+          const unsigned char* a1 = as_ + row1 * PA + ((row1 >> 3) & 1) * 32 + acol;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const bf16x8 ah = tr_read8(a0 + mi * 32, a1 + mi * 32);
+            const bf16x8 al = tr_read8(a0 + mi * 32 + 2 * CI, a1 + mi * 32 + 2 * CI);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              f32x4 c = acc[kh * 3 + kw][mi][ni];
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ni], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ni], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ni], c, 0, 0, 0);
+              acc[kh * 3 + kw][mi][ni] = c;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // every wave is done reading this tile
+    if (next < numTiles) WG_STORE()
+    __syncthreads();
+  }
+#undef WG_LOAD
+#undef WG_STORE
+#undef WG_SPLIT_STORE
+
+  // ---- write the partial slab (after combining the WK waves that share a (ci,co) tile) -------
+  float* out = a.partial + (size_t)blockIdx.y * 9 * a.cin_pad * a.cout_pad;
+  float* red = reinterpret_cast<float*>(smem);  // [wave][mi][ni][256]
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (WK > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          *reinterpret_cast<f32x4*>(red + ((wave * MI + mi) * NI + ni) * 256 + lane * 4) = acc[t][mi][ni];
+      __syncthreads();
+    }
+    if (wk == 0) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          f32x4 v = acc[t][mi][ni];
+          if (WK > 1) {
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < WK; ++k) v += *reinterpret_cast<const f32x4*>(red + (((wave + k) * MI + mi) * NI + ni) * 256 + lane * 4);
+          }
+          const int co = co0 + (wn * NI + ni) * 16 + lr;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int ci = ci0 + (wm * MI + mi) * 16 + g * 4 + r4;
+            out[((size_t)t * a.cin_pad + ci) * a.cout_pad + co] = v[r4];
+          }
+        }
+    }
+  }
+}
+
+// (ci tile, co tile) of the split kernel for a layer
+void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO) {
+  *CI = cin_p <= 32 ? 32 : 64;
+  *CO = cout_p <= 32 ? 32 : 64;
+}
+
+int wgrad_split_num_tiles(int N, int H, int W) { return N * ceil_div(H, kWgTR) * ceil_div(W, kWgTC); }
+
+int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO) {
+  const int wtiles = (cin_pad / CI) * (cout_pad / CO);
+  const int tiles = wgrad_split_num_tiles(N, H, W);
+  int splits = ceil_div(1024, wtiles);  // one 4-wave workgroup per CU: ~4 waves of workgroups
+  if (splits > tiles) splits = tiles;
+  if (splits > 1024) splits = 1024;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
+  int CI, CO;
+  wgrad_split_tiles(a.cin_p, a.cout_p, &CI, &CO);
+  if (a.cin_pad % CI || a.cout_pad % CO || a.cin_p % 4 || a.cout_p % 4 || a.ldx % 4 || a.lddz % 4 || a.H < 2 || a.W < 2) {
+    set_error("wgrad_split: bad geometry");
+    return MIMO_ERR_INVALID;
+  }
+  const int tilesY = ceil_div(a.H, kWgTR), tilesX = ceil_div(a.W, kWgTC);
+  const int numTiles = a.N * tilesY * tilesX;
+  dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
+  if (CI == 32 && CO == 32)
+    hipLaunchKernelGGL((wgrad_split_kernel<2, 2, 1, 1, 4>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
+  else if (CI == 64 && CO == 32)
+    hipLaunchKernelGGL((wgrad_split_kernel<2, 2, 2, 1, 2>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
+  else if (CI == 32 && CO == 64)
+    hipLaunchKernelGGL((wgrad_split_kernel<2, 2, 1, 2, 2>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
+  else
+    hipLaunchKernelGGL((wgrad_split_kernel<2, 2, 2, 2, 1>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+}  // namespace mimo

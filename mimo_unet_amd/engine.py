@@ -37,6 +37,7 @@ class NetGeometry:
     core_dropout_rate: float = 0.0
     decoder_dropout_rate: float = 0.0
     loss: str = "laplace_nll"
+    precision: str = "split16"  # arithmetic of the 3x3 fwd/dgrad convolutions: "fp32" | "split16"
 
 
 class Plan:
@@ -50,7 +51,7 @@ class Plan:
         cfg = L.MimoConfig(
             geom.in_channels, geom.out_channels, geom.num_subnetworks, geom.filter_base_count, batch, height, width,
             geom.encoder_dropout_rate, geom.core_dropout_rate, geom.decoder_dropout_rate,
-            1e-5, 0.1, L.LOSS_KINDS[geom.loss], 1e-5, 1e3, device.index or 0)
+            1e-5, 0.1, L.LOSS_KINDS[geom.loss], 1e-5, 1e3, device.index or 0, L.PRECISIONS[geom.precision])
         handle = C.c_void_p()
         with torch.cuda.device(device):
             L.check(self.lib.mimo_plan_create(C.byref(cfg), C.byref(handle)), "mimo_plan_create")

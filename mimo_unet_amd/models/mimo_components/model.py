@@ -15,6 +15,7 @@ in a `torch.autograd.Function`."""
 from __future__ import annotations
 
 import logging
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -171,8 +172,10 @@ class MimoUNet(nn.Module):
         self.encoder = SubnetworkEncoder(S, in_channels, f, encoder_dropout_rate)
         self.core = SubnetworkCore(S, f, core_dropout_rate, center_dropout_rate)
         self.decoder = SubnetworkDecoder(S, f, out_channels, decoder_dropout_rate, final_dropout_rate)
+        # arithmetic of the 3x3 forward / data-gradient convolutions (include/mimo_hip.h mimo_precision)
+        precision = os.environ.get("MIMO_PRECISION", "split16")
         self._geom = NetGeometry(in_channels, out_channels, S, f, encoder_dropout_rate, core_dropout_rate,
-                                 decoder_dropout_rate, loss)
+                                 decoder_dropout_rate, loss, precision)
         self._plans: Dict[tuple, Plan] = {}
         self._flat_params = self._flat_grads = self._flat_buffers = None
         self._param_list: List[nn.Parameter] = []
@@ -185,6 +188,12 @@ class MimoUNet(nn.Module):
         return ([m for m in self.encoder.in_convs] + [d.conv for d in self.encoder.down1s]
                 + [c.down2.conv, c.down3.conv, c.down4.conv, c.up1.conv, c.up2.conv, c.up3.conv]
                 + [u.conv for u in self.decoder.up4s])
+
+    def set_precision(self, precision: str) -> None:
+        """"fp32" (f32-input MFMA, exact) or "split16" (split-bf16 MFMA, ~1e-5 relative per product)."""
+        if precision != self._geom.precision:
+            self._geom = NetGeometry(**{**self._geom.__dict__, "precision": precision})
+            self._plans.clear()
 
     def set_loss(self, loss: str) -> None:
         if loss != self._geom.loss:

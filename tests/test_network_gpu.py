@@ -13,13 +13,18 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def build_model(cfg: O.NetConfig, state, *, loss="laplace_nll", lr=1e-3, wd=0.0, T=0.3, dropout=(0.0, 0.0, 0.0)):
+PRECISIONS = ["split16", "fp32"]
+
+
+def build_model(cfg: O.NetConfig, state, *, loss="laplace_nll", lr=1e-3, wd=0.0, T=0.3, dropout=(0.0, 0.0, 0.0),
+                precision="split16"):
     from mimo.models.mimo_unet import MimoUnetModel
     m = MimoUnetModel(in_channels=cfg.in_channels, out_channels=cfg.out_channels, num_subnetworks=cfg.num_subnetworks,
                       filter_base_count=cfg.filter_base_count, center_dropout_rate=0.0, final_dropout_rate=0.0,
                       encoder_dropout_rate=dropout[0], core_dropout_rate=dropout[1], decoder_dropout_rate=dropout[2],
                       loss=loss, weight_decay=wd, learning_rate=lr, seed=0, loss_buffer_size=10, loss_buffer_temperature=T)
     m.load_state_dict({"model." + k: v for k, v in state.items()})
+    m.model.set_precision(precision)
     return m.cuda()
 
 
@@ -27,24 +32,39 @@ def is_prebn_bias(k):
     return k.endswith((".0.bias", ".3.bias")) and "double_conv" in k
 
 
-def check_grads(named_grads, ref_grads, tol=TOL):
-    worst = ("", 0.0)
+def check_grads(named_grads, ref_grads, tol=TOL, flip_robust=False):
+    """Per-tensor max error relative to the tensor's scale.  flip_robust (split16 arithmetic): the
+    forward differs from fp32 by a few 1e-6, which on these tiny networks can flip a single
+    ReLU / max-pool mask and move one or two tensors by percents (the derivative is discontinuous;
+    reproduced on CPU by emulating the split arithmetic) — require 1e-3 on >= 85 % of the
+    tensors, 5e-2 on all, and the whole gradient to agree (cosine > 0.9995)."""
+    worst, errs, dot, n1, n2 = ("", 0.0), [], 0.0, 0.0, 0.0
     for k, ref in ref_grads.items():
-        g = named_grads[k]
+        g = named_grads[k].double()
+        r = torch.as_tensor(ref).double()
         scale = ref_grads[k[:-4] + "weight"] if is_prebn_bias(k) else ref  # zero-gradient biases: noise, see oracle test
-        e = float((g.double() - torch.as_tensor(ref).double()).abs().max()) / max(float(torch.as_tensor(scale).abs().max()), 1e-30)
+        e = float((g - r).abs().max()) / max(float(torch.as_tensor(scale).abs().max()), 1e-30)
+        errs.append(e)
         if e > worst[1]:
             worst = (k, e)
-        assert e < tol, (k, e)
+        if not is_prebn_bias(k):
+            dot, n1, n2 = dot + float((g * r).sum()), n1 + float((g * g).sum()), n2 + float((r * r).sum())
+        assert e < (5e-2 if flip_robust else tol), (k, e)
+    if flip_robust:
+        frac = sum(e < tol for e in errs) / len(errs)
+        cos = dot / (n1 * n2) ** 0.5
+        assert frac >= 0.85 and cos > 0.9995, (frac, cos, worst)
     return worst
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["cfg1_step.npz", "mini_s2_step.npz", "mini_gauss_step.npz"])
-def test_train_steps_match_reference_golden(name):
+def test_train_steps_match_reference_golden(name, precision):
     fx = load_npz(name)
     cfg = cfg_from_meta(fx["meta"])
     steps, lr, wd = int(fx["meta"][8]), float(fx["lr"]), float(fx["wd"])
-    model = build_model(cfg, state_from(fx, "init/"), loss=str(fx["loss_kind"]), lr=lr, wd=wd, T=float(fx["temperature"]))
+    model = build_model(cfg, state_from(fx, "init/"), loss=str(fx["loss_kind"]), lr=lr, wd=wd, T=float(fx["temperature"]),
+                        precision=precision)
     model.train()
     opt = model.configure_optimizers()["optimizer"]
     for it in range(steps):
@@ -67,8 +87,9 @@ def test_train_steps_match_reference_golden(name):
             preds = out_dict["preds"].view(N, S, half, *image.shape[-2:]).cpu()
             e_out = rel_err(preds, ref_out[:, :, :half])
             grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
-            worst = check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")})
-            print(f"{name}: out err {e_out:.2e}, worst grad err {worst[1]:.2e} at {worst[0]}")
+            worst = check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")},
+                                flip_robust=(precision != "fp32"))
+            print(f"{name} [{precision}]: out err {e_out:.2e}, worst grad err {worst[1]:.2e} at {worst[0]}")
             assert e_out < TOL
             sd = model.state_dict()
             for k, v in fx.items():
@@ -92,18 +113,19 @@ def test_train_steps_match_reference_golden(name):
             assert rel_err(ours, v) < TOL, name_
         else:  # Adam turns rounding-level gradient differences into sign-level update differences
             d = np.abs(ours - v)
-            assert d.max() <= 1.0 * budget + 1e-5 * np.abs(v).max(), (name_, d.max())
-            rms_bound = (0.05 if d.size >= 256 else 0.25) * budget  # few-element tensors: rms ~ max
+            assert d.max() <= 2.02 * budget + 1e-5 * np.abs(v).max(), (name_, d.max())  # two runs, opposite signs
+            rms_bound = (0.1 if d.size >= 256 else 0.25) * budget  # few-element tensors: rms ~ max
             assert np.sqrt((d ** 2).mean()) <= rms_bound, (name_, np.sqrt((d ** 2).mean()))
     np.testing.assert_allclose(model.loss_buffer.buffer.numpy(), fx["final/loss_buffer"], rtol=TOL, atol=1e-6)
 
 
-def test_input_gradient_and_generic_backward_cfg1():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_input_gradient_and_generic_backward_cfg1(precision):
     """dL/d(input image) through the plain forward + torch-side loss (the FGSM path,
     scripts/test/test_nyuv2_depth.py:41-55)."""
     fx = load_npz("cfg1_step.npz")
     cfg = cfg_from_meta(fx["meta"])
-    model = build_model(cfg, state_from(fx, "init/"))
+    model = build_model(cfg, state_from(fx, "init/"), precision=precision)
     model.train()
     x = torch.from_numpy(fx["s0/image"])[torch.from_numpy(fx["s0/perms"])[0]][:, None].cuda().requires_grad_(True)
     y = torch.from_numpy(fx["s0/label"])[torch.from_numpy(fx["s0/perms"])[0]][:, None].cuda()
@@ -111,10 +133,11 @@ def test_input_gradient_and_generic_backward_cfg1():
     loss = model.loss_fn.forward(p1, p2, y, reduce_mean=False).mean(dim=(0, 2, 3, 4)).mean()
     loss.backward()
     e = rel_err(x.grad.cpu(), fx["s0/dx"])
-    print(f"dx err {e:.2e}")
-    assert e < TOL
+    print(f"[{precision}] dx err {e:.2e}")
+    assert e < (TOL if precision == "fp32" else 5e-2)
     grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
-    check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")})
+    check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")},
+                flip_robust=(precision != "fp32"))
 
 
 @pytest.mark.parametrize("tag", ["50x70", "100x100", "128x160"])
@@ -171,7 +194,7 @@ def _oracle_run(cfg, st, image, label, mask, perms, lb_w, loss, dtype):
     return ts, O.train_step(ts, cast(image), cast(label), cast(mask), perms, apply_optimizer=False)
 
 
-def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False):
+def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, precision="split16"):
     """One training step (forward, loss, backward) of the HIP path against the CPU oracle.
 
     Outputs, losses and BatchNorm buffers: 1e-3 relative against the fp32 oracle.
@@ -194,7 +217,7 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False):
     label = torch.rand(N, cfg.out_channels // 2, H, W, generator=g)
     mask = (torch.rand(N, 1, H, W, generator=g) > 0.3).float() if with_mask else None
     perms = O.draw_perms(N, cfg.num_subnetworks, generator=g)
-    model = build_model(cfg, st, loss=loss)
+    model = build_model(cfg, st, loss=loss, precision=precision)
     model.train()
     lb_w = torch.tensor([0.7 + 0.6 * s / max(cfg.num_subnetworks - 1, 1) for s in range(cfg.num_subnetworks)])
     model.loss_buffer.get_weights = lambda: lb_w  # fixed non-uniform weights on both sides
@@ -223,23 +246,25 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False):
         nr += float((g64 ** 2).sum())
         nd += float(((grads[k] - g64) ** 2).sum())
     cos, rel_l2 = dot / (nh * nr) ** 0.5, (nd / nr) ** 0.5
-    print(f"out {e_out:.2e} loss {e_loss:.2e} bn-buffers {e_buf:.2e}; grads vs fp64: cos {cos:.7f} rel-L2 {rel_l2:.2e}; "
+    print(f"[{precision}] out {e_out:.2e} loss {e_loss:.2e} bn-buffers {e_buf:.2e}; grads vs fp64: cos {cos:.7f} rel-L2 {rel_l2:.2e}; "
           f"worst tensor {worst[0]} hip {worst[1]:.2e} (fp32 oracle {worst[2]:.2e})")
     assert e_out < TOL and e_loss < TOL and e_buf < TOL
     assert cos > 0.9999 and rel_l2 < 2e-2
     return e_out, worst
 
 
-def test_cfg3_shape_vs_oracle():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_cfg3_shape_vs_oracle(precision):
     """BASELINE config[2] geometry (2->1 ch, 256x256, S=2, fbc=30) at a batch the CPU oracle finishes in seconds."""
-    e_out, worst = _oracle_vs_hip(O.NetConfig(2, 2, 2, 30), N=2, H=256, W=256, seed=5)
+    e_out, worst = _oracle_vs_hip(O.NetConfig(2, 2, 2, 30), N=2, H=256, W=256, seed=5, precision=precision)
     print(f"cfg3-shape: out err {e_out:.2e}; worst grad {worst}")
     assert e_out < TOL
 
 
-def test_cfg2_shape_vs_oracle():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_cfg2_shape_vs_oracle(precision):
     """BASELINE config[1] geometry (3->1 ch, S=2, fbc=21: channel counts 21/42/63/31 exercise every padding path)."""
-    e_out, worst = _oracle_vs_hip(O.NetConfig(3, 2, 2, 21), N=2, H=128, W=128, seed=6, with_mask=True)
+    e_out, worst = _oracle_vs_hip(O.NetConfig(3, 2, 2, 21), N=2, H=128, W=128, seed=6, with_mask=True, precision=precision)
     print(f"cfg2-shape: out err {e_out:.2e}; worst grad {worst}")
     assert e_out < TOL
 

@@ -42,9 +42,14 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("precision", ["fp32", "split16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv3x3_forward_dgrad_wgrad(case):
+def test_conv3x3_forward_dgrad_wgrad(case, precision):
+    """fp32: f32-input MFMA (exact fp32 products).  split16: fp16 hi/lo forward (~2^-22 per product),
+    bf16 hi/lo data and weight gradients (~1e-5 per product) -> tolerance 1e-4."""
     L = _lib()
+    prec = L.PRECISIONS[precision]
+    tol = TOL if precision == "fp32" else 1e-4
     lib = L.load()
     N, H, W, Ci, Co = case
     g = torch.Generator().manual_seed(sum(case))
@@ -63,7 +68,7 @@ def test_conv3x3_forward_dgrad_wgrad(case):
     zd = torch.full((N, H, W, cop), float("nan"), device="cuda")
     stats = torch.zeros(2, Co, dtype=torch.float64, device="cuda")
     L.check(lib.mimo_op_conv3x3_forward(xd.data_ptr(), wd_.data_ptr(), bd.data_ptr(), zd.data_ptr(), stats.data_ptr(),
-                                        N, H, W, Ci, cip, Co, cop, st), "conv fwd")
+                                        N, H, W, Ci, cip, Co, cop, prec, st), "conv fwd")
     torch.cuda.synchronize()
     z = from_nhwc(zd, Co)
     errs = {"fwd": rel_err(z, z_ref.detach())}
@@ -74,18 +79,18 @@ def test_conv3x3_forward_dgrad_wgrad(case):
     # data gradient (transposed conv + fold of the reflect border)
     dzd = to_nhwc(dz, cop)
     dxd = torch.full((N, H, W, cip), float("nan"), device="cuda")
-    L.check(lib.mimo_op_conv3x3_dgrad(dzd.data_ptr(), wd_.data_ptr(), dxd.data_ptr(), N, H, W, Ci, cip, Co, cop, st),
+    L.check(lib.mimo_op_conv3x3_dgrad(dzd.data_ptr(), wd_.data_ptr(), dxd.data_ptr(), N, H, W, Ci, cip, Co, cop, prec, st),
             "conv dgrad")
     errs["dgrad"] = rel_err(from_nhwc(dxd, Ci), xr.grad)
     # weight / bias gradient
     dwd = torch.full((Co, Ci, 3, 3), float("nan"), device="cuda")
     dbd = torch.full((Co,), float("nan"), device="cuda")
     L.check(lib.mimo_op_conv3x3_wgrad(xd.data_ptr(), dzd.data_ptr(), dwd.data_ptr(), dbd.data_ptr(), N, H, W, Ci, cip,
-                                      Co, cop, st), "conv wgrad")
+                                      Co, cop, prec, st), "conv wgrad")
     errs["wgrad"] = rel_err(dwd.cpu(), wr.grad)
     errs["bgrad"] = rel_err(dbd.cpu(), br.grad)
-    print("conv", case, {k: f"{v:.2e}" for k, v in errs.items()})
-    bad = {k: v for k, v in errs.items() if not v < TOL}
+    print("conv", precision, case, {k: f"{v:.2e}" for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not v < (TOL if k in ("bgrad", "sum", "sumsq") else tol)}
     assert not bad, bad
 
 
