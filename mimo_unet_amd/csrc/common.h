@@ -76,6 +76,8 @@ void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO);
 int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO);
 int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream);
 int wgrad_pick_splits(int N, int H, int W, int cin_pad, int cout_pad);
+// extra floats the reduction needs behind the splits*9*cin_pad*cout_pad partial slabs
+size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad);
 // dW[co][ci][kh][kw] (torch OIHW) = sum over splits of partial[..][tap][cin_map^-1(ci)][co]
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map,
                         int cin_p, int cin, int cout, float* dw, hipStream_t stream);

@@ -9,6 +9,8 @@
 // Layout: activations NHWC with the channel count padded to a multiple of 8 (zero-filled).
 // Implicit GEMM: M = output pixels of a TR x TC tile (linearised, 16 per MFMA fragment),
 // N = output channels (16 per fragment), K = 9 taps x input channels (4 per MFMA).
+#include <algorithm>
+
 #include "common.h"
 
 namespace mimo {
@@ -402,31 +404,81 @@ int wgrad_launch(const WgradLaunch& a, hipStream_t stream) {
   return MIMO_OK;
 }
 
-// dw (torch OIHW [cout][cin][3][3]) <- sum over splits; cin_map[padded ci] = logical ci or -1
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int cin_pad, int cout_pad,
-                                    const int* __restrict__ cin_map, int cin_p, int cin, int cout,
-                                    float* __restrict__ dw) {
-  const int total = 9 * cin_p * cout;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int co = i % cout;
-    const int rest = i / cout;
-    const int cip = rest % cin_p, tap = rest / cin_p;
+// dw (torch OIHW [cout][cin][3][3]) <- sum over splits of partial[split][tap][ci_pad][co_pad];
+// cin_map[padded ci] = logical ci or -1.  Two stages, both fully coalesced:
+//   A (only when splits > kReduceFan): slab group sums, element-wise, grid over (elements, groups)
+//   B: per (32 ci x 32 co) tile, sum <= kReduceFan slabs with co-contiguous reads, transpose the
+//      [9][32][32] tile through LDS and write torch's layout as 288-float contiguous runs per co
+constexpr int kReduceFan = 16;
+
+__global__ void wgrad_group_sum_kernel(const float* __restrict__ partial, int splits, size_t slab, float* __restrict__ out) {
+  const int grp = blockIdx.y;
+  const int s0 = grp * kReduceFan, s1 = min(splits, s0 + kReduceFan);
+  const size_t n4 = slab / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = s0; s < s1; ++s) {
+      const float4 v = reinterpret_cast<const float4*>(partial + (size_t)s * slab)[i];
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(out + (size_t)grp * slab)[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int cin_pad,
+                                                           int cout_pad, const int* __restrict__ cin_map, int cin_p,
+                                                           int cin, int cout, float* __restrict__ dw) {
+  constexpr int PITCH = 289;  // 32*9 + 1: conflict-free transposed LDS writes
+  __shared__ float tile[32 * PITCH];
+  const int coTiles = cout_pad / 32;
+  const int ciT = blockIdx.x / coTiles, coT = blockIdx.x - ciT * coTiles;
+  const int ci0 = ciT * 32, co0 = coT * 32;
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const size_t slab = (size_t)9 * cin_pad * cout_pad;
+  for (int row = rl; row < 288; row += 8) {  // row = tap*32 + ci_local
+    const int tap = row >> 5, cil = row & 31;
+    const float* p = partial + ((size_t)tap * cin_pad + ci0 + cil) * cout_pad + co0 + col;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += p[k * slab];
+    tile[col * PITCH + cil * 9 + tap] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 288; i += 256) {
+    const int co = i / 288, j = i - co * 288;
+    const int cil = j / 9, tap = j - cil * 9;
+    const int cip = ci0 + cil;
+    if (co0 + co >= cout || cip >= cin_p) continue;
     const int ci = cin_map ? cin_map[cip] : (cip < cin ? cip : -1);
     if (ci < 0) continue;
-    const size_t stride = (size_t)9 * cin_pad * cout_pad;
-    const float* p = partial + ((size_t)tap * cin_pad + cip) * cout_pad + co;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += p[k * stride];
-    dw[((size_t)co * cin + ci) * 9 + tap] = s;
+    dw[((size_t)(co0 + co) * cin + ci) * 9 + tap] = tile[co * PITCH + j];
   }
+}
+
+// scratch (floats) the reduction needs behind the `splits` slabs of the wgrad kernels
+size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad) {
+  return splits > kReduceFan ? (size_t)ceil_div(splits, kReduceFan) * 9 * cin_pad * cout_pad : 0;
 }
 
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map, int cin_p,
                         int cin, int cout, float* dw, hipStream_t stream) {
-  const int total = 9 * cin_p * cout;
-  const int blocks = min(ceil_div(total, 256), 4096);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, splits, cin_pad, cout_pad,
-                     cin_map, cin_p, cin, cout, dw);
+  const size_t slab = (size_t)9 * cin_pad * cout_pad;
+  const float* src = partial;
+  int n = splits;
+  while (n > kReduceFan) {  // stage A (repeated for very large split counts); output behind the inputs
+    const int groups = ceil_div(n, kReduceFan);
+    float* out = const_cast<float*>(src) + (size_t)n * slab;
+    const int bx = (int)std::min<size_t>((slab / 4 + 255) / 256, 512);
+    hipLaunchKernelGGL(wgrad_group_sum_kernel, dim3(bx, groups), dim3(256), 0, stream, src, n, slab, out);
+    MIMO_KERNEL_CHECK();
+    src = out;
+    n = groups;
+  }
+  const int blocks = (cin_pad / 32) * (cout_pad / 32);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, n, cin_pad, cout_pad, cin_map, cin_p,
+                     cin, cout, dw);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

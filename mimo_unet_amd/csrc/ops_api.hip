@@ -169,7 +169,7 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
                           mimo_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   Temp t;
-  const bool split = precision == MIMO_PREC_SPLIT16 && cin_p >= 16;
+  const bool split = precision == MIMO_PREC_SPLIT16;
   WgradLaunch a;
   a.x = x;
   a.dz = dz;
@@ -191,7 +191,7 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
     a.cout_pad = round_up(cout_p, 32);
     a.splits = wgrad_pick_splits(n, h, wd, a.cin_pad, a.cout_pad);
   }
-  a.partial = t.get<float>((size_t)a.splits * 9 * a.cin_pad * a.cout_pad);
+  a.partial = t.get<float>((size_t)(a.splits + a.splits / 8 + 2) * 9 * a.cin_pad * a.cout_pad);
   int* cm = t.ints(ident_map(cin_p, cin));
   if (!a.partial || !cm) {
     set_error("mimo_op_conv3x3_wgrad: allocation failed");

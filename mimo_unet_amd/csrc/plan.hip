@@ -231,7 +231,7 @@ struct mimo_plan {
     L.N = n;
     L.H = h;
     L.W = w;
-    L.wg_split = cfg.precision == MIMO_PREC_SPLIT16 && L.cin_p >= 16;
+    L.wg_split = cfg.precision == MIMO_PREC_SPLIT16;
     if (L.wg_split) {
       int CI, CO;
       wgrad_split_tiles(L.cin_p, L.cout_p, &CI, &CO);
@@ -284,7 +284,8 @@ struct mimo_plan {
     const size_t padv = (size_t)n * (h + 2) * (w + 2) * L.cin_p;
     cap_act = std::max(cap_act, act);
     cap_pad = std::max(cap_pad, padv);
-    cap_slab = std::max(cap_slab, (size_t)L.wg_splits * 9 * L.wg_cin_pad * L.wg_cout_pad);
+    // slabs + the reduction's group-sum levels (geometric: < splits/15 extra slabs)
+    cap_slab = std::max(cap_slab, (size_t)(L.wg_splits + L.wg_splits / 8 + 2) * 9 * L.wg_cin_pad * L.wg_cout_pad);
     const size_t stat_rows = conv3x3_stat_rows(n, h, w);
     cap_partial = std::max(cap_partial, stat_rows * 2 * L.cout_pad);
     cap_partial = std::max(cap_partial, (size_t)kEwMaxBlocks * 2 * L.cout_p);

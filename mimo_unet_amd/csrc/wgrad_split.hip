@@ -242,7 +242,7 @@ int wgrad_split_num_tiles(int N, int H, int W) { return N * ceil_div(H, kWgTR) *
 int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO) {
   const int wtiles = (cin_pad / CI) * (cout_pad / CO);
   const int tiles = wgrad_split_num_tiles(N, H, W);
-  int splits = ceil_div(1024, wtiles);  // one 4-wave workgroup per CU: ~4 waves of workgroups
+  int splits = ceil_div(512, wtiles);  // one 4-wave workgroup per CU: ~2 rounds of workgroups
   if (splits > tiles) splits = tiles;
   if (splits > 1024) splits = 1024;
   if (splits < 1) splits = 1;
