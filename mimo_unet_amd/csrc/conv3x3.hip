@@ -433,16 +433,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int cin, int cout, float* __restrict__ dw) {
   constexpr int PITCH = 289;  // 32*9 + 1: conflict-free transposed LDS writes
   __shared__ float tile[32 * PITCH];
-  const int coTiles = cout_pad / 32;
+  const int coTiles = (cout_pad + 31) / 32;  // cin_pad / cout_pad are multiples of 32 or 48
   const int ciT = blockIdx.x / coTiles, coT = blockIdx.x - ciT * coTiles;
   const int ci0 = ciT * 32, co0 = coT * 32;
   const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const size_t slab = (size_t)9 * cin_pad * cout_pad;
   for (int row = rl; row < 288; row += 8) {  // row = tap*32 + ci_local
     const int tap = row >> 5, cil = row & 31;
-    const float* p = partial + ((size_t)tap * cin_pad + ci0 + cil) * cout_pad + co0 + col;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += p[k * slab];
+    if (ci0 + cil < cin_pad && co0 + col < cout_pad) {
+      const float* p = partial + ((size_t)tap * cin_pad + ci0 + cil) * cout_pad + co0 + col;
+      for (int k = 0; k < splits; ++k) s += p[k * slab];
+    }
     tile[col * PITCH + cil * 9 + tap] = s;
   }
   __syncthreads();
@@ -476,7 +478,7 @@ int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_
     src = out;
     n = groups;
   }
-  const int blocks = (cin_pad / 32) * (cout_pad / 32);
+  const int blocks = ceil_div(cin_pad, 32) * ceil_div(cout_pad, 32);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, n, cin_pad, cout_pad, cin_map, cin_p,
                      cin, cout, dw);
   MIMO_KERNEL_CHECK();

@@ -22,6 +22,8 @@
 //     writes the prefetched registers to LDS: global latency hides under the MFMA work
 //   * LDS rows are 64 bf16 (32 hi | 32 lo) + 16 B pad = 144 B: ds_read_b128 fragment reads with
 //     compile-time offsets, 16 consecutive pixels land on distinct bank quads
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mimo {
@@ -337,7 +339,10 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
   const int nfr = a.cout_pad / 16;
   int nf = 4;
   while (nfr % nf != 0) --nf;
-  if (use_big_tile(a.Ho, a.Wo)) {
+  // NF <= 2: little MFMA work per tile -> 256-pixel tiles so that two workgroups share a CU and
+  // one's loads / stores overlap the other's MFMAs (MIMO_CONV_BIGTILE_NF2=1 restores 512-pixel tiles)
+  static const bool big_nf2 = getenv("MIMO_CONV_BIGTILE_NF2") && atoi(getenv("MIMO_CONV_BIGTILE_NF2")) != 0;
+  if (use_big_tile(a.Ho, a.Wo) && (nf >= 3 || big_nf2)) {
     switch (nf) {
       case 4: return launch_bf16x3<4, 4, F16>(a, rows, stream);
       case 3: return launch_bf16x3<4, 3, F16>(a, rows, stream);

@@ -231,10 +231,18 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
   }
 }
 
-// (ci tile, co tile) of the split kernel for a layer
+// (ci tile, co tile) of the split kernel for a layer: 32, 48 or 64 channels, whichever pads least
+// (ties -> the larger tile: fewer re-reads of the other operand)
+static int pick_ctile(int c_p) {
+  if (c_p <= 32) return 32;
+  // 48-wide tiles only where they save >= 15 % of padded work (48, 96, 144 channels): they hold
+  // more accumulators per wave and run a little slower per MFMA than the 64-wide configuration
+  const int p64 = round_up(c_p, 64), p48 = round_up(c_p, 48);
+  return (double)p48 <= 0.85 * p64 ? 48 : 64;
+}
 void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO) {
-  *CI = cin_p <= 32 ? 32 : 64;
-  *CO = cout_p <= 32 ? 32 : 64;
+  *CI = pick_ctile(cin_p);
+  *CO = pick_ctile(cout_p);
 }
 
 int wgrad_split_num_tiles(int N, int H, int W) { return N * ceil_div(H, kWgTR) * ceil_div(W, kWgTC); }
@@ -259,14 +267,21 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
   const int tilesY = ceil_div(a.H, kWgTR), tilesX = ceil_div(a.W, kWgTC);
   const int numTiles = a.N * tilesY * tilesX;
   dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
-  if (CI == 32 && CO == 32)
-    hipLaunchKernelGGL((wgrad_split_kernel<2, 2, 1, 1, 4>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
-  else if (CI == 64 && CO == 32)
-    hipLaunchKernelGGL((wgrad_split_kernel<2, 2, 2, 1, 2>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
-  else if (CI == 32 && CO == 64)
-    hipLaunchKernelGGL((wgrad_split_kernel<2, 2, 1, 2, 2>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
-  else
-    hipLaunchKernelGGL((wgrad_split_kernel<2, 2, 2, 2, 1>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles);
+#define WG_LAUNCH(MI, NI, WM, WN, WK) \
+  hipLaunchKernelGGL((wgrad_split_kernel<MI, NI, WM, WN, WK>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles)
+  const int key = CI * 100 + CO;
+  switch (key) {
+    case 3232: WG_LAUNCH(2, 2, 1, 1, 4); break;
+    case 3248: WG_LAUNCH(2, 3, 1, 1, 4); break;
+    case 3264: WG_LAUNCH(2, 2, 1, 2, 2); break;
+    case 4832: WG_LAUNCH(3, 2, 1, 1, 4); break;
+    case 4848: WG_LAUNCH(3, 3, 1, 1, 4); break;
+    case 4864: WG_LAUNCH(3, 2, 1, 2, 2); break;
+    case 6432: WG_LAUNCH(2, 2, 2, 1, 2); break;
+    case 6448: WG_LAUNCH(2, 3, 2, 1, 2); break;
+    default: WG_LAUNCH(2, 2, 2, 2, 1); break;
+  }
+#undef WG_LAUNCH
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

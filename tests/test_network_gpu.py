@@ -114,7 +114,7 @@ def test_train_steps_match_reference_golden(name, precision):
         else:  # Adam turns rounding-level gradient differences into sign-level update differences
             d = np.abs(ours - v)
             assert d.max() <= 2.02 * budget + 1e-5 * np.abs(v).max(), (name_, d.max())  # two runs, opposite signs
-            rms_bound = (0.1 if d.size >= 256 else 0.25) * budget  # few-element tensors: rms ~ max
+            rms_bound = (0.1 if d.size >= 256 else 1.0) * budget  # few-element tensors: rms ~ max (one Adam sign flip)
             assert np.sqrt((d ** 2).mean()) <= rms_bound, (name_, np.sqrt((d ** 2).mean()))
     np.testing.assert_allclose(model.loss_buffer.buffer.numpy(), fx["final/loss_buffer"], rtol=TOL, atol=1e-6)
 
@@ -310,3 +310,61 @@ def test_full_size_properties():
         b1, b2 = model(x5[pi])
     assert rel_err(b1.cpu(), a1[pi].cpu()) < 1e-5 and rel_err(b2.cpu(), a2[pi].cpu()) < 1e-5
     assert p1.shape == a1.shape
+
+
+def test_validation_step_matches_oracle():
+    """validation_step (mimo_unet.py:146-183): repeat over S, per-subnetwork NLL, uncertainties,
+    combined NLL — against the oracle's restatement, eval-mode BatchNorm."""
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    st = state_from(fx, "final/")
+    st.pop("loss_buffer", None)
+    model = build_model(cfg, st)
+    model.eval()
+    image, label, mask = (torch.from_numpy(fx[f"s0/{k}"]) for k in ("image", "label", "mask"))
+    out = model.validation_step({"image": image.cuda(), "label": label.cuda(), "mask": mask.cuda()}, 0)
+    S = cfg.num_subnetworks
+    with torch.no_grad():
+        o = O.mimo_unet_forward(cfg, st, O.repeat_subnetworks(image, S), training=False)
+        p1, p2 = O.split_heads(o, cfg.out_channels)
+        lab = O.repeat_subnetworks(label, S)
+        val_loss = O.laplace_nll(p1, p2, lab, mask=O.repeat_subnetworks(mask, S), reduce_mean=False).mean(dim=(0, 2, 3, 4))
+        mean, alea, epi = O.compute_uncertainties("laplace_nll", p1, p2)
+        comb = O.calculate_dist_param("laplace_nll", torch.sqrt(alea + epi), log=True)
+        val_comb = O.laplace_nll(p1.mean(dim=1), comb, label, mask=mask)
+    assert abs(out["loss"].item() - float(val_loss.mean())) <= TOL * abs(float(val_loss.mean()))
+    assert rel_err(out["preds"].cpu(), mean) < TOL
+    assert rel_err(out["aleatoric_std_map"].cpu(), alea.sqrt()) < TOL
+    assert rel_err(out["epistemic_std_map"].cpu(), epi.sqrt()) < TOL
+    assert rel_err(out["err_map"].cpu(), mean - label) < TOL
+    assert abs(model.logged["val_loss_combined"].item() - float(val_comb)) <= TOL * abs(float(val_comb))
+    for s in range(S):
+        assert abs(model.logged[f"val_loss_{s}"].item() - float(val_loss[s])) <= TOL * abs(float(val_loss[s]))
+    assert set(out) == {"loss", "label", "preds", "aleatoric_std_map", "epistemic_std_map", "err_map", "mask"}
+
+
+def test_deep_ensemble_of_two_checkpoints(tmp_path):
+    """EnsembleModule over two checkpoints (ensemble.py:42,95-113): predictions concatenated on the
+    subnetwork axis, uncertainties over all of them; checkpoints written and re-loaded from disk."""
+    from mimo.models.ensemble import EnsembleModule
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    states = [state_from(fx, "init/"), state_from(fx, "final/")]
+    states[1].pop("loss_buffer", None)
+    paths = []
+    for i, st in enumerate(states):
+        m = build_model(cfg, st).cpu()
+        p = str(tmp_path / f"m{i}.ckpt")
+        torch.save({"state_dict": m.state_dict(), "hyper_parameters": dict(m.hparams)}, p)
+        paths.append(p)
+    ens = EnsembleModule(paths).cuda()
+    x = torch.from_numpy(fx["s1/image"])
+    mean, alea, epi = ens(x.cuda())
+    assert ens.num_subnetworks == 2 * cfg.num_subnetworks and not mean.is_cuda
+    with torch.no_grad():
+        outs = [O.mimo_unet_forward(cfg, st, O.repeat_subnetworks(x, cfg.num_subnetworks), training=False) for st in states]
+        p1 = torch.cat([O.split_heads(o, cfg.out_channels)[0] for o in outs], 1)
+        p2 = torch.cat([O.split_heads(o, cfg.out_channels)[1] for o in outs], 1)
+        ref = O.compute_uncertainties("laplace_nll", p1, p2)
+    for a, b in zip((mean, alea, epi), ref):
+        assert rel_err(a, b) < TOL
