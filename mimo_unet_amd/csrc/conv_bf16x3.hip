@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
 
   // ---- staging helpers (plain unrolled code: the prefetch arrays must stay in registers) ------
   f32x4 xreg[XU];
-  u32x4 wreg[WU];
+  u32x4 wreg[3][WU];  // weights in flight for the next TWO phases (memory latency under load > one phase)
 #define MIMO_LOAD_X(CHUNK)                                                                      \
   _Pragma("unroll") for (int k_ = 0; k_ < XU; ++k_) {                                           \
     const int u_ = tid + k_ * 512;                                                              \
@@ -172,20 +172,20 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
     }                                                                                           \
   }
   // weights of chunk CHUNK, tap row ROW: global [chunk][tap][cout_pad][8 x 16 B]
-#define MIMO_LOAD_W(CHUNK, ROW)                                                                 \
+#define MIMO_LOAD_W(SLOT, CHUNK, ROW)                                                           \
   _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                           \
     const int u_ = min(tid + k_ * 512, WUNITS - 1);                                             \
     const int t_ = u_ / (NB * 8);                                                               \
     const int rem_ = u_ - t_ * (NB * 8);                                                        \
-    wreg[k_] = wpk[(((size_t)(CHUNK) * 9 + ((ROW) * 3 + t_)) * a.cout_pad + co0 + (rem_ >> 3)) * 8 + (rem_ & 7)]; \
+    wreg[SLOT][k_] = wpk[(((size_t)(CHUNK) * 9 + ((ROW) * 3 + t_)) * a.cout_pad + co0 + (rem_ >> 3)) * 8 + (rem_ & 7)]; \
   }
-#define MIMO_STORE_W(BUF)                                                                       \
+#define MIMO_STORE_W(SLOT, BUF)                                                                 \
   _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                           \
     const int u_ = tid + k_ * 512;                                                              \
     if (u_ < WUNITS) {                                                                          \
       const int t_ = u_ / (NB * 8);                                                             \
       const int rem_ = u_ - t_ * (NB * 8);                                                      \
-      *reinterpret_cast<u32x4*>(ws + (BUF) * WROWB + (t_ * NB + (rem_ >> 3)) * kPitchB + (rem_ & 7) * 16) = wreg[k_]; \
+      *reinterpret_cast<u32x4*>(ws + (BUF) * WROWB + (t_ * NB + (rem_ >> 3)) * kPitchB + (rem_ & 7) * 16) = wreg[SLOT][k_]; \
     }                                                                                           \
   }
 
@@ -207,20 +207,27 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
     for (int nf = 0; nf < NF; ++nf) acc[m][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // prologue: chunk 0, tap row 0
+  // phase p = 3*c + r uses weight slot r; slot (r+1)%3 holds phase p+1 (in registers), slot (r+2)%3
+  // is being loaded for phase p+2
+  const int nphases = 3 * nchunks;
   MIMO_LOAD_X(0)
-  MIMO_LOAD_W(0, 0)
+  MIMO_LOAD_W(0, 0, 0)
+  if (nphases > 1) {
+    MIMO_LOAD_W(1, 0, 1)
+  }
   MIMO_STORE_X()
-  MIMO_STORE_W(0)
+  MIMO_STORE_W(0, 0)
   __syncthreads();
 
   int buf = 0;
   for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const bool last = (c == nchunks - 1) && (r == 2);
-      if (!last) {
-        const int nc = r < 2 ? c : c + 1, nr = r < 2 ? r + 1 : 0;
-        MIMO_LOAD_W(nc, nr)
+      const int ph = 3 * c + r;
+      const bool last = ph + 1 >= nphases;
+      if (ph + 2 < nphases) {  // two phases ahead: (c, r+2) or (c+1, r-1)
+        const int nc = r < 1 ? c : c + 1, nr = (r + 2) % 3;
+        MIMO_LOAD_W((r + 2) % 3, nc, nr)
       }
       if (r == 0 && c + 1 < nchunks) {
         MIMO_LOAD_X(c + 1)
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
         }
       }
       if (!last) {  // other buffer: last read one phase ago, behind a barrier
-        MIMO_STORE_W(buf ^ 1)
+        MIMO_STORE_W((r + 1) % 3, buf ^ 1)
       }
       if (r == 2 && c + 1 < nchunks) {
         __syncthreads();  // every wave is done reading this chunk's input tile
