@@ -86,6 +86,7 @@ def main():
     args = ap.parse_args()
     c = dict(CONFIGS[args.config])
     if args.batch:
+        c["name"] = c["name"].replace(f"batch {c['batch']} per GPU", f"batch {args.batch} per GPU (non-default)")
         c["batch"] = args.batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,12 +94,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU over RCCL ("nccl").  MIMO_BENCH_BACKEND=gloo lets several ranks share one GPU
+    # (functional check of the data-parallel path on a single-GPU box; not a performance configuration)
+    backend = os.environ.get("MIMO_BENCH_BACKEND", "nccl")
+    dev = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(1)
     model = make_model(c).cuda()
@@ -113,13 +121,15 @@ def main():
 
     from mimo_unet_amd.ddp import FlatGradientAllReducer
     reducer = FlatGradientAllReducer() if world > 1 else None
+    if reducer is not None:
+        reducer.attach(model.model)  # all-reduce of the core/decoder gradients overlaps the encoder backward
 
     def step(i):
         opt.zero_grad()
         out = model.training_step(batch, i)
         out["loss"].backward()
         if reducer is not None:
-            reducer.all_reduce(model.model.flat_gradients())  # bucketed sum over RCCL; FlatAdam scales by 1/world
+            reducer.finish()  # bucketed sums over RCCL were started from inside backward; FlatAdam scales by 1/world
         opt.step()
         return out["loss"]
 
@@ -175,7 +185,8 @@ def main():
         "dtype": "f32" if os.environ.get("MIMO_PRECISION", "split16") == "fp32" else "f32 (split into 16-bit hi/lo pairs on the MFMA)",
         "data": "synthetic",
         "config": {"workload": c["name"], "global_batch": world * B, "per_gpu_batch": B, "image": [c["H"], c["W"]],
-                   "parallelism": f"dp{world}", "optimizer": "adam(lr=1e-3) fused", "final_loss": round(float(loss.detach()), 5)},
+                   "parallelism": f"dp{world}" + ("" if world == 1 else f" ({backend}, all-reduce overlapped with the encoder backward)"),
+                   "optimizer": "adam(lr=1e-3) fused", "final_loss": round(float(loss.detach()), 5)},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

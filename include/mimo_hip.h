@@ -115,6 +115,15 @@ int mimo_loss_forward(mimo_plan* plan, const float* label, const float* mask, co
  * Parameter gradients are written (not accumulated) into the bound flat grads buffer. */
 int mimo_backward(mimo_plan* plan, const float* dout, const float* dloss, float* dx, mimo_stream stream);
 
+/* The same backward in two stages, for data-parallel training (no reference counterpart: the reference
+ * is single-GPU).  stage 0 = heads + decoders + shared core, stage 1 = the S encoders (+ dx).  The flat
+ * gradient buffer is laid out encoder | core | decoder | heads, so after stage 0 the range
+ * [mimo_plan_encoder_param_floats(plan), mimo_plan_param_floats(plan)) — 99 % of the bytes — is final
+ * and its all-reduce can overlap stage 1. */
+int mimo_backward_stage(mimo_plan* plan, int stage, const float* dout, const float* dloss, float* dx,
+                        mimo_stream stream);
+int64_t mimo_plan_encoder_param_floats(const mimo_plan* plan);
+
 /* ---- measurement (no reference counterpart): per-kernel-class device time from HIP events
  * recorded on the launch stream around every 3x3 convolution launch, with the ALGORITHMIC
  * flops (2*9*Cin*Cout*N*H*W, logical channels) and bytes ((Cin+Cout)*N*H*W*4) of those

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "mimo_forward": (C.c_int, [_P, C.POINTER(ForwardArgs), _P]),
     "mimo_loss_forward": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "mimo_backward": (C.c_int, [_P, _P, _P, _P, _P]),
+    "mimo_backward_stage": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "mimo_plan_encoder_param_floats": (_L, [_P]),
     "mimo_plan_profile": (C.c_int, [_P, C.c_int]),
     "mimo_plan_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double)]),

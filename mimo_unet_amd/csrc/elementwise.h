@@ -53,19 +53,21 @@ int up_bwd_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, i
                   int Cp, int accumulate, hipStream_t st);
 
 // ---- BatchNorm + ReLU backward ------------------------------------------------------------
-// dy = da * mask * [z*scale+shift > 0]; partial rows of (sum dy, sum dy*xhat).
+// dy = da * mask * [z*scale+shift > 0] is evaluated on the fly by both passes (never stored).
 // da source: plain (da != nullptr, ldda) or folded from dxpad (da == nullptr).
+// pass 1: partial rows of (sum dy, sum dy*xhat)
 int bnrelu_bwd_reduce_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
                              const float* scale, const float* shift, const float* mean, const float* invstd,
-                             const float* mask, int C, int Cp, int N, int H, int W, float* dy, float* partial,
-                             int* rows, hipStream_t st);
+                             const float* mask, int C, int Cp, int N, int H, int W, float* partial, int* rows,
+                             hipStream_t st);
 // c1 = sum_dy/count, c2 = sum_dyxhat/count (zero when !training); dgamma, dbeta -> grads
 int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_t count, int training, float* c1,
                            float* c2, float* dgamma, float* dbeta, hipStream_t st);
-// dz = scale * (dy - c1 - xhat*c2); partial rows of sum dz (conv bias gradient)
-int bn_bwd_apply_launch(const float* dy, const float* z, int ldz, const float* scale, const float* mean,
-                        const float* invstd, const float* c1, const float* c2, int Cp, int64_t P, float* dz,
-                        float* partial, int* rows, hipStream_t st);
+// pass 2: dz = scale * (dy - c1 - xhat*c2); partial rows of sum dz (conv bias gradient)
+int bn_bwd_apply_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
+                        const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
+                        int C, const float* c1, const float* c2, int Cp, int N, int H, int W, float* dz, float* partial,
+                        int* rows, hipStream_t st);
 // out[c] = sum over chunks of sums[chunk][c], c < C
 int vec_finalize_launch(const double* sums, int chunks, int cols, int C, float* out, hipStream_t st);
 

@@ -515,11 +515,38 @@ int up_bwd_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, i
 // ---------------------------------------------------------------------------------------
 // BatchNorm + ReLU backward
 // ---------------------------------------------------------------------------------------
+// dy = (gradient arriving at the activation) * dropout mask * [relu input > 0], evaluated on the fly by
+// both passes (never stored): the source is a plain NHWC buffer or the padded-domain dgrad output
+__device__ __forceinline__ float4 relu_grad4(const float* da, int ldda, const float* dxpad, int ldp, const float* mask, int C,
+                                             int p, int q, int H, int W, float4 v, float4 sc, float4 sh) {
+  float4 g;
+  const int n = p / (H * W);
+  if (da) {
+    g = ld4(da + (size_t)p * ldda + 4 * q);
+  } else {
+    const int r = p - n * H * W;
+    const int y = r / W, x = r - y * W;
+    g = fold_read(dxpad, ldp, n, y, x, H, W, 4 * q);
+  }
+  if (mask) {
+    const float4 m = mask4(mask, n, C, 4 * q);
+    g.x *= m.x;
+    g.y *= m.y;
+    g.z *= m.z;
+    g.w *= m.w;
+  }
+  g.x = fmaf(v.x, sc.x, sh.x) > 0.f ? g.x : 0.f;
+  g.y = fmaf(v.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
+  g.z = fmaf(v.z, sc.z, sh.z) > 0.f ? g.z : 0.f;
+  g.w = fmaf(v.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
+  return g;
+}
+
 __global__ void bnrelu_bwd_reduce_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ dxpad,
                                          int ldp, const float* __restrict__ z, int ldz, const float* __restrict__ scale,
                                          const float* __restrict__ shift, const float* __restrict__ mean,
                                          const float* __restrict__ invstd, const float* __restrict__ mask, int C, int Cv,
-                                         int N, int H, int W, float* __restrict__ dy, float* __restrict__ partial) {
+                                         int N, int H, int W, float* __restrict__ partial) {
   __shared__ float4 red[256];
   const PQ t = pixquad(Cv);
   const int Cp = 4 * Cv;
@@ -528,28 +555,8 @@ __global__ void bnrelu_bwd_reduce_kernel(const float* __restrict__ da, int ldda,
     const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q), mu = ld4(mean + 4 * t.q), is = ld4(invstd + 4 * t.q);
     const int P = N * H * W;
     for (int p = t.p; p < P; p += t.pstep) {
-      float4 g;
-      const int n = p / (H * W);
-      if (da) {
-        g = ld4(da + (size_t)p * ldda + 4 * t.q);
-      } else {
-        const int r = p - n * H * W;
-        const int y = r / W, x = r - y * W;
-        g = fold_read(dxpad, ldp, n, y, x, H, W, 4 * t.q);
-      }
-      if (mask) {
-        const float4 m = mask4(mask, n, C, 4 * t.q);
-        g.x *= m.x;
-        g.y *= m.y;
-        g.z *= m.z;
-        g.w *= m.w;
-      }
       const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
-      g.x = fmaf(v.x, sc.x, sh.x) > 0.f ? g.x : 0.f;
-      g.y = fmaf(v.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
-      g.z = fmaf(v.z, sc.z, sh.z) > 0.f ? g.z : 0.f;
-      g.w = fmaf(v.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
-      st4(dy + (size_t)p * Cp + 4 * t.q, g);
+      const float4 g = relu_grad4(da, ldda, dxpad, ldp, mask, C, p, t.q, H, W, v, sc, sh);
       a1 = f4add(a1, g);
       a2.x += g.x * (v.x - mu.x) * is.x;
       a2.y += g.y * (v.y - mu.y) * is.y;
@@ -568,13 +575,13 @@ __global__ void bnrelu_bwd_reduce_kernel(const float* __restrict__ da, int ldda,
 
 int bnrelu_bwd_reduce_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
                              const float* scale, const float* shift, const float* mean, const float* invstd,
-                             const float* mask, int C, int Cp, int N, int H, int W, float* dy, float* partial,
-                             int* rows, hipStream_t st) {
+                             const float* mask, int C, int Cp, int N, int H, int W, float* partial, int* rows,
+                             hipStream_t st) {
   const int Cv = Cp / 4;
   const dim3 grid = pq_grid(Cv, (int64_t)N * H * W);
   *rows = grid.x;
   hipLaunchKernelGGL(bnrelu_bwd_reduce_kernel, grid, dim3(256), 0, st, da, ldda, dxpad, ldp, z, ldz, scale, shift, mean,
-                     invstd, mask, C, Cv, N, H, W, dy, partial);
+                     invstd, mask, C, Cv, N, H, W, partial);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -605,21 +612,23 @@ int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_
   return MIMO_OK;
 }
 
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z, int ldz,
-                                    const float* __restrict__ scale, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ c1,
-                                    const float* __restrict__ c2, int Cv, int P, float* __restrict__ dz,
-                                    float* __restrict__ partial) {
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ dxpad, int ldp,
+                                    const float* __restrict__ z, int ldz, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ mask, int C,
+                                    const float* __restrict__ c1, const float* __restrict__ c2, int Cv, int N, int H,
+                                    int W, float* __restrict__ dz, float* __restrict__ partial) {
   __shared__ float4 red[256];
   const PQ t = pixquad(Cv);
   const int Cp = 4 * Cv;
   float4 acc = f4zero();
   if (t.active) {
-    const float4 sc = ld4(scale + 4 * t.q), mu = ld4(mean + 4 * t.q), is = ld4(invstd + 4 * t.q);
+    const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q), mu = ld4(mean + 4 * t.q), is = ld4(invstd + 4 * t.q);
     const float4 k1 = ld4(c1 + 4 * t.q), k2 = ld4(c2 + 4 * t.q);
+    const int P = N * H * W;
     for (int p = t.p; p < P; p += t.pstep) {
-      const float4 g = ld4(dy + (size_t)p * Cp + 4 * t.q);
       const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
+      const float4 g = relu_grad4(da, ldda, dxpad, ldp, mask, C, p, t.q, H, W, v, sc, sh);
       float4 r;
       r.x = sc.x * (g.x - k1.x - (v.x - mu.x) * is.x * k2.x);
       r.y = sc.y * (g.y - k1.y - (v.y - mu.y) * is.y * k2.y);
@@ -633,14 +642,15 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
   if (t.pl == 0 && t.q < Cv) st4(partial + (size_t)blockIdx.x * Cp + 4 * t.q, s);
 }
 
-int bn_bwd_apply_launch(const float* dy, const float* z, int ldz, const float* scale, const float* mean,
-                        const float* invstd, const float* c1, const float* c2, int Cp, int64_t P, float* dz,
-                        float* partial, int* rows, hipStream_t st) {
+int bn_bwd_apply_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
+                        const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
+                        int C, const float* c1, const float* c2, int Cp, int N, int H, int W, float* dz, float* partial,
+                        int* rows, hipStream_t st) {
   const int Cv = Cp / 4;
-  const dim3 grid = pq_grid(Cv, P);
+  const dim3 grid = pq_grid(Cv, (int64_t)N * H * W);
   *rows = grid.x;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, dy, z, ldz, scale, mean, invstd, c1, c2, Cv, (int)P, dz,
-                     partial);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, da, ldda, dxpad, ldp, z, ldz, scale, shift, mean, invstd,
+                     mask, C, c1, c2, Cv, N, H, W, dz, partial);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

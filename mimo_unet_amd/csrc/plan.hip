@@ -116,7 +116,7 @@ struct mimo_plan {
   std::vector<Head> heads;
 
   // scratch
-  float *s_dy = nullptr, *s_dz = nullptr, *s_dxpadA = nullptr, *s_dxpadB = nullptr, *s_wslab = nullptr,
+  float *s_dz = nullptr, *s_dxpadA = nullptr, *s_dxpadB = nullptr, *s_wslab = nullptr,
         *s_partial = nullptr, *s_losspart = nullptr;
   double* s_sums = nullptr;
   size_t cap_act = 0, cap_pad = 0, cap_slab = 0, cap_partial = 0, cap_sums = 0;
@@ -167,7 +167,8 @@ struct mimo_plan {
   }
 
   // per-call state
-  bool fwd_done = false, fwd_training = false, had_perm = false, loss_done = false;
+  bool fwd_done = false, fwd_training = false, had_perm = false, loss_done = false, bwd_stage0_done = false;
+  int64_t encoder_param_floats = 0;
   float* out = nullptr;
   const float *label = nullptr, *lmask = nullptr;
   const int64_t* lperm = nullptr;
@@ -401,6 +402,7 @@ struct mimo_plan {
       MIMO_TRY(set_input(dc, IN_POOL, &enc_in[s]->out, nullptr, enc_in[s]->out.Cp, H2, W2));
       down1.push_back(dc);
     }
+    encoder_param_floats = param_floats;  // everything registered so far belongs to the S encoders
     // ---- core (model.py:190-243) ----
     const float pc = cfg.core_dropout_rate;
     MIMO_TRY(make_dc(&down2, "core.down2.conv.double_conv", x2cat.chmap, 2 * f * S, 4 * f * S, 4 * f * S, H3, W3, pc,
@@ -455,7 +457,6 @@ struct mimo_plan {
     const int fp = pad_channels(f);
     cap_partial = std::max(cap_partial, (size_t)kEwMaxBlocks * (Co * fp + Co));
     cap_sums = std::max(cap_sums, (size_t)kMaxChunks * (Co * fp + Co));
-    MIMO_TRY(dalloc(&s_dy, cap_act));
     MIMO_TRY(dalloc(&s_dz, cap_act));
     MIMO_TRY(dalloc(&s_dxpadA, cap_pad));
     MIMO_TRY(dalloc(&s_dxpadB, cap_pad));
@@ -603,12 +604,12 @@ struct mimo_plan {
     int rows = 0, chunks = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
     MIMO_TRY(bnrelu_bwd_reduce_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd,
-                                      mask, L.Cout, L.cout_p, L.N, L.H, L.W, s_dy, s_partial, &rows, st));
+                                      mask, L.Cout, L.cout_p, L.N, L.H, L.W, s_partial, &rows, st));
     MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_p, s_sums, &chunks, st));
     MIMO_TRY(bn_bwd_finalize_launch(s_sums, chunks, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
                                     grads + L.off_gamma, grads + L.off_beta, st));
-    MIMO_TRY(bn_bwd_apply_launch(s_dy, L.z, L.cout_p, L.scale, L.mean, L.invstd, L.c1, L.c2, L.cout_p, P, s_dz, s_partial,
-                                 &rows, st));
+    MIMO_TRY(bn_bwd_apply_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
+                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, s_dz, s_partial, &rows, st));
     MIMO_TRY(rowsum_launch(s_partial, rows, L.cout_p, s_sums, &chunks, st));
     MIMO_TRY(vec_finalize_launch(s_sums, chunks, L.cout_p, L.Cout, grads + L.off_b, st));
     WgradLaunch wg;
@@ -678,7 +679,10 @@ struct mimo_plan {
     return MIMO_OK;
   }
 
-  int backward(const float* dout, const float* dloss, float* dx, hipStream_t st) {
+  // stage 0: heads + decoder + core (98.6 % of the parameter bytes at cfg3); stage 1: encoders (+ dx).
+  // The flat gradient buffer is ordered encoder | core | decoder | heads, so after stage 0 the range
+  // [encoder_param_floats, param_floats) is final and can be all-reduced while stage 1 runs.
+  int backward(const float* dout, const float* dloss, float* dx, int stage_first, int stage_last, hipStream_t st) {
     if (!fwd_done) {
       set_error("mimo_backward: call mimo_forward first");
       return MIMO_ERR_STATE;
@@ -699,6 +703,18 @@ struct mimo_plan {
       set_error("mimo_backward: dx requires a forward without perm");
       return MIMO_ERR_INVALID;
     }
+    if (stage_first < 0 || stage_last > 1 || stage_first > stage_last) {
+      set_error("mimo_backward: bad stage range %d..%d", stage_first, stage_last);
+      return MIMO_ERR_INVALID;
+    }
+    if (stage_first == 1) {
+      if (!bwd_stage0_done) {
+        set_error("mimo_backward: stage 1 before stage 0");
+        return MIMO_ERR_STATE;
+      }
+      return backward_encoders(dx, st);
+    }
+    bwd_stage0_done = false;
     for (auto& dc : dcs) dc->out.grad_writes = 0;
     x2cat.grad_writes = 0;
     if (!fwd_training) {  // eval-mode forward skipped the dgrad weight packing
@@ -724,11 +740,18 @@ struct mimo_plan {
     MIMO_TRY(dc_backward(down4, true, st));
     MIMO_TRY(dc_backward(down3, true, st));
     MIMO_TRY(dc_backward(down2, true, st));
+    bwd_stage0_done = true;
+    if (stage_last >= 1) return backward_encoders(dx, st);
+    return MIMO_OK;
+  }
+
+  int backward_encoders(float* dx, hipStream_t st) {
     for (int s = S - 1; s >= 0; --s) MIMO_TRY(dc_backward(down1[s], true, st));
     for (int s = S - 1; s >= 0; --s) {
       MIMO_TRY(dc_backward(enc_in[s], dx != nullptr, st));
       if (dx) MIMO_TRY(unpack_dx_launch(s_dxpadB, Ci_p, N, S, s, Ci, H, W, dx, st));
     }
+    bwd_stage0_done = false;
     return MIMO_OK;
   }
 };
@@ -846,7 +869,17 @@ int mimo_backward(mimo_plan* plan, const float* dout, const float* dloss, float*
     set_error("mimo_backward: null plan");
     return MIMO_ERR_INVALID;
   }
-  return plan->backward(dout, dloss, dx, (hipStream_t)stream);
+  return plan->backward(dout, dloss, dx, 0, 1, (hipStream_t)stream);
 }
+
+int mimo_backward_stage(mimo_plan* plan, int stage, const float* dout, const float* dloss, float* dx, mimo_stream stream) {
+  if (!plan) {
+    set_error("mimo_backward_stage: null plan");
+    return MIMO_ERR_INVALID;
+  }
+  return plan->backward(dout, dloss, dx, stage, stage, (hipStream_t)stream);
+}
+
+int64_t mimo_plan_encoder_param_floats(const mimo_plan* plan) { return plan ? plan->encoder_param_floats : 0; }
 
 }  // extern "C"

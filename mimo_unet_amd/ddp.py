@@ -61,3 +61,9 @@ class FlatGradientAllReducer:
     def all_reduce(self, flat: torch.Tensor) -> None:
         self.start(flat)
         self.finish()
+
+    def attach(self, net) -> None:
+        """Overlap with the backward: `net` (MimoUNet) calls `start` as soon as a range of its flat
+        gradient buffer is final (core + decoder after backward stage 0, encoders after stage 1);
+        call `finish()` before the optimiser step."""
+        net.grad_ready_hook = self.start

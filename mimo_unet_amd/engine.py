@@ -59,6 +59,7 @@ class Plan:
         self.specs = self._read_specs()
         self.param_floats = int(self.lib.mimo_plan_param_floats(handle))
         self.buffer_floats = int(self.lib.mimo_plan_buffer_floats(handle))
+        self.encoder_param_floats = int(self.lib.mimo_plan_encoder_param_floats(handle))
         self.num_double_convs = int(self.lib.mimo_plan_num_double_convs(handle))
         self.double_conv_channels = [int(self.lib.mimo_plan_double_conv_channels(handle, i))
                                      for i in range(self.num_double_convs)]
@@ -121,9 +122,15 @@ class Plan:
         L.check(self.lib.mimo_loss_forward(self.handle, label.data_ptr(), L.ptr(mask) or None, L.ptr(perm) or None,
                                            loss_out.data_ptr(), L.current_stream()), "mimo_loss_forward")
 
-    def backward(self, dout: Optional[torch.Tensor], dloss: Optional[torch.Tensor], dx: Optional[torch.Tensor]) -> None:
-        L.check(self.lib.mimo_backward(self.handle, L.ptr(dout) or None, L.ptr(dloss) or None, L.ptr(dx) or None,
-                                       L.current_stream()), "mimo_backward")
+    def backward(self, dout: Optional[torch.Tensor], dloss: Optional[torch.Tensor], dx: Optional[torch.Tensor],
+                 stage: Optional[int] = None) -> None:
+        """stage None: whole backward; 0: heads + decoders + core; 1: encoders (+ dx)."""
+        if stage is None:
+            L.check(self.lib.mimo_backward(self.handle, L.ptr(dout) or None, L.ptr(dloss) or None, L.ptr(dx) or None,
+                                           L.current_stream()), "mimo_backward")
+        else:
+            L.check(self.lib.mimo_backward_stage(self.handle, stage, L.ptr(dout) or None, L.ptr(dloss) or None,
+                                                 L.ptr(dx) or None, L.current_stream()), "mimo_backward_stage")
 
 
     PROF_KINDS = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")

@@ -181,6 +181,8 @@ class MimoUNet(nn.Module):
         self._param_list: List[nn.Parameter] = []
         self._flat_device = None
         self.mask_override: Optional[Dict[int, torch.Tensor]] = None  # tests: {double-conv index: [N,C] multipliers}
+        # called as hook(flat_grads, begin, end) when gradients [begin, end) are final (see ddp.FlatGradientAllReducer)
+        self.grad_ready_hook = None
 
     # ---- execution order of the DoubleConvs == mimo_plan's (engine) order -----------------
     def double_convs(self) -> List[DoubleConv]:
@@ -311,7 +313,16 @@ class MimoUNet(nn.Module):
         aliased = any(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in views)
         saved = g.clone() if aliased else None
         plan.bind(self._flat_params, g, self._flat_buffers)
-        plan.backward(dout, dloss, dx)
+        hook = self.grad_ready_hook
+        if hook is None:
+            plan.backward(dout, dloss, dx)
+        else:
+            # data-parallel overlap: the core/decoder/head gradients (the tail of the flat buffer, 99 % of
+            # its bytes) are final after stage 0; their all-reduce runs while the encoders back-propagate
+            plan.backward(dout, dloss, dx, stage=0)
+            hook(g, plan.encoder_param_floats, g.numel())
+            plan.backward(dout, dloss, dx, stage=1)
+            hook(g, 0, plan.encoder_param_floats)
         for p, v in views:
             if p.grad is None:
                 p.grad = v

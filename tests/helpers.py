@@ -36,3 +36,11 @@ def rms_rel_err(a, b):
     a = torch.as_tensor(a, dtype=torch.float64).flatten()
     b = torch.as_tensor(b, dtype=torch.float64).flatten()
     return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def free_port():
+    """A TCP port that is free right now on 127.0.0.1 (rendezvous of the multi-process tests)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]

@@ -1,0 +1,67 @@
+"""Data-parallel path on the GPU box: two ranks (sharing the single GPU, gloo transport) run the real
+training step on their shard; after the overlapped all-reduce both hold the mean of the two shard
+gradients and take the same fused-Adam step."""
+import os
+
+import pytest
+import torch
+
+from tests.helpers import free_port, cfg_from_meta, load_npz, state_from
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from mimo_unet_amd.ddp import FlatGradientAllReducer, shard_batch
+    from tests.test_network_gpu import build_model
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    g = torch.Generator().manual_seed(3)
+    full = {"image": torch.rand(4, 2, 32, 32, generator=g), "label": torch.rand(4, 1, 32, 32, generator=g)}
+    shard = {k: v.cuda() for k, v in shard_batch(full, rank, world).items()}
+    perms = torch.stack([torch.arange(2), torch.tensor([1, 0])]).cuda()
+    model = build_model(cfg, state_from(fx, "init/"))
+    model.train()
+    opt = model.configure_optimizers()["optimizer"]
+    red = FlatGradientAllReducer(bucket_bytes=1 << 18)
+    red.attach(model.model)
+    opt.grad_scale = red.scale
+    calls = []
+    inner = model.model.grad_ready_hook
+    model.model.grad_ready_hook = lambda flat, b, e: (calls.append((b, e)), inner(flat, b, e))
+    local = {}
+    # local (un-reduced) gradient of this shard, for the reference mean
+    m2 = build_model(cfg, state_from(fx, "init/"))
+    m2.train()
+    m2.training_step_with_perms(shard["image"], shard["label"], None, perms)["loss"].backward()
+    local = m2.model.flat_gradients().clone().cpu()
+    opt.zero_grad()
+    model.training_step_with_perms(shard["image"], shard["label"], None, perms)["loss"].backward()
+    red.finish()
+    reduced = model.model.flat_gradients().clone().cpu()
+    opt.step()
+    torch.cuda.synchronize()
+    q.put((rank, local, reduced, model.model.flat_parameters().clone().cpu(), calls))
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_step_gloo_on_gpu():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, l0, r0, p0, c0), (_, l1, r1, p1, c1) = res
+    assert torch.allclose(r0, l0 + l1, rtol=1e-6, atol=1e-9) and torch.equal(r0, r1)  # sum on every rank
+    assert torch.equal(p0, p1)                                                       # identical Adam step (scale 1/2)
+    assert len(c0) == 2 and c0[0][1] == r0.numel() and c0[1][0] == 0 and c0[0][0] == c0[1][1]

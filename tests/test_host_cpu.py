@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import load_npz
+from tests.helpers import free_port, load_npz
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -158,7 +158,7 @@ def test_gradient_allreduce_gloo_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 500
+    port = free_port()
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

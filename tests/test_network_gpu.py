@@ -368,3 +368,27 @@ def test_deep_ensemble_of_two_checkpoints(tmp_path):
         ref = O.compute_uncertainties("laplace_nll", p1, p2)
     for a, b in zip((mean, alea, epi), ref):
         assert rel_err(a, b) < TOL
+
+
+def test_staged_backward_equals_monolithic_and_hook_ranges():
+    """mimo_backward_stage 0 + 1 (data-parallel overlap path) == mimo_backward, and the gradient-ready hook
+    is told disjoint ranges that cover the flat buffer, the first one being the core/decoder tail."""
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    image, label, perms = (torch.from_numpy(fx[f"s0/{k}"]).cuda() for k in ("image", "label", "perms"))
+    grads, calls = [], []
+    for staged in (False, True):
+        model = build_model(cfg, state_from(fx, "init/"))
+        model.train()
+        if staged:
+            model.model.grad_ready_hook = lambda flat, b, e: calls.append((b, e, flat[b:e].clone()))
+        out = model.training_step_with_perms(image, label, None, perms)
+        out["loss"].backward()
+        grads.append(model.model.flat_gradients().clone())
+    assert torch.equal(grads[0], grads[1])
+    (b0, e0, g0), (b1, e1, g1) = calls
+    assert b1 == 0 and e1 == b0 and e0 == grads[0].numel() and b0 > 0
+    assert torch.equal(g0, grads[0][b0:e0]) and torch.equal(g1, grads[0][:e1])  # final when announced
+    names = dict(model.model.named_parameters())
+    enc_numel = sum(p.numel() for n, p in names.items() if n.startswith("encoder."))
+    assert enc_numel <= b0 <= enc_numel + 4 * len(names)  # encoder block (+16-byte alignment gaps)
