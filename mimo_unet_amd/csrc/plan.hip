@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -166,6 +167,18 @@ struct mimo_plan {
     return MIMO_OK;
   }
 
+  // hipGraph replay of the eval-mode forward (launch-bound at small batch: ~100+ kernel launches).
+  // The captured kernels read plan-owned staging copies of x / perm / masks and write a plan-owned
+  // logits buffer, so the graph stays valid when the caller's tensors move.
+  bool graph_enabled = true;
+  hipStream_t cap_stream = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  uint64_t graph_key = 0;
+  float *g_x = nullptr, *g_out = nullptr;
+  int64_t* g_perm = nullptr;
+  std::vector<float*> g_masks;
+  std::vector<const float*> g_mask_ptrs;
+
   // per-call state
   bool fwd_done = false, fwd_training = false, had_perm = false, loss_done = false, bwd_stage0_done = false;
   int64_t encoder_param_floats = 0;
@@ -183,6 +196,8 @@ struct mimo_plan {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
     }
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
   }
 
   template <typename T>
@@ -464,6 +479,16 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&s_partial, cap_partial));
     MIMO_TRY(dalloc(&s_sums, cap_sums));
     MIMO_TRY(dalloc(&s_losspart, (size_t)S * 512));
+    // hipGraph staging
+    const char* ge = getenv("MIMO_HIP_GRAPH");
+    graph_enabled = !(ge && atoi(ge) == 0);
+    MIMO_TRY(dalloc(&g_x, (size_t)N * S * Ci * H * W));
+    MIMO_TRY(dalloc(&g_out, (size_t)N * S * Co * H * W));
+    MIMO_TRY(dalloc(&g_perm, (size_t)S * N));
+    g_masks.resize(dcs.size());
+    g_mask_ptrs.assign(dcs.size(), nullptr);
+    for (size_t i = 0; i < dcs.size(); ++i) MIMO_TRY(dalloc(&g_masks[i], (size_t)N * dcs[i]->c2.Cout));
+    MIMO_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     return MIMO_OK;
   }
 
@@ -540,6 +565,68 @@ struct mimo_plan {
   }
 
   int forward(const mimo_forward_args* args, hipStream_t st) {
+    if (!params || !bnbuf) {
+      set_error("mimo_forward: parameters not bound (mimo_plan_bind)");
+      return MIMO_ERR_STATE;
+    }
+    if (!args || !args->x || !args->out) {
+      set_error("mimo_forward: null argument");
+      return MIMO_ERR_INVALID;
+    }
+    const int64_t img = (int64_t)Ci * H * W;
+    const bool x5 = args->stride_s == img && args->stride_n == (int64_t)S * img;
+    const bool x4 = args->stride_s == 0 && args->stride_n == img;
+    if (!graph_enabled || args->training || prof_on || !(x5 || x4)) return forward_impl(args, st);
+    // ---- stage the caller's tensors, (re)capture if the call shape changed, replay ----
+    uint64_t key = 1 | (x5 ? 2 : 0) | (args->perm ? 4 : 0);
+    for (size_t i = 0; i < dcs.size(); ++i)
+      if (args->drop_masks && args->drop_masks[i]) key |= 1ull << (8 + i);
+    MIMO_HIP_CHECK(hipMemcpyAsync(g_x, args->x, (size_t)N * (x5 ? S : 1) * img * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (args->perm)
+      MIMO_HIP_CHECK(hipMemcpyAsync(g_perm, args->perm, (size_t)S * N * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    for (size_t i = 0; i < dcs.size(); ++i) {
+      const bool on = args->drop_masks && args->drop_masks[i];
+      g_mask_ptrs[i] = on ? g_masks[i] : nullptr;
+      if (on)
+        MIMO_HIP_CHECK(hipMemcpyAsync(g_masks[i], args->drop_masks[i], (size_t)N * dcs[i]->c2.Cout * sizeof(float),
+                                      hipMemcpyDeviceToDevice, st));
+    }
+    if (!graph_exec || key != graph_key) {
+      if (graph_exec) {
+        (void)hipGraphExecDestroy(graph_exec);
+        graph_exec = nullptr;
+      }
+      mimo_forward_args ga = *args;
+      ga.x = g_x;
+      ga.perm = args->perm ? g_perm : nullptr;
+      ga.drop_masks = args->drop_masks ? g_mask_ptrs.data() : nullptr;
+      ga.out = g_out;
+      MIMO_HIP_CHECK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+      const int rc = forward_impl(&ga, cap_stream);
+      hipGraph_t graph = nullptr;
+      const hipError_t ce = hipStreamEndCapture(cap_stream, &graph);
+      if (rc != MIMO_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      MIMO_HIP_CHECK(ce);
+      const hipError_t ie = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      MIMO_HIP_CHECK(ie);
+      graph_key = key;
+    }
+    MIMO_HIP_CHECK(hipGraphLaunch(graph_exec, st));
+    MIMO_HIP_CHECK(hipMemcpyAsync(args->out, g_out, (size_t)N * S * Co * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
+    for (size_t i = 0; i < dcs.size(); ++i) dcs[i]->mask = args->drop_masks ? args->drop_masks[i] : nullptr;
+    out = args->out;
+    fwd_done = true;
+    fwd_training = false;
+    had_perm = args->perm != nullptr;
+    loss_done = false;
+    return MIMO_OK;
+  }
+
+  int forward_impl(const mimo_forward_args* args, hipStream_t st) {
     if (!params || !bnbuf) {
       set_error("mimo_forward: parameters not bound (mimo_plan_bind)");
       return MIMO_ERR_STATE;
