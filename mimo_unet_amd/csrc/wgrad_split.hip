@@ -17,6 +17,8 @@
 //     next spatial tile is prefetched into registers while the current one is multiplied
 //   * waves are arranged WM x WN over (ci,co) and WK over K (tile rows); WK > 1 partial sums
 //     are combined through LDS once, at the end
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mimo {
@@ -231,25 +233,238 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Wave-specialised variant for the 64x64 (ci,co) tile — the configuration that carries ~80 % of the
+// weight-gradient time.  PMC counters of the kernel above: 3.3 VALU per MFMA with ONE wave per SIMD,
+// i.e. the staging work (address arithmetic, fp32 -> hi/lo split, LDS writes) sits in the same
+// instruction stream as the MFMAs and the matrix pipe idles about half the time.  Here waves 0-3
+// ("consumers") only issue transposed LDS reads + MFMAs and waves 4-7 ("producers", one per SIMD
+// next to a consumer) do all the staging into a double-buffered LDS tile, so the VALU and the MFMA
+// pipes of every SIMD run concurrently.  Tile = 2 rows x 32 columns (K = 64 pixels), one barrier
+// per tile; producers run one tile ahead in LDS and two tiles ahead in registers.
+// ---------------------------------------------------------------------------------------
+constexpr int kWsTR = 2;
+constexpr int kWsAPix = (kWsTR + 2) * kWgTCP;  // 136
+constexpr int kWsDPix = kWsTR * kWgTC;         // 64
+
+__global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
+  constexpr int CI = 64, CO = 64, MI = 2, NI = 2;
+  constexpr int PA = wg_pitch(CI), PD = wg_pitch(CO);
+  constexpr int QA = CI / 4, QD = CO / 4;
+  constexpr int XA = (kWsAPix * QA + 255) / 256, XD = (kWsDPix * QD + 255) / 256;  // per producer thread
+  constexpr int ABYTES = kWsAPix * PA, DBYTES = kWsDPix * PD, BUFBYTES = ABYTES + DBYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFBYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int coTiles = a.cout_pad / CO;
+  const int ciT = blockIdx.x / coTiles, coT = blockIdx.x - ciT * coTiles;
+  const int ci0 = ciT * CI, co0 = coT * CO;
+  const int ntiles_mine = blockIdx.y < numTiles ? (numTiles - 1 - blockIdx.y) / gridDim.y + 1 : 0;
+
+  if (wave >= 4) {
+    // =========================== producers ===========================
+    const int ptid = tid - 256;
+    f32x4 xa[XA], xd[XD];
+    // per-unit constants, hoisted out of the tile loop: halo-tile coordinates, channel, LDS destination
+    int a_tr[XA], a_tc[XA], a_ch[XA], a_dst[XA], d_r[XD], d_c[XD], d_ch[XD], d_dst[XD];
+#pragma unroll
+    for (int k = 0; k < XA; ++k) {
+      const int u = ptid + k * 256;
+      const int uc = min(u, kWsAPix * QA - 1);
+      const int pix = uc / QA, qq = uc - pix * QA;
+      a_tr[k] = pix / kWgTCP - 1;
+      a_tc[k] = pix % kWgTCP - 1;
+      a_ch[k] = ci0 + 4 * qq < a.cin_p ? ci0 + 4 * qq : -1;
+      a_dst[k] = u < kWsAPix * QA ? pix * PA + ((pix >> 3) & 1) * 32 + qq * 8 : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < XD; ++k) {
+      const int u = ptid + k * 256;
+      const int pix = u / QD, qq = u - pix * QD;
+      d_r[k] = pix / kWgTC;
+      d_c[k] = pix % kWgTC;
+      d_ch[k] = (pix < kWsDPix && co0 + 4 * qq < a.cout_p) ? co0 + 4 * qq : -1;
+      d_dst[k] = pix < kWsDPix ? ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + qq * 8 : -1;
+    }
+    const int H2 = 2 * a.H - 2, W2 = 2 * a.W - 2;
+#define WS_LOAD(TILE)                                                                               \
+  {                                                                                                 \
+    int t_ = (TILE);                                                                                \
+    const int tx_ = t_ % tilesX;                                                                    \
+    t_ /= tilesX;                                                                                   \
+    const int ty_ = t_ % tilesY;                                                                    \
+    const int n_ = t_ / tilesY;                                                                     \
+    const int y0_ = ty_ * kWsTR, x0_ = tx_ * kWgTC;                                                 \
+    const float* ximg_ = a.x + (size_t)n_ * a.H * a.W * a.ldx;                                      \
+    const float* dimg_ = a.dz + (size_t)n_ * a.H * a.W * a.lddz;                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < XA; ++k_) {                                             \
+      int iy_ = y0_ + a_tr[k_], ix_ = x0_ + a_tc[k_];                                               \
+      iy_ = max(iy_, -iy_);           /* reflect at 0 */                                            \
+      iy_ = max(min(iy_, H2 - iy_), 0); /* reflect at H-1; clamp the tile overhang */               \
+      ix_ = max(ix_, -ix_);                                                                         \
+      ix_ = max(min(ix_, W2 - ix_), 0);                                                             \
+      const bool ok_ = a_ch[k_] >= 0;                                                               \
+      const f32x4 v_ = *reinterpret_cast<const f32x4*>(ximg_ + (iy_ * a.W + ix_) * a.ldx + max(a_ch[k_], 0)); \
+      xa[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+    }                                                                                               \
+    _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
+      const int y_ = y0_ + d_r[k_], x_ = x0_ + d_c[k_];                                             \
+      const bool ok_ = d_ch[k_] >= 0 && y_ < a.H && x_ < a.W;                                       \
+      const f32x4 v_ = *reinterpret_cast<const f32x4*>(dimg_ + (ok_ ? (y_ * a.W + x_) * a.lddz + d_ch[k_] : 0)); \
+      xd[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+    }                                                                                               \
+  }
+#define WS_SPLIT_STORE(V, DST, CCH)                                                                 \
+  {                                                                                                 \
+    bf16x4 hi_, lo_;                                                                                \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                              \
+      hi_[e_] = (__bf16)(V)[e_];                                                                    \
+      lo_[e_] = (__bf16)((V)[e_] - (float)hi_[e_]);                                                 \
+    }                                                                                               \
+    *reinterpret_cast<bf16x4*>(DST) = hi_;                                                          \
+    *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                                            \
+  }
+#define WS_STORE(BUF)                                                                               \
+  {                                                                                                 \
+    unsigned char* base_ = smem + (BUF) * BUFBYTES;                                                 \
+    _Pragma("unroll") for (int k_ = 0; k_ < XA; ++k_) {                                             \
+      if (a_dst[k_] >= 0) {                                                                         \
+        unsigned char* d_ = base_ + a_dst[k_];                                                      \
+        WS_SPLIT_STORE(xa[k_], d_, CI)                                                              \
+      }                                                                                             \
+    }                                                                                               \
+    _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
+      if (d_dst[k_] >= 0) {                                                                         \
+        unsigned char* d_ = base_ + d_dst[k_];                                                      \
+        WS_SPLIT_STORE(xd[k_], d_, CO)                                                              \
+      }                                                                                             \
+    }                                                                                               \
+  }
+    if (ntiles_mine > 0) {
+      WS_LOAD(blockIdx.y)
+      WS_STORE(0)
+      if (ntiles_mine > 1) WS_LOAD(blockIdx.y + gridDim.y)
+    }
+    __syncthreads();  // tile 0 is in LDS
+    for (int i = 0; i < ntiles_mine; ++i) {
+      // consumers multiply tile i from buffer i&1; the other buffer was released by the previous barrier
+      if (i + 1 < ntiles_mine) {
+        WS_STORE((i + 1) & 1)
+        if (i + 2 < ntiles_mine) WS_LOAD(blockIdx.y + (i + 2) * gridDim.y)
+      }
+      __syncthreads();
+    }
+#undef WS_LOAD
+#undef WS_STORE
+#undef WS_SPLIT_STORE
+    return;
+  }
+
+  // =========================== consumers ===========================
+  const int lr = lane & 15, g = lane >> 4;
+  const int q = lr >> 2, p4 = lr & 3;
+  const int wn = wave & 1, wm = wave >> 1;
+  f32x4 acc[9][MI][NI];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[t][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int rowk = 8 * g + q;
+  const int dcol = (wn * NI) * 32 + 8 * p4 + 32 * (g & 1);
+  const int acol = (wm * MI) * 32 + 8 * p4;
+
+  __syncthreads();  // tile 0 is in LDS
+  for (int i = 0; i < ntiles_mine; ++i) {
+    const unsigned char* as_ = smem + (i & 1) * BUFBYTES;
+    const unsigned char* ds_ = as_ + ABYTES;
+#pragma unroll 1
+    for (int r = 0; r < kWsTR; ++r) {
+      bf16x8 bh[NI], bl[NI];
+      const unsigned char* d0 = ds_ + (r * kWgTC + rowk) * PD + dcol;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        bh[ni] = tr_read8(d0 + ni * 32, d0 + ni * 32 + 4 * PD);
+        bl[ni] = tr_read8(d0 + ni * 32 + 2 * CO, d0 + ni * 32 + 2 * CO + 4 * PD);
+      }
+      // tap-level software pipeline: the 8 transposed reads of tap t+1 are issued before the 12 MFMAs of
+      // tap t (LDS latency ~130 cycles vs 192 cycles of MFMA per tap); the sched_group_barriers pin that
+      // order, otherwise the compiler schedules the reads just-in-time and the lone consumer wave stalls
+      bf16x8 ah[2][MI], al[2][MI];
+#define WS_READ_A(SLOT, TAP)                                                                  \
+  {                                                                                           \
+    const int row0_ = (r + (TAP) / 3) * kWgTCP + rowk + (TAP) % 3, row1_ = row0_ + 4;         \
+    const unsigned char* a0_ = as_ + row0_ * PA + ((row0_ >> 3) & 1) * 32 + acol;             \
+    const unsigned char* a1_ = as_ + row1_ * PA + ((row1_ >> 3) & 1) * 32 + acol;             \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                       \
+      ah[SLOT][mi] = tr_read8(a0_ + mi * 32, a1_ + mi * 32);                                  \
+      al[SLOT][mi] = tr_read8(a0_ + mi * 32 + 2 * CI, a1_ + mi * 32 + 2 * CI);                \
+    }                                                                                         \
+  }
+      WS_READ_A(0, 0)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) WS_READ_A((t + 1) & 1, t + 1)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            f32x4 c = acc[t][mi][ni];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t & 1][mi], bh[ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1][mi], bl[ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1][mi], bh[ni], c, 0, 0, 0);
+            acc[t][mi][ni] = c;
+          }
+        if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 4 * MI * 2, 0);  // DS reads of tap t+1
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * MI * NI, 0);                // MFMAs of tap t
+      }
+#undef WS_READ_A
+    }
+    __syncthreads();
+  }
+  float* out = a.partial + (size_t)blockIdx.y * 9 * a.cin_pad * a.cout_pad;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int co = co0 + (wn * NI + ni) * 16 + lr;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int ci = ci0 + (wm * MI + mi) * 16 + g * 4 + r4;
+          out[((size_t)t * a.cin_pad + ci) * a.cout_pad + co] = acc[t][mi][ni][r4];
+        }
+      }
+}
+
 // (ci tile, co tile) of the split kernel for a layer: 32, 48 or 64 channels, whichever pads least
 // (ties -> the larger tile: fewer re-reads of the other operand)
 static int pick_ctile(int c_p) {
   if (c_p <= 32) return 32;
-  // 48-wide tiles only where they save >= 15 % of padded work (48, 96, 144 channels): they hold
+  // 48-wide tiles only where they save >= 30 % of padded work (measured: the wave-specialised 64x64
+  // kernel with 25 % padding beats the 48-wide configuration on the 96->48 decoder layer): they hold
   // more accumulators per wave and run a little slower per MFMA than the 64-wide configuration
   const int p64 = round_up(c_p, 64), p48 = round_up(c_p, 48);
-  return (double)p48 <= 0.85 * p64 ? 48 : 64;
+  return (double)p48 <= 0.70 * p64 ? 48 : 64;
 }
 void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO) {
   *CI = pick_ctile(cin_p);
   *CO = pick_ctile(cout_p);
 }
 
-int wgrad_split_num_tiles(int N, int H, int W) { return N * ceil_div(H, kWgTR) * ceil_div(W, kWgTC); }
+static bool wgrad_use_ws(int CI, int CO) {
+  static const bool on = !(getenv("MIMO_WGRAD_WS") && atoi(getenv("MIMO_WGRAD_WS")) == 0);
+  return on && CI == 64 && CO == 64;
+}
+
+int wgrad_split_num_tiles(int N, int H, int W, int tr) { return N * ceil_div(H, tr) * ceil_div(W, kWgTC); }
 
 int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO) {
   const int wtiles = (cin_pad / CI) * (cout_pad / CO);
-  const int tiles = wgrad_split_num_tiles(N, H, W);
+  const int tiles = wgrad_split_num_tiles(N, H, W, wgrad_use_ws(CI, CO) ? kWsTR : kWgTR);
   int splits = ceil_div(512, wtiles);  // one 4-wave workgroup per CU: ~2 rounds of workgroups
   if (splits > tiles) splits = tiles;
   if (splits > 1024) splits = 1024;
@@ -264,9 +479,15 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
     set_error("wgrad_split: bad geometry");
     return MIMO_ERR_INVALID;
   }
-  const int tilesY = ceil_div(a.H, kWgTR), tilesX = ceil_div(a.W, kWgTC);
+  const bool ws = wgrad_use_ws(CI, CO);
+  const int tilesY = ceil_div(a.H, ws ? kWsTR : kWgTR), tilesX = ceil_div(a.W, kWgTC);
   const int numTiles = a.N * tilesY * tilesX;
   dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
+  if (ws) {
+    hipLaunchKernelGGL(wgrad_split_ws_kernel, grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles);
+    MIMO_KERNEL_CHECK();
+    return MIMO_OK;
+  }
 #define WG_LAUNCH(MI, NI, WM, WN, WK) \
   hipLaunchKernelGGL((wgrad_split_kernel<MI, NI, WM, WN, WK>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles)
   const int key = CI * 100 + CO;

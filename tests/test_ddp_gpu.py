@@ -45,7 +45,10 @@ def _worker(rank, world, port, q):
     reduced = model.model.flat_gradients().clone().cpu()
     opt.step()
     torch.cuda.synchronize()
-    q.put((rank, local, reduced, model.model.flat_parameters().clone().cpu(), calls))
+    # numpy (pickled by value): torch tensors on an mp.Queue travel as shared fds, which break when
+    # the sender exits before the parent has received them
+    q.put((rank, local.numpy(), reduced.numpy(), model.model.flat_parameters().clone().cpu().numpy(), calls))
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -61,6 +64,7 @@ def test_two_rank_training_step_gloo_on_gpu():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    res = [(r, torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(c), d) for r, a, b, c, d in res]
     (_, l0, r0, p0, c0), (_, l1, r1, p1, c1) = res
     assert torch.allclose(r0, l0 + l1, rtol=1e-6, atol=1e-9) and torch.equal(r0, r1)  # sum on every rank
     assert torch.equal(p0, p1)                                                       # identical Adam step (scale 1/2)

@@ -150,7 +150,8 @@ def _ddp_worker(rank, world, port, q):
     red.start(flat, 0, 500)
     red.start(flat, 500)
     red.finish()
-    q.put((rank, local, flat.clone(), red.scale, shard["image"].shape[0]))
+    q.put((rank, local.numpy(), flat.clone().numpy(), red.scale, shard["image"].shape[0]))  # by value
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -166,6 +167,7 @@ def test_gradient_allreduce_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    res = [(r, torch.from_numpy(a), torch.from_numpy(b), c, d) for r, a, b, c, d in res]
     (_, l0, r0, s0, n0), (_, l1, r1, s1, n1) = res
     assert n0 == n1 == 4 and s0 == s1 == 0.5
     assert torch.allclose(r0, l0 + l1) and torch.equal(r0, r1)          # every rank holds the sum
