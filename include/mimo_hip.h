@@ -93,6 +93,11 @@ typedef struct mimo_forward_args {
   int32_t training;
   const float* const* drop_masks; /* host array [num_double_convs] or NULL */
   float* out;
+  /* element-wise nn.Dropout multipliers (0 or 1/(1-p)), reference layout, or NULL (= none):
+   * host array [1 + S] of device pointers, each NULL for "not active":
+   *   [0]     center_dropout (model.py:213)        [N][8fS][H/16][W/16]  on down4's output
+   *   [1 + s] final_dropouts[s] (model.py:277-281) [N][f][H][W]          in front of head s   */
+  const float* const* elem_masks;
 } mimo_forward_args;
 int mimo_plan_num_double_convs(const mimo_plan* plan);
 int mimo_plan_double_conv_channels(const mimo_plan* plan, int index); /* Cout of DoubleConv #index */

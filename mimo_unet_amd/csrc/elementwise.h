@@ -52,6 +52,9 @@ int fold_slice_launch(const float* dxpad, int ldp, int choff, float* da, int ldd
 int up_bwd_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, int N, int H, int W, int h, int w,
                   int Cp, int accumulate, hipStream_t st);
 
+// a[N,HW] (ld) *= mask, mask in the reference's NCHW layout [N][C][HW] (nn.Dropout multipliers)
+int elem_mask_mul_launch(float* a, int ld, const float* mask, int N, int C, int Cp, int HW, hipStream_t st);
+
 // ---- BatchNorm + ReLU backward ------------------------------------------------------------
 // dy = da * mask * [z*scale+shift > 0] is evaluated on the fly by both passes (never stored).
 // da source: plain (da != nullptr, ldda) or folded from dxpad (da == nullptr).

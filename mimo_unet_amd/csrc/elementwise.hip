@@ -466,6 +466,37 @@ int fold_slice_launch(const float* dxpad, int ldp, int choff, float* da, int ldd
   return MIMO_OK;
 }
 
+// ---- element-wise dropout (nn.Dropout after down4 and in front of each 1x1 head) -------------
+// a[n,p,c] *= mask[n,c,p]: the multipliers arrive in the reference's NCHW layout, so one thread owns a
+// pixel (coalesced mask reads per channel plane) and walks its own contiguous channel row of `a`.
+__global__ void elem_mask_mul_kernel(float* __restrict__ a, int ld, const float* __restrict__ mask, int N, int C, int Cv,
+                                     int HW) {
+  const int64_t P = (int64_t)N * HW;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(p / HW);
+    const int r = (int)(p - (int64_t)n * HW);
+    const float* m = mask + (size_t)n * C * HW + r;
+    float* row = a + (size_t)p * ld;
+    for (int q = 0; q < Cv; ++q) {
+      float4 v = ld4(row + 4 * q);
+      const int c = 4 * q;
+      v.x *= c + 0 < C ? m[(size_t)(c + 0) * HW] : 1.f;
+      v.y *= c + 1 < C ? m[(size_t)(c + 1) * HW] : 1.f;
+      v.z *= c + 2 < C ? m[(size_t)(c + 2) * HW] : 1.f;
+      v.w *= c + 3 < C ? m[(size_t)(c + 3) * HW] : 1.f;
+      st4(row + 4 * q, v);
+    }
+  }
+}
+
+int elem_mask_mul_launch(float* a, int ld, const float* mask, int N, int C, int Cp, int HW, hipStream_t st) {
+  const int64_t P = (int64_t)N * HW;
+  const int blocks = (int)std::min<int64_t>((P + 255) / 256, 4096);
+  hipLaunchKernelGGL(elem_mask_mul_kernel, dim3(blocks), dim3(256), 0, st, a, ld, mask, N, C, Cp / 4, HW);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
 // weight with which output index o (of an x2 align_corners upsample of `in` samples) reads input i
 __device__ __forceinline__ float lerp_weight(int o, int i, int in) {
   const Lerp l = lerp_src(o, in, 2 * in);

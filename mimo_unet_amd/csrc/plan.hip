@@ -184,6 +184,7 @@ struct mimo_plan {
   int64_t encoder_param_floats = 0;
   float* out = nullptr;
   const float *label = nullptr, *lmask = nullptr;
+  std::vector<const float*> elem_masks;  // [1 + S] element-wise dropout multipliers of the last forward (or empty)
   const int64_t* lperm = nullptr;
 
   ~mimo_plan() {
@@ -576,7 +577,7 @@ struct mimo_plan {
     const int64_t img = (int64_t)Ci * H * W;
     const bool x5 = args->stride_s == img && args->stride_n == (int64_t)S * img;
     const bool x4 = args->stride_s == 0 && args->stride_n == img;
-    if (!graph_enabled || args->training || prof_on || !(x5 || x4)) return forward_impl(args, st);
+    if (!graph_enabled || args->training || prof_on || !(x5 || x4) || args->elem_masks) return forward_impl(args, st);
     // ---- stage the caller's tensors, (re)capture if the call shape changed, replay ----
     uint64_t key = 1 | (x5 ? 2 : 0) | (args->perm ? 4 : 0);
     for (size_t i = 0; i < dcs.size(); ++i)
@@ -615,6 +616,7 @@ struct mimo_plan {
       MIMO_HIP_CHECK(ie);
       graph_key = key;
     }
+    elem_masks.clear();
     MIMO_HIP_CHECK(hipGraphLaunch(graph_exec, st));
     MIMO_HIP_CHECK(hipMemcpyAsync(args->out, g_out, (size_t)N * S * Co * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
     for (size_t i = 0; i < dcs.size(); ++i) dcs[i]->mask = args->drop_masks ? args->drop_masks[i] : nullptr;
@@ -637,6 +639,9 @@ struct mimo_plan {
     }
     const bool training = args->training != 0;
     for (size_t i = 0; i < dcs.size(); ++i) dcs[i]->mask = args->drop_masks ? args->drop_masks[i] : nullptr;
+    elem_masks.assign(1 + S, nullptr);
+    if (args->elem_masks)
+      for (int i = 0; i <= S; ++i) elem_masks[i] = args->elem_masks[i];
     for (int s = 0; s < S; ++s)
       MIMO_TRY(pack_input_launch(args->x, args->stride_n, args->stride_s, args->perm, s, N, Ci, H, W, enc_in[s]->in_buf,
                                  Ci_p, st));
@@ -645,12 +650,18 @@ struct mimo_plan {
     MIMO_TRY(dc_forward(down2, training, st));
     MIMO_TRY(dc_forward(down3, training, st));
     MIMO_TRY(dc_forward(down4, training, st));
+    // center_dropout: in place on down4's output, whose only reader is up1's upsample (the BN/ReLU
+    // backward recomputes its mask from z, not from a)
+    if (elem_masks[0]) MIMO_TRY(elem_mask_mul_launch(down4->out.a, down4->out.ld, elem_masks[0], N, down4->out.C,
+                                                     down4->out.Cp, down4->out.H * down4->out.W, st));
     MIMO_TRY(dc_forward(up1, training, st));
     MIMO_TRY(dc_forward(up2, training, st));
     MIMO_TRY(dc_forward(up3, training, st));
     for (int s = 0; s < S; ++s) {
       MIMO_TRY(dc_forward(up4[s], training, st));
       const Act& o = up4[s]->out;
+      // final_dropouts[s]: in place, the head (forward and weight gradient) is the only reader
+      if (elem_masks[1 + s]) MIMO_TRY(elem_mask_mul_launch(o.a, o.ld, elem_masks[1 + s], N, o.C, o.Cp, H * W, st));
       MIMO_TRY(head_fwd_launch(o.a, o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co, N, S, s, H * W,
                                args->out, st));
     }
@@ -819,11 +830,16 @@ struct mimo_plan {
                                st));
       MIMO_TRY(rowsum_launch(s_partial, rows, Co * fp + Co, s_sums, &chunks, st));
       MIMO_TRY(head_bwd_finalize_launch(s_sums, chunks, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, st));
+      if (!elem_masks.empty() && elem_masks[1 + s])
+        MIMO_TRY(elem_mask_mul_launch(dc->out.da, dc->out.ldda, elem_masks[1 + s], N, dc->out.C, dc->out.Cp, H * W, st));
       MIMO_TRY(dc_backward(dc, true, st));
     }
     MIMO_TRY(dc_backward(up3, true, st));
     MIMO_TRY(dc_backward(up2, true, st));
     MIMO_TRY(dc_backward(up1, true, st));
+    if (!elem_masks.empty() && elem_masks[0])
+      MIMO_TRY(elem_mask_mul_launch(down4->out.da, down4->out.ldda, elem_masks[0], N, down4->out.C, down4->out.Cp,
+                                    down4->out.H * down4->out.W, st));
     MIMO_TRY(dc_backward(down4, true, st));
     MIMO_TRY(dc_backward(down3, true, st));
     MIMO_TRY(dc_backward(down2, true, st));

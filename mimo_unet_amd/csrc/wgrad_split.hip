@@ -465,11 +465,26 @@ int wgrad_split_num_tiles(int N, int H, int W, int tr) { return N * ceil_div(H, 
 int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO) {
   const int wtiles = (cin_pad / CI) * (cout_pad / CO);
   const int tiles = wgrad_split_num_tiles(N, H, W, wgrad_use_ws(CI, CO) ? kWsTR : kWgTR);
-  int splits = ceil_div(512, wtiles);  // one 4-wave workgroup per CU: ~2 rounds of workgroups
-  if (splits > tiles) splits = tiles;
-  if (splits > 1024) splits = 1024;
-  if (splits < 1) splits = 1;
-  return splits;
+  static const int mode = [] { const char* e = getenv("MIMO_WGRAD_SPLIT_MODE"); return e ? atoi(e) : 1; }();
+  if (!wgrad_use_ws(CI, CO) || mode == 0) {
+    int splits = ceil_div(512, wtiles);  // one 4-wave workgroup per CU: ~2 rounds of workgroups
+    if (splits > tiles) splits = tiles;
+    if (splits > 1024) splits = 1024;
+    if (splits < 1) splits = 1;
+    return splits;
+  }
+  // wave-specialised kernel: one workgroup per CU (128 KB of LDS), all workgroups of a launch do the same
+  // work, so time ~ rounds x (pixel tiles per workgroup + fixed cost); the fixed cost (147 KB slab written
+  // per workgroup and re-read by the reduction, pipeline fill) is worth about `kFixed` pixel tiles.
+  constexpr int kCUs = 256, kFixed = 8;
+  int best = 1;
+  long bestCost = -1;
+  for (int s = 1; s <= tiles && s <= 1024; ++s) {
+    const long rounds = ceil_div(wtiles * s, kCUs);
+    const long cost = rounds * (ceil_div(tiles, s) + kFixed);
+    if (bestCost < 0 || cost < bestCost) bestCost = cost, best = s;
+  }
+  return best;
 }
 
 int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {

@@ -100,8 +100,11 @@ class Plan:
         self._bound = key
 
     def forward(self, x: torch.Tensor, out: torch.Tensor, *, training: bool, perm: Optional[torch.Tensor] = None,
-                masks: Optional[Sequence[Optional[torch.Tensor]]] = None, broadcast_subnetworks: bool = False) -> None:
-        """x: [N,S,Ci,H,W] (or [N,Ci,H,W] with perm / broadcast) contiguous fp32 on the plan's device."""
+                masks: Optional[Sequence[Optional[torch.Tensor]]] = None, broadcast_subnetworks: bool = False,
+                elem_masks: Optional[Sequence[Optional[torch.Tensor]]] = None) -> None:
+        """x: [N,S,Ci,H,W] (or [N,Ci,H,W] with perm / broadcast) contiguous fp32 on the plan's device.
+        masks: per DoubleConv [N,C] Dropout2d multipliers; elem_masks: [center, final_0 .. final_{S-1}]
+        full-shape nn.Dropout multipliers (NCHW, fp32, contiguous) or None entries."""
         g = self.geom
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         if x.dim() == 5:
@@ -113,8 +116,15 @@ class Plan:
         if masks is not None and any(m is not None for m in masks):
             assert len(masks) == self.num_double_convs
             mask_arr = (C.c_void_p * self.num_double_convs)(*[L.ptr(m) or None for m in masks])
+        elem_arr = None
+        if elem_masks is not None and any(m is not None for m in elem_masks):
+            assert len(elem_masks) == 1 + g.num_subnetworks
+            for m in elem_masks:
+                assert m is None or (m.is_cuda and m.dtype == torch.float32 and m.is_contiguous())
+            elem_arr = (C.c_void_p * len(elem_masks))(*[L.ptr(m) or None for m in elem_masks])
         args = L.ForwardArgs(x.data_ptr(), stride_n, stride_s, L.ptr(perm) or None, int(training),
-                             C.cast(mask_arr, C.POINTER(C.c_void_p)) if mask_arr is not None else None, out.data_ptr())
+                             C.cast(mask_arr, C.POINTER(C.c_void_p)) if mask_arr is not None else None, out.data_ptr(),
+                             C.cast(elem_arr, C.POINTER(C.c_void_p)) if elem_arr is not None else None)
         L.check(self.lib.mimo_forward(self.handle, C.byref(args), L.current_stream()), "mimo_forward")
 
     def loss_forward(self, label: torch.Tensor, mask: Optional[torch.Tensor], perm: Optional[torch.Tensor],

@@ -106,14 +106,14 @@ class _NetFunction(torch.autograd.Function):
     """out (and optionally the per-subnetwork loss vector) = net(x); gradients through the C ABI."""
 
     @staticmethod
-    def forward(ctx, net: "MimoUNet", x, label, lmask, perm, masks, bn_training, *params):
+    def forward(ctx, net: "MimoUNet", x, label, lmask, perm, masks, bn_training, elem_masks, *params):
         ctx.set_materialize_grads(False)
         plan = net._plan_for(x, perm)
         n = plan.batch
         S, Co = net.num_subnetworks, net.out_channels
         out = torch.empty(n, S, Co, plan.height, plan.width, device=x.device, dtype=torch.float32)
         plan.bind(net._flat_params, net._flat_grads, net._flat_buffers)
-        plan.forward(x, out, training=bn_training, perm=perm, masks=masks)
+        plan.forward(x, out, training=bn_training, perm=perm, masks=masks, elem_masks=elem_masks)
         if label is not None:
             loss = torch.empty(S, device=x.device, dtype=torch.float32)
             plan.loss_forward(label, lmask, perm, loss)
@@ -121,7 +121,7 @@ class _NetFunction(torch.autograd.Function):
             loss = torch.zeros(0, device=x.device, dtype=torch.float32)
         plan.generation += 1
         ctx.net, ctx.plan, ctx.generation = net, plan, plan.generation
-        ctx.keep = (x, label, lmask, perm, masks, out)  # device memory the plan still points at
+        ctx.keep = (x, label, lmask, perm, masks, out, elem_masks)  # device memory the plan still points at
         ctx.x_shape = x.shape
         ctx.has_loss = label is not None
         ctx.mark_non_differentiable(*[])
@@ -130,7 +130,7 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dloss):
         net, plan = ctx.net, ctx.plan
-        n_in = 7 + len(net._param_list)
+        n_in = 8 + len(net._param_list)
         if dout is None and (dloss is None or not ctx.has_loss):
             return (None,) * n_in
         if plan.generation != ctx.generation:
@@ -145,7 +145,7 @@ class _NetFunction(torch.autograd.Function):
         dout_c = None if dout is None else dout.contiguous().float()
         dloss_c = None if (dloss is None or not ctx.has_loss) else dloss.contiguous().float()
         net._run_backward(plan, dout_c, dloss_c, dx)
-        return (None, dx, None, None, None, None, None) + (None,) * len(net._param_list)
+        return (None, dx, None, None, None, None, None, None) + (None,) * len(net._param_list)
 
 
 class MimoUNet(nn.Module):
@@ -161,8 +161,6 @@ class MimoUNet(nn.Module):
             raise ValueError("Do not specify spatial_dropout together with center_dropout_rate or final_dropout_rate!")
         if not bilinear or use_pooling_indices:
             raise NotImplementedError("only bilinear=True, use_pooling_indices=False (what MimoUnetModel hard-wires)")
-        if center_dropout_rate > 0.0 or final_dropout_rate > 0.0:
-            raise NotImplementedError("element-wise center/final dropout is not implemented in the HIP engine yet")
         super().__init__()
         logger.info("Creating MimoUNet(HIP): in=%d out=%d S=%d f=%d dropout enc/core/dec=%g/%g/%g", in_channels, out_channels,
                     num_subnetworks, filter_base_count, encoder_dropout_rate, core_dropout_rate, decoder_dropout_rate)
@@ -181,6 +179,8 @@ class MimoUNet(nn.Module):
         self._param_list: List[nn.Parameter] = []
         self._flat_device = None
         self.mask_override: Optional[Dict[int, torch.Tensor]] = None  # tests: {double-conv index: [N,C] multipliers}
+        # tests: {"center" | "final{s}": full-shape nn.Dropout multipliers (reference NCHW layout)}
+        self.elem_mask_override: Optional[Dict[str, torch.Tensor]] = None
         # called as hook(flat_grads, begin, end) when gradients [begin, end) are final (see ddp.FlatGradientAllReducer)
         self.grad_ready_hook = None
 
@@ -269,6 +269,24 @@ class MimoUNet(nn.Module):
             masks.append(m)
         return masks if any_mask else None
 
+    # ---- element-wise dropout (nn.Dropout: center after down4, final in front of each head) ----
+    def _elem_dropout_masks(self, n: int, h: int, w: int, device) -> Optional[List[Optional[torch.Tensor]]]:
+        S, f = self.num_subnetworks, self.filter_base_count
+        sites = [("center", self.core.center_dropout, (n, 8 * f * S, h // 16, w // 16))]
+        sites += [(f"final{s}", d, (n, f, h, w)) for s, d in enumerate(self.decoder.final_dropouts)]
+        out, any_mask = [], False
+        for key, d, shape in sites:
+            m = None
+            if self.elem_mask_override is not None and key in self.elem_mask_override:
+                m = self.elem_mask_override[key].to(device=device, dtype=torch.float32).contiguous()
+                if tuple(m.shape) != shape:
+                    raise ValueError(f"{key} dropout mask: expected {shape}, got {tuple(m.shape)}")
+            elif d.p > 0.0 and d.training:
+                m = torch.bernoulli(torch.full(shape, 1.0 - d.p, device=device)).div_(1.0 - d.p)
+            any_mask |= m is not None
+            out.append(m)
+        return out if any_mask else None
+
     def _bn_training(self) -> bool:
         return self.encoder.in_convs[0].norm.training
 
@@ -283,9 +301,10 @@ class MimoUNet(nn.Module):
         n = perm.shape[1] if perm is not None else x.shape[0]
         bn_training = self._bn_training()
         masks = self._dropout_masks(n, x.device)
+        elem_masks = self._elem_dropout_masks(n, x.shape[-2], x.shape[-1], x.device)
         # make sure the flat storage exists before the parameters are handed to autograd
         self._plan_for(x, perm)
-        out, loss = _NetFunction.apply(self, x, label, lmask, perm, masks, bn_training, *self._param_list)
+        out, loss = _NetFunction.apply(self, x, label, lmask, perm, masks, bn_training, elem_masks, *self._param_list)
         if bn_training:
             self._bump_batch_counters()
         return out, loss

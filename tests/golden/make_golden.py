@@ -221,6 +221,48 @@ def mc_dropout_fixture():
     print("mc_dropout.npz")
 
 
+def elem_dropout_fixture():
+    """Element-wise center / final nn.Dropout (model.py:213 and :277-281 of the reference) in a
+    training-mode forward + backward; masks recorded in call order (center, final 0..S-1)."""
+    Ci, Co, S, f, N, H, W, pc, pf = 2, 2, 2, 4, 3, 32, 32, 0.2, 0.3
+    torch.manual_seed(21)
+    net = MimoUNet(in_channels=Ci, out_channels=Co, num_subnetworks=S, filter_base_count=f,
+                   center_dropout_rate=pc, final_dropout_rate=pf)
+    net.train()
+    g = torch.Generator().manual_seed(22)
+    fx = {"meta": np.array([Ci, Co, S, f, N, H, W]), "pc": np.float64(pc), "pf": np.float64(pf)}
+    for k, v in net.state_dict().items():
+        fx["init/" + k] = npd(v)
+    x = torch.rand(N, S, Ci, H, W, generator=g).requires_grad_(True)
+    y = torch.rand(N, S, Co // 2, H, W, generator=g)
+    rec = []
+    orig = F.dropout
+
+    def fake(inp, p=0.5, training=True, inplace=False):
+        if not training or p == 0:
+            return inp
+        mk = (torch.rand(inp.shape, generator=g) >= p).float() / (1 - p)
+        rec.append(mk)
+        return inp * mk
+
+    F.dropout = fake
+    try:
+        out = net(x)
+    finally:
+        F.dropout = orig
+    assert len(rec) == 1 + S
+    loss = LaplaceNLL().forward(out[:, :, :Co // 2], out[:, :, Co // 2:], y, reduce_mean=False).mean(dim=(0, 2, 3, 4))
+    loss.mean().backward()
+    fx["x"], fx["y"], fx["out"], fx["loss"], fx["dx"] = npd(x), npd(y), npd(out), npd(loss), npd(x.grad)
+    fx["mask/center"] = npd(rec[0])
+    for s in range(S):
+        fx[f"mask/final{s}"] = npd(rec[1 + s])
+    for k, p in net.named_parameters():
+        fx["grad/" + k] = npd(p.grad)
+    np.savez_compressed(os.path.join(HERE, "elem_dropout.npz"), **fx)
+    print("elem_dropout.npz")
+
+
 if __name__ == "__main__":
     # BASELINE config[0]: synthetic 3ch 64x64, S=1, fbc=8, batch 4
     train_fixture("cfg1_step.npz", Ci=3, Co=2, S=1, f=8, N=4, H=64, W=64, use_mask=False, steps=3, seed=1)
@@ -232,3 +274,4 @@ if __name__ == "__main__":
     odd_size_fixture()
     loss_fixture()
     mc_dropout_fixture()
+    elem_dropout_fixture()

@@ -17,10 +17,11 @@ PRECISIONS = ["split16", "fp32"]
 
 
 def build_model(cfg: O.NetConfig, state, *, loss="laplace_nll", lr=1e-3, wd=0.0, T=0.3, dropout=(0.0, 0.0, 0.0),
-                precision="split16"):
+                precision="split16", center_final=(0.0, 0.0)):
     from mimo.models.mimo_unet import MimoUnetModel
     m = MimoUnetModel(in_channels=cfg.in_channels, out_channels=cfg.out_channels, num_subnetworks=cfg.num_subnetworks,
-                      filter_base_count=cfg.filter_base_count, center_dropout_rate=0.0, final_dropout_rate=0.0,
+                      filter_base_count=cfg.filter_base_count, center_dropout_rate=center_final[0],
+                      final_dropout_rate=center_final[1],
                       encoder_dropout_rate=dropout[0], core_dropout_rate=dropout[1], decoder_dropout_rate=dropout[2],
                       loss=loss, weight_decay=wd, learning_rate=lr, seed=0, loss_buffer_size=10, loss_buffer_temperature=T)
     m.load_state_dict({"model." + k: v for k, v in state.items()})
@@ -138,6 +139,42 @@ def test_input_gradient_and_generic_backward_cfg1(precision):
     grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
     check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")},
                 flip_robust=(precision != "fp32"))
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_elementwise_center_final_dropout_golden(precision):
+    """nn.Dropout after down4 and in front of each head (model.py:213, :277-281), recorded masks:
+    logits, loss, input gradient and every parameter gradient against the reference."""
+    fx = load_npz("elem_dropout.npz")
+    Ci, Co, S, f, N, H, W = (int(v) for v in fx["meta"])
+    cfg = O.NetConfig(Ci, Co, S, f)
+    model = build_model(cfg, state_from(fx, "init/"), precision=precision, center_final=(float(fx["pc"]), float(fx["pf"])))
+    model.train()
+    model.model.elem_mask_override = {"center": torch.from_numpy(fx["mask/center"]),
+                                      **{f"final{s}": torch.from_numpy(fx[f"mask/final{s}"]) for s in range(S)}}
+    x = torch.from_numpy(fx["x"]).cuda().requires_grad_(True)
+    y = torch.from_numpy(fx["y"]).cuda()
+    p1, p2 = model(x)
+    e_out = rel_err(torch.cat([p1, p2], dim=2).detach().cpu(), fx["out"])
+    loss = model.loss_fn.forward(p1, p2, y, reduce_mean=False).mean(dim=(0, 2, 3, 4))
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), fx["loss"], rtol=TOL)
+    loss.mean().backward()
+    e_dx = rel_err(x.grad.cpu(), fx["dx"])
+    grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
+    worst = check_grads(grads, {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")},
+                        flip_robust=(precision != "fp32"))
+    print(f"elem dropout [{precision}]: out {e_out:.2e} dx {e_dx:.2e} worst grad {worst[1]:.2e} at {worst[0]}")
+    assert e_out < TOL and e_dx < (TOL if precision == "fp32" else 5e-2)
+    # without an override the module draws its own Bernoulli masks: a different, but finite, result
+    model.model.elem_mask_override = None
+    with torch.no_grad():
+        q1, _ = model(x.detach())
+    assert torch.isfinite(q1).all() and not torch.equal(q1, p1.detach())
+    model.eval()  # nn.Dropout inactive in eval mode
+    with torch.no_grad():
+        a1, _ = model(x.detach())
+        b1, _ = model(x.detach())
+    assert torch.equal(a1, b1)
 
 
 @pytest.mark.parametrize("tag", ["50x70", "100x100", "128x160"])

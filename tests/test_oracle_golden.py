@@ -156,6 +156,40 @@ def test_mc_dropout_ensemble():
     assert rel_err(mean, fx["mean"]) < TOL and rel_err(al, fx["alea"]) < 1e-4 and rel_err(ep, fx["epi"]) < 1e-3
 
 
+def elem_dropout_inputs(fx):
+    """cfg, state, masks dict (oracle keys) and tensors of tests/golden/elem_dropout.npz."""
+    Ci, Co, S, f, N, H, W = (int(v) for v in fx["meta"])
+    cfg = O.NetConfig(Ci, Co, S, f, center_dropout_rate=float(fx["pc"]), final_dropout_rate=float(fx["pf"]))
+    masks = {"core.center_dropout": torch.from_numpy(fx["mask/center"])}
+    for s in range(S):
+        masks[f"decoder.final_dropouts.{s}"] = torch.from_numpy(fx[f"mask/final{s}"])
+    return cfg, state_from(fx, "init/"), masks
+
+
+def test_elementwise_center_final_dropout():
+    """nn.Dropout after down4 and before each 1x1 head (model.py:213, :277-281): forward, loss and
+    every gradient against the reference run with the same recorded masks."""
+    fx = load_npz("elem_dropout.npz")
+    cfg, st, masks = elem_dropout_inputs(fx)
+    Co = cfg.out_channels
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if not O.is_buffer(k)}
+    full = {**st, **params}
+    x = torch.from_numpy(fx["x"]).requires_grad_(True)
+    out = O.mimo_unet_forward(cfg, full, x, training=True, masks=masks)
+    assert rel_err(out, fx["out"]) < TOL
+    p1, p2 = O.split_heads(out, Co)
+    loss = O.laplace_nll(p1, p2, torch.from_numpy(fx["y"]), reduce_mean=False).mean(dim=(0, 2, 3, 4))
+    np.testing.assert_allclose(loss.detach().numpy(), fx["loss"], rtol=1e-5)
+    loss.mean().backward()
+    assert rel_err(x.grad, fx["dx"]) < 1e-4
+    for k, p in params.items():
+        if k.endswith(("double_conv.0.bias", "double_conv.3.bias")):
+            # a bias in front of a training-mode BatchNorm has zero gradient; both sides hold rounding noise
+            assert float(p.grad.abs().max()) < 1e-6 and float(np.abs(fx["grad/" + k]).max()) < 1e-6, k
+        else:
+            assert rel_err(p.grad, fx["grad/" + k]) < 2e-4, k
+
+
 def test_param_inventory_matches_reference_state_dict():
     fx = load_npz("cfg1_step.npz")
     cfg = cfg_from_meta(fx["meta"])
