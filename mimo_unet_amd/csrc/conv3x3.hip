@@ -431,21 +431,48 @@ __global__ void wgrad_group_sum_kernel(const float* __restrict__ partial, int sp
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int cin_pad,
                                                            int cout_pad, const int* __restrict__ cin_map, int cin_p,
                                                            int cin, int cout, float* __restrict__ dw) {
-  constexpr int PITCH = 289;  // 32*9 + 1: conflict-free transposed LDS writes
+  constexpr int PITCH = 289;  // 32*9 + 1
   __shared__ float tile[32 * PITCH];
   const int coTiles = (cout_pad + 31) / 32;  // cin_pad / cout_pad are multiples of 32 or 48
   const int ciT = blockIdx.x / coTiles, coT = blockIdx.x - ciT * coTiles;
   const int ci0 = ciT * 32, co0 = coT * 32;
-  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const size_t slab = (size_t)9 * cin_pad * cout_pad;
-  for (int row = rl; row < 288; row += 8) {  // row = tap*32 + ci_local
+  const size_t slab4 = (size_t)9 * cin_pad * cout_pad / 4;
+  // the [9][32 ci][32 co] tile = 2304 float4 units, 9 per thread: independent accumulators, so the
+  // loads of all units and slabs are in flight together (the kernel is pure latency otherwise)
+  float4 acc[9];
+  const float4* src[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int u = threadIdx.x + k * 256;
+    const int row = u >> 3, c4 = u & 7;  // row = tap*32 + ci_local
     const int tap = row >> 5, cil = row & 31;
-    float s = 0.f;
-    if (ci0 + cil < cin_pad && co0 + col < cout_pad) {
-      const float* p = partial + ((size_t)tap * cin_pad + ci0 + cil) * cout_pad + co0 + col;
-      for (int k = 0; k < splits; ++k) s += p[k * slab];
+    const bool ok = ci0 + cil < cin_pad && co0 + 4 * c4 < cout_pad;
+    src[k] = ok ? reinterpret_cast<const float4*>(partial + ((size_t)tap * cin_pad + ci0 + cil) * cout_pad + co0 + 4 * c4)
+                : nullptr;
+    acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int sidx = 0; sidx < splits; ++sidx) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (src[k]) {
+        const float4 v = src[k][(size_t)sidx * slab4];
+        acc[k].x += v.x;
+        acc[k].y += v.y;
+        acc[k].z += v.z;
+        acc[k].w += v.w;
+      }
     }
-    tile[col * PITCH + cil * 9 + tap] = s;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int u = threadIdx.x + k * 256;
+    const int row = u >> 3, c4 = u & 7;
+    const int tap = row >> 5, cil = row & 31;
+    float* t = tile + (4 * c4) * PITCH + cil * 9 + tap;
+    t[0] = acc[k].x;
+    t[PITCH] = acc[k].y;
+    t[2 * PITCH] = acc[k].z;
+    t[3 * PITCH] = acc[k].w;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 32 * 288; i += 256) {
@@ -461,7 +488,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // scratch (floats) the reduction needs behind the `splits` slabs of the wgrad kernels
 size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad) {
-  return splits > kReduceFan ? (size_t)ceil_div(splits, kReduceFan) * 9 * cin_pad * cout_pad : 0;
+  size_t slabs = 0;
+  for (int n = splits; n > 1;) {  // every stage-A output (upper bound: all stages down to one slab)
+    n = ceil_div(n, kReduceFan);
+    slabs += n;
+  }
+  return slabs * 9 * cin_pad * cout_pad;
 }
 
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map, int cin_p,
@@ -469,7 +501,11 @@ int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_
   const size_t slab = (size_t)9 * cin_pad * cout_pad;
   const float* src = partial;
   int n = splits;
-  while (n > kReduceFan) {  // stage A (repeated for very large split counts); output behind the inputs
+  const int blocks = ceil_div(cin_pad, 32) * ceil_div(cout_pad, 32);
+  // few output tiles (small layers, hundreds of splits): the transposing kernel has too few workgroups to
+  // stream many slabs, so stage A sums all the way down to one slab
+  const int final_fan = blocks >= 128 ? kReduceFan : 1;
+  while (n > final_fan) {  // stage A (repeated for large split counts); output behind the inputs
     const int groups = ceil_div(n, kReduceFan);
     float* out = const_cast<float*>(src) + (size_t)n * slab;
     const int bx = (int)std::min<size_t>((slab / 4 + 255) / 256, 512);
@@ -478,7 +514,6 @@ int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_
     src = out;
     n = groups;
   }
-  const int blocks = ceil_div(cin_pad, 32) * ceil_div(cout_pad, 32);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, n, cin_pad, cout_pad, cin_map, cin_p,
                      cin, cout, dw);
   MIMO_KERNEL_CHECK();

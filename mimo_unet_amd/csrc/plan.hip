@@ -122,6 +122,17 @@ struct mimo_plan {
   double* s_sums = nullptr;
   size_t cap_act = 0, cap_pad = 0, cap_slab = 0, cap_partial = 0, cap_sums = 0;
 
+  // Weight gradients run on a side stream: wgrad(L) (matrix-pipe bound, little HBM traffic) overlaps
+  // the bandwidth-bound BatchNorm / gather kernels and the data gradient of the layers below it on the
+  // caller's stream.  dz ping-pongs between two buffers so that layer L-1 can write its dz while
+  // wgrad(L) still reads the other one.  MIMO_WGRAD_STREAM=0 puts everything back on one stream.
+  bool wg_async = true;
+  hipStream_t wg_stream = nullptr;
+  hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
+  bool wg_pending[2] = {false, false};
+  float* s_dz2[2] = {nullptr, nullptr};
+  int dz_idx = 0;
+
   // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
   struct ProfRec {
     hipEvent_t a, b;
@@ -199,6 +210,9 @@ struct mimo_plan {
     }
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (wg_stream) (void)hipStreamDestroy(wg_stream);
+    for (hipEvent_t e : {ev_dz[0], ev_dz[1], ev_wg[0], ev_wg[1], ev_join})
+      if (e) (void)hipEventDestroy(e);
   }
 
   template <typename T>
@@ -474,6 +488,18 @@ struct mimo_plan {
     cap_partial = std::max(cap_partial, (size_t)kEwMaxBlocks * (Co * fp + Co));
     cap_sums = std::max(cap_sums, (size_t)kMaxChunks * (Co * fp + Co));
     MIMO_TRY(dalloc(&s_dz, cap_act));
+    {
+      const char* we = getenv("MIMO_WGRAD_STREAM");
+      wg_async = !(we && atoi(we) == 0);
+      s_dz2[0] = s_dz;
+      s_dz2[1] = s_dz;
+      if (wg_async) {
+        MIMO_TRY(dalloc(&s_dz2[1], cap_act));
+        MIMO_HIP_CHECK(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&ev_dz[0], &ev_dz[1], &ev_wg[0], &ev_wg[1], &ev_join})
+          MIMO_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+      }
+    }
     MIMO_TRY(dalloc(&s_dxpadA, cap_pad));
     MIMO_TRY(dalloc(&s_dxpadB, cap_pad));
     MIMO_TRY(dalloc(&s_wslab, cap_slab));
@@ -706,35 +732,22 @@ struct mimo_plan {
     MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_p, s_sums, &chunks, st));
     MIMO_TRY(bn_bwd_finalize_launch(s_sums, chunks, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
                                     grads + L.off_gamma, grads + L.off_beta, st));
+    const int b = dz_idx;
+    float* dz = s_dz2[b];
+    if (wg_async) {
+      dz_idx ^= 1;
+      if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
+    }
     MIMO_TRY(bn_bwd_apply_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
-                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, s_dz, s_partial, &rows, st));
+                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, s_partial, &rows, st));
+    // wgrad(L) may start as soon as dz exists, next to dgrad(L) (releasing it only after dgrad(L), i.e. next
+    // to the bandwidth-bound kernels of the layer below, measured the same step time)
+    if (wg_async) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
     MIMO_TRY(rowsum_launch(s_partial, rows, L.cout_p, s_sums, &chunks, st));
     MIMO_TRY(vec_finalize_launch(s_sums, chunks, L.cout_p, L.Cout, grads + L.off_b, st));
-    WgradLaunch wg;
-    wg.x = L.in;
-    wg.dz = s_dz;
-    wg.partial = s_wslab;
-    wg.N = L.N;
-    wg.H = L.H;
-    wg.W = L.W;
-    wg.ldx = L.ld_in;
-    wg.lddz = L.cout_p;
-    wg.cin_p = L.cin_p;
-    wg.cout_p = L.cout_p;
-    wg.cin_pad = L.wg_cin_pad;
-    wg.cout_pad = L.wg_cout_pad;
-    wg.splits = L.wg_splits;
-    prof_begin(MIMO_PROF_CONV_WGRAD, st);
-    if (L.wg_split)
-      MIMO_TRY(wgrad_split_launch(wg, st));
-    else
-      MIMO_TRY(wgrad_launch(wg, st));
-    prof_end(MIMO_PROF_CONV_WGRAD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
-    MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
-                                 grads + L.off_w, st));
     if (need_dgrad) {
       ConvLaunch a;
-      a.x = s_dz;
+      a.x = dz;
       a.y = dxpad_out;
       a.w = L.wd;
       a.bias = nullptr;
@@ -758,6 +771,46 @@ struct mimo_plan {
         MIMO_TRY(conv3x3_launch(a, nullptr, st));
       prof_end(MIMO_PROF_CONV_DGRAD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     }
+    hipStream_t ws = st;
+    if (wg_async) {
+      MIMO_HIP_CHECK(hipStreamWaitEvent(wg_stream, ev_dz[b], 0));
+      ws = wg_stream;
+    }
+    WgradLaunch wg;
+    wg.x = L.in;
+    wg.dz = dz;
+    wg.partial = s_wslab;
+    wg.N = L.N;
+    wg.H = L.H;
+    wg.W = L.W;
+    wg.ldx = L.ld_in;
+    wg.lddz = L.cout_p;
+    wg.cin_p = L.cin_p;
+    wg.cout_p = L.cout_p;
+    wg.cin_pad = L.wg_cin_pad;
+    wg.cout_pad = L.wg_cout_pad;
+    wg.splits = L.wg_splits;
+    prof_begin(MIMO_PROF_CONV_WGRAD, ws);
+    if (L.wg_split)
+      MIMO_TRY(wgrad_split_launch(wg, ws));
+    else
+      MIMO_TRY(wgrad_launch(wg, ws));
+    prof_end(MIMO_PROF_CONV_WGRAD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), ws);
+    if (wg_async) {
+      MIMO_HIP_CHECK(hipEventRecord(ev_wg[b], wg_stream));
+      wg_pending[b] = true;
+    }
+    MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
+                                 grads + L.off_w, ws));
+    return MIMO_OK;
+  }
+
+  // the caller's stream waits for every weight gradient issued so far
+  int wg_join(hipStream_t st) {
+    if (!wg_async || !(wg_pending[0] || wg_pending[1])) return MIMO_OK;
+    MIMO_HIP_CHECK(hipEventRecord(ev_join, wg_stream));
+    MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
+    wg_pending[0] = wg_pending[1] = false;
     return MIMO_OK;
   }
 
@@ -845,7 +898,7 @@ struct mimo_plan {
     MIMO_TRY(dc_backward(down2, true, st));
     bwd_stage0_done = true;
     if (stage_last >= 1) return backward_encoders(dx, st);
-    return MIMO_OK;
+    return wg_join(st);  // the core / decoder / head gradients are final for the caller (all-reduce)
   }
 
   int backward_encoders(float* dx, hipStream_t st) {
@@ -855,7 +908,7 @@ struct mimo_plan {
       if (dx) MIMO_TRY(unpack_dx_launch(s_dxpadB, Ci_p, N, S, s, Ci, H, W, dx, st));
     }
     bwd_stage0_done = false;
-    return MIMO_OK;
+    return wg_join(st);
   }
 };
 

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   if (wave >= 4) {
     // =========================== producers ===========================
     const int ptid = tid - 256;
-    f32x4 xa[XA], xd[XD];
+    f32x4 xa0[XA], xd0[XD], xa1[XA], xd1[XD];  // two tiles in flight: global latency > one tile of MFMAs
     // per-unit constants, hoisted out of the tile loop: halo-tile coordinates, channel, LDS destination
     int a_tr[XA], a_tc[XA], a_ch[XA], a_dst[XA], d_r[XD], d_c[XD], d_ch[XD], d_dst[XD];
 #pragma unroll
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       d_dst[k] = pix < kWsDPix ? ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + qq * 8 : -1;
     }
     const int H2 = 2 * a.H - 2, W2 = 2 * a.W - 2;
-#define WS_LOAD(TILE)                                                                               \
+#define WS_LOAD(XA_, XD_, TILE)                                                                     \
   {                                                                                                 \
     int t_ = (TILE);                                                                                \
     const int tx_ = t_ % tilesX;                                                                    \
@@ -306,13 +306,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       ix_ = max(min(ix_, W2 - ix_), 0);                                                             \
       const bool ok_ = a_ch[k_] >= 0;                                                               \
       const f32x4 v_ = *reinterpret_cast<const f32x4*>(ximg_ + (iy_ * a.W + ix_) * a.ldx + max(a_ch[k_], 0)); \
-      xa[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+      XA_[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                               \
     }                                                                                               \
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
       const int y_ = y0_ + d_r[k_], x_ = x0_ + d_c[k_];                                             \
       const bool ok_ = d_ch[k_] >= 0 && y_ < a.H && x_ < a.W;                                       \
       const f32x4 v_ = *reinterpret_cast<const f32x4*>(dimg_ + (ok_ ? (y_ * a.W + x_) * a.lddz + d_ch[k_] : 0)); \
-      xd[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+      XD_[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                               \
     }                                                                                               \
   }
 #define WS_SPLIT_STORE(V, DST, CCH)                                                                 \
@@ -325,33 +325,42 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     *reinterpret_cast<bf16x4*>(DST) = hi_;                                                          \
     *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                                            \
   }
-#define WS_STORE(BUF)                                                                               \
+#define WS_STORE(XA_, XD_, BUF)                                                                      \
   {                                                                                                 \
     unsigned char* base_ = smem + (BUF) * BUFBYTES;                                                 \
     _Pragma("unroll") for (int k_ = 0; k_ < XA; ++k_) {                                             \
       if (a_dst[k_] >= 0) {                                                                         \
         unsigned char* d_ = base_ + a_dst[k_];                                                      \
-        WS_SPLIT_STORE(xa[k_], d_, CI)                                                              \
+        WS_SPLIT_STORE(XA_[k_], d_, CI)                                                             \
       }                                                                                             \
     }                                                                                               \
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
       if (d_dst[k_] >= 0) {                                                                         \
         unsigned char* d_ = base_ + d_dst[k_];                                                      \
-        WS_SPLIT_STORE(xd[k_], d_, CO)                                                              \
+        WS_SPLIT_STORE(XD_[k_], d_, CO)                                                             \
       }                                                                                             \
     }                                                                                               \
   }
+    // register set s (0/1) carries tile j with j&1 == s; loads are issued two tiles (= two barriers) ahead
+    const int T0 = blockIdx.y, TS = gridDim.y;
     if (ntiles_mine > 0) {
-      WS_LOAD(blockIdx.y)
-      WS_STORE(0)
-      if (ntiles_mine > 1) WS_LOAD(blockIdx.y + gridDim.y)
+      WS_LOAD(xa0, xd0, T0)
+      if (ntiles_mine > 1) WS_LOAD(xa1, xd1, T0 + TS)
+      WS_STORE(xa0, xd0, 0)
+      if (ntiles_mine > 2) WS_LOAD(xa0, xd0, T0 + 2 * TS)
     }
     __syncthreads();  // tile 0 is in LDS
-    for (int i = 0; i < ntiles_mine; ++i) {
+    for (int i = 0; i < ntiles_mine; i += 2) {
       // consumers multiply tile i from buffer i&1; the other buffer was released by the previous barrier
       if (i + 1 < ntiles_mine) {
-        WS_STORE((i + 1) & 1)
-        if (i + 2 < ntiles_mine) WS_LOAD(blockIdx.y + (i + 2) * gridDim.y)
+        WS_STORE(xa1, xd1, 1)
+        if (i + 3 < ntiles_mine) WS_LOAD(xa1, xd1, T0 + (i + 3) * TS)
+      }
+      __syncthreads();
+      if (i + 1 >= ntiles_mine) break;
+      if (i + 2 < ntiles_mine) {
+        WS_STORE(xa0, xd0, 0)
+        if (i + 4 < ntiles_mine) WS_LOAD(xa0, xd0, T0 + (i + 4) * TS)
       }
       __syncthreads();
     }
