@@ -9,6 +9,9 @@
 //     exactly in the epilogue); activations below 0.125 keep >= 3e-8 absolute precision.
 //   * F16 = false (data gradient): bf16 hi/lo keep fp32's exponent range for the tiny dz values;
 //     ~1e-5 per product on the gradient side is harmless (gradient error 2e-5, same emulation).
+//     The input (dz) arrives PRE-SPLIT — per pixel and 32-channel chunk [hi 32 | lo 32] bf16, written
+//     by the BatchNorm-backward kernel (elementwise.hip st_split4) — which is this kernel's LDS row
+//     image: the loader is a plain copy of one 128-byte line per (pixel, chunk).
 //
 // Same implicit GEMM as conv3x3.hip (M = TRxTC output pixels of one image, N = output channels,
 // K = 9 taps x input channels) with a deeper structure:
@@ -146,10 +149,19 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
     const int u_ = tid + k_ * 512;                                                              \
     const int p_ = min(u_ >> 3, npix_lds - 1), q_ = u_ & 7;                                     \
     const int o_ = goff[p_];                                                                    \
-    const int ch_ = (CHUNK) * 32 + 4 * q_;                                                      \
-    const bool ok_ = o_ >= 0 && ch_ < a.cin_p;                                                  \
-    const f32x4 v_ = *reinterpret_cast<const f32x4*>(ximg + (ok_ ? o_ + ch_ : 0));              \
-    xreg[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                            \
+    if (F16) { /* fp32 input: unit q_ = 4 channels */                                           \
+      const int ch_ = (CHUNK) * 32 + 4 * q_;                                                    \
+      const bool ok_ = o_ >= 0 && ch_ < a.cin_p;                                                \
+      const f32x4 v_ = *reinterpret_cast<const f32x4*>(ximg + (ok_ ? o_ + ch_ : 0));            \
+      xreg[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                          \
+    } else { /* pre-split input, chunk record [hi rc | lo rc] bf16: unit q_ = 8 channels, 16 bytes */ \
+      const int rc_ = min(32, a.cin_p - (CHUNK) * 32);                                          \
+      const bool ok_ = o_ >= 0 && 8 * (q_ & 3) < rc_;                                           \
+      const unsigned short* s_ = reinterpret_cast<const unsigned short*>(ximg + (ok_ ? o_ : 0)) + \
+                                 (ok_ ? (CHUNK) * 64 + (q_ >> 2) * rc_ + 8 * (q_ & 3) : 0);     \
+      const f32x4 v_ = *reinterpret_cast<const f32x4*>(s_);                                     \
+      xreg[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                          \
+    }                                                                                           \
   }
 #define MIMO_STORE_X()                                                                          \
   _Pragma("unroll") for (int k_ = 0; k_ < XU; ++k_) {                                           \
@@ -157,18 +169,22 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
     const int p_ = u_ >> 3, q_ = u_ & 7;                                                        \
     if (p_ < npix_lds) {                                                                        \
       const f32x4 v_ = xreg[k_];                                                                \
-      bf16x4 hi_, lo_;                                                                          \
-      hi_[0] = (ET)v_[0];                                                                       \
-      hi_[1] = (ET)v_[1];                                                                       \
-      hi_[2] = (ET)v_[2];                                                                       \
-      hi_[3] = (ET)v_[3];                                                                       \
-      lo_[0] = (ET)(v_[0] - (float)hi_[0]);                                                     \
-      lo_[1] = (ET)(v_[1] - (float)hi_[1]);                                                     \
-      lo_[2] = (ET)(v_[2] - (float)hi_[2]);                                                     \
-      lo_[3] = (ET)(v_[3] - (float)hi_[3]);                                                     \
-      unsigned char* d_ = xs + p_ * kPitchB + q_ * 8;                                           \
-      *reinterpret_cast<bf16x4*>(d_) = hi_;                                                     \
-      *reinterpret_cast<bf16x4*>(d_ + 64) = lo_;                                                \
+      if (F16) {                                                                                \
+        bf16x4 hi_, lo_;                                                                        \
+        hi_[0] = (ET)v_[0];                                                                     \
+        hi_[1] = (ET)v_[1];                                                                     \
+        hi_[2] = (ET)v_[2];                                                                     \
+        hi_[3] = (ET)v_[3];                                                                     \
+        lo_[0] = (ET)(v_[0] - (float)hi_[0]);                                                   \
+        lo_[1] = (ET)(v_[1] - (float)hi_[1]);                                                   \
+        lo_[2] = (ET)(v_[2] - (float)hi_[2]);                                                   \
+        lo_[3] = (ET)(v_[3] - (float)hi_[3]);                                                   \
+        unsigned char* d_ = xs + p_ * kPitchB + q_ * 8;                                         \
+        *reinterpret_cast<bf16x4*>(d_) = hi_;                                                   \
+        *reinterpret_cast<bf16x4*>(d_ + 64) = lo_;                                              \
+      } else { /* the row image [hi 32 | lo 32] is the global layout: plain 16-byte copy */     \
+        *reinterpret_cast<f32x4*>(xs + p_ * kPitchB + q_ * 16) = v_;                            \
+      }                                                                                         \
     }                                                                                           \
   }
   // weights of chunk CHUNK, tap row ROW: global [chunk][tap][cout_pad][8 x 16 B]

@@ -69,8 +69,11 @@ int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_
 // pass 2: dz = scale * (dy - c1 - xhat*c2); partial rows of sum dz (conv bias gradient)
 int bn_bwd_apply_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
-                        int C, const float* c1, const float* c2, int Cp, int N, int H, int W, float* dz, float* partial,
-                        int* rows, hipStream_t st);
+                        int C, const float* c1, const float* c2, int Cp, int N, int H, int W, float* dz, int split_out,
+                        float* partial, int* rows, hipStream_t st);
+// dst[p] = [hi Cp bf16 | lo Cp bf16] of src[p][Cp] — the storage the bf16-pair convolution kernels read
+// (split_out != 0 above writes dz in this form directly)
+int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStream_t st);
 // out[c] = sum over chunks of sums[chunk][c], c < C
 int vec_finalize_launch(const double* sums, int chunks, int cols, int C, float* out, hipStream_t st);
 

@@ -643,12 +643,46 @@ int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_
   return MIMO_OK;
 }
 
+// Split storage of a gradient tensor for the bf16-pair MFMA kernels (data and weight gradient): per
+// pixel, per 32-channel chunk, [hi: 32 bf16 | lo: 32 bf16] with v ~= hi + lo (a last partial chunk of r
+// channels is [hi r | lo r]) — the same 4*Cp bytes as fp32, and one contiguous 128-byte line per
+// (pixel, chunk), which is exactly the LDS row image of the data-gradient kernel.  The split is the one
+// the convolution loaders used to do on every read (hi = RNE(v), lo = RNE(v - hi)).
+typedef __bf16 bf16x4_ew __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_split4(float* base, size_t p, int Cp, int q, float4 r) {
+  bf16x4_ew hi, lo;
+  hi[0] = (__bf16)r.x;
+  hi[1] = (__bf16)r.y;
+  hi[2] = (__bf16)r.z;
+  hi[3] = (__bf16)r.w;
+  lo[0] = (__bf16)(r.x - (float)hi[0]);
+  lo[1] = (__bf16)(r.y - (float)hi[1]);
+  lo[2] = (__bf16)(r.z - (float)hi[2]);
+  lo[3] = (__bf16)(r.w - (float)hi[3]);
+  const int ch = 4 * q, chunk = ch >> 5, rc = min(32, Cp - 32 * chunk);
+  unsigned char* d = reinterpret_cast<unsigned char*>(base) + p * (size_t)Cp * 4 + chunk * 128 + (ch & 31) * 2;
+  *reinterpret_cast<bf16x4_ew*>(d) = hi;
+  *reinterpret_cast<bf16x4_ew*>(d + 2 * rc) = lo;
+}
+
+__global__ void split_pairs_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cv, int64_t P) {
+  const PQ t = pixquad(Cv);
+  if (!t.active) return;
+  for (int64_t p = t.p; p < P; p += t.pstep) st_split4(dst, (size_t)p, 4 * Cv, t.q, ld4(src + (size_t)p * 4 * Cv + 4 * t.q));
+}
+
+int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStream_t st) {
+  hipLaunchKernelGGL(split_pairs_kernel, pq_grid(Cp / 4, P), dim3(256), 0, st, src, dst, Cp / 4, P);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ dxpad, int ldp,
                                     const float* __restrict__ z, int ldz, const float* __restrict__ scale,
                                     const float* __restrict__ shift, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ mask, int C,
                                     const float* __restrict__ c1, const float* __restrict__ c2, int Cv, int N, int H,
-                                    int W, float* __restrict__ dz, float* __restrict__ partial) {
+                                    int W, float* __restrict__ dz, int split_out, float* __restrict__ partial) {
   __shared__ float4 red[256];
   const PQ t = pixquad(Cv);
   const int Cp = 4 * Cv;
@@ -665,7 +699,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, cons
       r.y = sc.y * (g.y - k1.y - (v.y - mu.y) * is.y * k2.y);
       r.z = sc.z * (g.z - k1.z - (v.z - mu.z) * is.z * k2.z);
       r.w = sc.w * (g.w - k1.w - (v.w - mu.w) * is.w * k2.w);
-      st4(dz + (size_t)p * Cp + 4 * t.q, r);
+      if (split_out)
+        st_split4(dz, p, Cp, t.q, r);
+      else
+        st4(dz + (size_t)p * Cp + 4 * t.q, r);
       acc = f4add(acc, r);
     }
   }
@@ -675,13 +712,13 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, cons
 
 int bn_bwd_apply_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
-                        int C, const float* c1, const float* c2, int Cp, int N, int H, int W, float* dz, float* partial,
-                        int* rows, hipStream_t st) {
+                        int C, const float* c1, const float* c2, int Cp, int N, int H, int W, float* dz, int split_out,
+                        float* partial, int* rows, hipStream_t st) {
   const int Cv = Cp / 4;
   const dim3 grid = pq_grid(Cv, (int64_t)N * H * W);
   *rows = grid.x;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, da, ldda, dxpad, ldp, z, ldz, scale, shift, mean, invstd,
-                     mask, C, c1, c2, Cv, N, H, W, dz, partial);
+                     mask, C, c1, c2, Cv, N, H, W, dz, split_out, partial);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

@@ -137,8 +137,18 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
   }
   MIMO_TRY(pack_weights_launch(w, wdp, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
   if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, 0, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
+  const float* dz_in = dz;
+  if (split) {  // the bf16-pair kernel reads dz in split storage (see elementwise.h split_pairs_launch)
+    float* dzs = t.get<float>((size_t)n * h * wd * cout_p);
+    if (!dzs) {
+      set_error("mimo_op_conv3x3_dgrad: allocation failed");
+      return MIMO_ERR_HIP;
+    }
+    MIMO_TRY(split_pairs_launch(dz, dzs, (int64_t)n * h * wd, cout_p, st));
+    dz_in = dzs;
+  }
   ConvLaunch a;
-  a.x = dz;
+  a.x = dz_in;
   a.y = dxpad;
   a.w = wdp;
   a.bias = nullptr;
@@ -197,10 +207,18 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
     set_error("mimo_op_conv3x3_wgrad: allocation failed");
     return MIMO_ERR_HIP;
   }
-  if (split)
+  if (split) {  // split storage of dz, as the BatchNorm-backward kernel writes it in the plan
+    float* dzs = t.get<float>((size_t)n * h * wd * cout_p);
+    if (!dzs) {
+      set_error("mimo_op_conv3x3_wgrad: allocation failed");
+      return MIMO_ERR_HIP;
+    }
+    MIMO_TRY(split_pairs_launch(dz, dzs, (int64_t)n * h * wd, cout_p, st));
+    a.dz = dzs;
     MIMO_TRY(wgrad_split_launch(a, st));
-  else
+  } else {
     MIMO_TRY(wgrad_launch(a, st));
+  }
   MIMO_TRY(wgrad_reduce_launch(a.partial, a.splits, a.cin_pad, a.cout_pad, cm, cin_p, cin, cout, dw, st));
   if (dbias) {
     hipLaunchKernelGGL(colsum_naive_kernel, dim3(cout), dim3(256), 0, st, dz, (int64_t)n * h * wd, cout_p, cout, dbias);

@@ -131,6 +131,10 @@ struct mimo_plan {
   hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
   bool wg_pending[2] = {false, false};
   float* s_dz2[2] = {nullptr, nullptr};
+  // split (bf16 hi|lo) copy of dz for layers whose data gradient runs on the fp32 kernel while the weight
+  // gradient runs on the bf16-pair kernel (fewer than 16 output channels); null when no layer needs it
+  float* s_dzs2[2] = {nullptr, nullptr};
+  bool any_mixed_dz = false;
   int dz_idx = 0;
 
   // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
@@ -286,6 +290,7 @@ struct mimo_plan {
     // split-bf16 MFMA needs a K chunk of 32 channels; the 2..4-channel image conv stays on the fp32 kernel
     L.fwd_split = cfg.precision == MIMO_PREC_SPLIT16 && L.cin_p >= 16;
     L.dg_split = cfg.precision == MIMO_PREC_SPLIT16 && L.cout_p >= 16;
+    if (L.wg_split && !L.dg_split) any_mixed_dz = true;
     if (L.fwd_split) {
       uint16_t* q = nullptr;
       MIMO_TRY(dalloc(&q, (size_t)ceil_div(L.cin_p, 32) * 9 * L.cout_pad * 64));
@@ -493,6 +498,11 @@ struct mimo_plan {
       wg_async = !(we && atoi(we) == 0);
       s_dz2[0] = s_dz;
       s_dz2[1] = s_dz;
+      if (any_mixed_dz) {
+        MIMO_TRY(dalloc(&s_dzs2[0], cap_act));
+        s_dzs2[1] = s_dzs2[0];
+        if (wg_async) MIMO_TRY(dalloc(&s_dzs2[1], cap_act));
+      }
       if (wg_async) {
         MIMO_TRY(dalloc(&s_dz2[1], cap_act));
         MIMO_HIP_CHECK(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
@@ -739,7 +749,14 @@ struct mimo_plan {
       if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
     }
     MIMO_TRY(bn_bwd_apply_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
-                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, s_partial, &rows, st));
+                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, L.dg_split ? 1 : 0, s_partial, &rows, st));
+    // dz storage: bf16 hi|lo pairs when the data-gradient kernel is the bf16-pair one (then the weight
+    // gradient is too); fp32 otherwise, with a split copy for a bf16-pair weight gradient
+    const float* dz_wg = dz;
+    if (L.wg_split && !L.dg_split) {
+      MIMO_TRY(split_pairs_launch(dz, s_dzs2[b], P, L.cout_p, st));
+      dz_wg = s_dzs2[b];
+    }
     // wgrad(L) may start as soon as dz exists, next to dgrad(L) (releasing it only after dgrad(L), i.e. next
     // to the bandwidth-bound kernels of the layer below, measured the same step time)
     if (wg_async) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
@@ -778,7 +795,7 @@ struct mimo_plan {
     }
     WgradLaunch wg;
     wg.x = L.in;
-    wg.dz = dz;
+    wg.dz = dz_wg;
     wg.partial = s_wslab;
     wg.N = L.N;
     wg.H = L.H;

@@ -4,6 +4,10 @@
 //
 //   dW[tap][ci][co] = sum_pixels A(pixel + tap, ci) * dz(pixel, co)      (components.py:23,26 autograd)
 //
+// dz arrives PRE-SPLIT from the BatchNorm-backward kernel — per pixel and 32-channel chunk
+// [hi 32 | lo 32] bf16 (elementwise.hip st_split4) — so its staging is a 16-byte copy; the activation operand A is fp32 in
+// HBM (it also feeds the fp16-pair forward and the bandwidth-class kernels) and is split on the way in.
+//
 // GEMM view: M = input channels, N = output channels, K = pixels (32 per v_mfma_f32_16x16x32_bf16).
 // Both operands are stored in LDS the way they sit in HBM — pixel-major NHWC rows, split into
 // [hi C x bf16 | lo C x bf16] — and are read with ds_read_b64_tr_b16, the hardware transposed
@@ -107,8 +111,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
       const int pix_ = u_ / QD, qq_ = u_ - pix_ * QD;                                               \
       const int r_ = pix_ / kWgTC, c_ = pix_ - r_ * kWgTC;                                          \
       const int y_ = y0_ + r_, x_ = x0_ + c_;                                                       \
-      const bool ok_ = pix_ < kWgDPix && y_ < a.H && x_ < a.W && co0 + 4 * qq_ < a.cout_p;          \
-      const f32x4 v_ = *reinterpret_cast<const f32x4*>(dimg_ + (ok_ ? ((size_t)y_ * a.W + x_) * a.lddz + co0 + 4 * qq_ : 0)); \
+      /* dz is pre-split, per 32-channel chunk [hi rc | lo rc] bf16: unit = 8 channels, 16 bytes */ \
+      const int half_ = qq_ / (CO / 8), ch_ = co0 + 8 * (qq_ - half_ * (CO / 8));                   \
+      const int rc_ = min(32, a.cout_p - (ch_ & ~31));                                              \
+      const bool ok_ = pix_ < kWgDPix && y_ < a.H && x_ < a.W && ch_ < a.cout_p;                    \
+      const unsigned short* s_ = reinterpret_cast<const unsigned short*>(dimg_ + (ok_ ? ((size_t)y_ * a.W + x_) * a.lddz : 0)) + \
+                                 (ok_ ? (ch_ >> 5) * 64 + half_ * rc_ + (ch_ & 31) : 0);            \
+      const f32x4 v_ = *reinterpret_cast<const f32x4*>(s_);                                         \
       xd[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                                \
     }                                                                                               \
   }
@@ -135,9 +144,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
       const int u_ = tid + k_ * 256;                                                                \
       const int pix_ = u_ / QD, qq_ = u_ - pix_ * QD;                                               \
-      if (pix_ < kWgDPix) {                                                                         \
-        unsigned char* d_ = ds_ + pix_ * PD + ((pix_ >> 3) & 1) * 32 + qq_ * 8;                     \
-        WG_SPLIT_STORE(xd[k_], d_, CO)                                                              \
+      if (pix_ < kWgDPix) { /* row image [hi CO | lo CO]: plain 16-byte copy of the pre-split dz */ \
+        const int half_ = qq_ / (CO / 8), c8_ = qq_ - half_ * (CO / 8);                             \
+        unsigned char* d_ = ds_ + pix_ * PD + ((pix_ >> 3) & 1) * 32 + half_ * 2 * CO + c8_ * 16;   \
+        *reinterpret_cast<f32x4*>(d_) = xd[k_];                                                     \
       }                                                                                             \
     }                                                                                               \
   }
@@ -282,10 +292,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     for (int k = 0; k < XD; ++k) {
       const int u = ptid + k * 256;
       const int pix = u / QD, qq = u - pix * QD;
+      const int half = qq / (CO / 8), c8 = qq - half * (CO / 8);  // pre-split dz: 8 channels of the hi or lo plane
       d_r[k] = pix / kWgTC;
       d_c[k] = pix % kWgTC;
-      d_ch[k] = (pix < kWsDPix && co0 + 4 * qq < a.cout_p) ? co0 + 4 * qq : -1;
-      d_dst[k] = pix < kWsDPix ? ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + qq * 8 : -1;
+      const int ch = co0 + 8 * c8, rc = min(32, a.cout_p - (ch & ~31));  // chunk record [hi rc | lo rc]
+      d_ch[k] = (pix < kWsDPix && ch < a.cout_p) ? (ch >> 5) * 64 + half * rc + (ch & 31) : -1;  // in bf16 units
+      d_dst[k] = pix < kWsDPix ? ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + half * 2 * CO + c8 * 16 : -1;
     }
     const int H2 = 2 * a.H - 2, W2 = 2 * a.W - 2;
 #define WS_LOAD(XA_, XD_, TILE)                                                                     \
@@ -311,7 +323,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
       const int y_ = y0_ + d_r[k_], x_ = x0_ + d_c[k_];                                             \
       const bool ok_ = d_ch[k_] >= 0 && y_ < a.H && x_ < a.W;                                       \
-      const f32x4 v_ = *reinterpret_cast<const f32x4*>(dimg_ + (ok_ ? (y_ * a.W + x_) * a.lddz + d_ch[k_] : 0)); \
+      const unsigned short* s_ = reinterpret_cast<const unsigned short*>(dimg_ + (ok_ ? (y_ * a.W + x_) * a.lddz : 0)) + \
+                                 (ok_ ? d_ch[k_] : 0);                                              \
+      const f32x4 v_ = *reinterpret_cast<const f32x4*>(s_);                                         \
       XD_[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                               \
     }                                                                                               \
   }
@@ -335,10 +349,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       }                                                                                             \
     }                                                                                               \
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
-      if (d_dst[k_] >= 0) {                                                                         \
-        unsigned char* d_ = base_ + d_dst[k_];                                                      \
-        WS_SPLIT_STORE(XD_[k_], d_, CO)                                                             \
-      }                                                                                             \
+      if (d_dst[k_] >= 0) *reinterpret_cast<f32x4*>(base_ + d_dst[k_]) = XD_[k_]; /* plain copy */ \
     }                                                                                               \
   }
     // register set s (0/1) carries tile j with j&1 == s; loads are issued two tiles (= two barriers) ahead
