@@ -60,6 +60,12 @@ int pack_weights_bf16x3_launch(const float* w, void* dst, int f16, int cout, int
 int conv3x3_pick_nfrag(int cout);            // fragments (of 16 output channels) per workgroup
 int conv3x3_cout_pad(int cout);              // packed weight rows for that choice
 int conv3x3_stat_rows(int N, int Ho, int Wo);  // spatial workgroups == partial-stat rows
+int conv3x3_ws_stat_rows(int N, int Ho, int Wo);  // same for the wave-specialised split kernel (4 rows per tile)
+
+// 256 bytes of zeros in device memory: masked-out tile elements are LOADED from here instead of being
+// selected to zero after the load — a select on the loaded value makes the compiler wait for the load
+// right where it was issued, which silently removes a register prefetch.
+static __device__ __attribute__((aligned(256))) float kZeroPage[64];  // zero-initialised, never written
 
 struct WgradLaunch {
   const float* x;   // [N,H,W,ldx] activations feeding the conv (reflect-padded on the fly)

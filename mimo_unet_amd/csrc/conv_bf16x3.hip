@@ -149,18 +149,17 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
     const int u_ = tid + k_ * 512;                                                              \
     const int p_ = min(u_ >> 3, npix_lds - 1), q_ = u_ & 7;                                     \
     const int o_ = goff[p_];                                                                    \
+    /* masked-out units are loaded from kZeroPage (common.h), never selected after the load */   \
     if (F16) { /* fp32 input: unit q_ = 4 channels */                                           \
       const int ch_ = (CHUNK) * 32 + 4 * q_;                                                    \
       const bool ok_ = o_ >= 0 && ch_ < a.cin_p;                                                \
-      const f32x4 v_ = *reinterpret_cast<const f32x4*>(ximg + (ok_ ? o_ + ch_ : 0));            \
-      xreg[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                          \
+      xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg + o_ + ch_ : kZeroPage);            \
     } else { /* pre-split input, chunk record [hi rc | lo rc] bf16: unit q_ = 8 channels, 16 bytes */ \
       const int rc_ = min(32, a.cin_p - (CHUNK) * 32);                                          \
       const bool ok_ = o_ >= 0 && 8 * (q_ & 3) < rc_;                                           \
-      const unsigned short* s_ = reinterpret_cast<const unsigned short*>(ximg + (ok_ ? o_ : 0)) + \
-                                 (ok_ ? (CHUNK) * 64 + (q_ >> 2) * rc_ + 8 * (q_ & 3) : 0);     \
-      const f32x4 v_ = *reinterpret_cast<const f32x4*>(s_);                                     \
-      xreg[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                          \
+      const unsigned short* s_ = reinterpret_cast<const unsigned short*>(ximg + o_) +           \
+                                 ((CHUNK) * 64 + (q_ >> 2) * rc_ + 8 * (q_ & 3));               \
+      xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
     }                                                                                           \
   }
 #define MIMO_STORE_X()                                                                          \
@@ -342,6 +341,313 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
 #undef MIMO_LOAD_W
 #undef MIMO_STORE_W
 
+// ---------------------------------------------------------------------------------------
+// Wave-specialised, persistent variant (same arithmetic, same packed weights, same LDS row images).
+// In the kernel above every wave stages AND multiplies, and the input tile of the next chunk is
+// rewritten in an exclusive barrier-to-barrier section.  Here waves 0-3 ("consumers") only issue
+// ds_read_b128 + MFMA and waves 4-7 ("producers", one next to a consumer on every SIMD) do all the
+// staging: global loads two stages ahead in registers, fp32 -> hi/lo split (forward) or plain copy
+// (data gradient, pre-split dz), LDS writes into the OTHER input-tile / weight buffer.  The
+// workgroup is persistent over output tiles, so the first chunk of the next tile is staged under the
+// last chunk of the current one and the output epilogue of the consumers overlaps the producers.
+//   tile = 256 output pixels (4 consumers x 4 fragments of 16 pixels) x NF*16 output channels
+//   LDS  = 2 input tiles (360 x 144 B) + 2 weight tap rows (3 x NB x 144 B) <= 159 KB
+//   one workgroup barrier per phase (tap row of a 32-channel chunk)
+// BatchNorm partial sums: one row per (tile, consumer wave) — no cross-wave LDS reduction.
+// ---------------------------------------------------------------------------------------
+constexpr int kWsNPix = 256, kWsMaxPix = 360, kWsMF = 4;
+
+template <int NF, bool F16>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX,
+                                                            int numTiles) {
+  typedef typename Elem<F16>::T ET;
+  typedef typename Elem<F16>::V8 bf16x8;
+  typedef typename Elem<F16>::V4 bf16x4;
+  constexpr int NB = NF * 16;
+  constexpr int MF = kWsMF;
+  constexpr int XU = (kWsMaxPix * 8 + 255) / 256;  // 16-byte units of an input tile per producer thread (12)
+  constexpr int XP = XU / 3;                        // units handled per phase
+  static_assert(XU % 3 == 0, "input tile staged in three equal parts");
+  constexpr int WUNITS = 3 * NB * 8;
+  constexpr int WU = (WUNITS + 255) / 256;
+  constexpr int XBYTES = kWsMaxPix * kPitchB, WROWB = 3 * NB * kPitchB;
+  __shared__ __attribute__((aligned(16))) unsigned char xs[2 * XBYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char ws[2 * WROWB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int TCP = TC + 2, TRP = TR + 2;
+  const int npix_lds = TRP * TCP, npix_out = TR * TC;
+  const int co0 = blockIdx.y * NB;
+  const int nchunks = (a.cin_p + 31) / 32;
+  const int ntiles_mine = (int)blockIdx.x < numTiles ? (numTiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int nstages = ntiles_mine * nchunks;  // input-tile stages (tile, chunk); 3 phases each
+
+  if (wave >= 4) {
+    // =============================== producers ===============================
+    const int ptid = tid - 256;
+    f32x4 xreg[XU];
+    u32x4 wreg[3][WU];
+    int u_tr[XU], u_tc[XU];  // halo-tile coordinates of this thread's units (tile-shape constants)
+#pragma unroll
+    for (int k = 0; k < XU; ++k) {
+      const int p = min((ptid + k * 256) >> 3, npix_lds - 1);
+      u_tr[k] = p / TCP;
+      u_tc[k] = p - u_tr[k] * TCP;
+    }
+    const u32x4* wpk = reinterpret_cast<const u32x4*>(a.wpk);
+    // stage j = (tile j / nchunks, chunk j % nchunks)
+#define WS_LOAD_X(K0, K1, STAGE)                                                                     \
+  {                                                                                                  \
+    const int st_ = (STAGE);                                                                         \
+    const int ti_ = st_ / nchunks, ck_ = st_ - ti_ * nchunks;                                        \
+    int t_ = blockIdx.x + ti_ * gridDim.x;                                                           \
+    const int tx_ = t_ % tilesX;                                                                     \
+    t_ /= tilesX;                                                                                    \
+    const int ty_ = t_ % tilesY;                                                                     \
+    const int n_ = t_ / tilesY;                                                                      \
+    const int y0_ = ty_ * TR - a.off, x0_ = tx_ * TC - a.off;                                        \
+    const float* ximg_ = a.x + (size_t)n_ * a.Hi * a.Wi * a.ldx;                                     \
+    _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                         \
+      int iy_ = y0_ + u_tr[k_], ix_ = x0_ + u_tc[k_];                                                \
+      bool in_ = true;                                                                               \
+      if (a.off == 1) { /* reflect (forward) */                                                      \
+        iy_ = max(iy_, -iy_);                                                                        \
+        iy_ = max(min(iy_, 2 * a.Hi - 2 - iy_), 0);                                                  \
+        ix_ = max(ix_, -ix_);                                                                        \
+        ix_ = max(min(ix_, 2 * a.Wi - 2 - ix_), 0);                                                  \
+      } else { /* zero padding (transposed convolution) */                                           \
+        in_ = iy_ >= 0 && iy_ < a.Hi && ix_ >= 0 && ix_ < a.Wi;                                      \
+      }                                                                                              \
+      const int q_ = (ptid + k_ * 256) & 7;                                                          \
+      const int o_ = in_ ? (iy_ * a.Wi + ix_) * a.ldx : 0;                                           \
+      if (F16) {                                                                                     \
+        const int ch_ = ck_ * 32 + 4 * q_;                                                           \
+        const bool ok_ = in_ && ch_ < a.cin_p;                                                       \
+        xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg_ + o_ + ch_ : kZeroPage);              \
+      } else {                                                                                       \
+        const int rc_ = min(32, a.cin_p - ck_ * 32);                                                 \
+        const bool ok_ = in_ && 8 * (q_ & 3) < rc_;                                                  \
+        const unsigned short* s_ = reinterpret_cast<const unsigned short*>(ximg_ + o_) +             \
+                                   (ck_ * 64 + (q_ >> 2) * rc_ + 8 * (q_ & 3));                      \
+        xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
+      }                                                                                              \
+    }                                                                                                \
+  }
+#define WS_STORE_X(K0, K1, BUF)                                                                      \
+  _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                           \
+    const int u_ = ptid + k_ * 256;                                                                  \
+    const int p_ = u_ >> 3, q_ = u_ & 7;                                                             \
+    if (p_ < npix_lds) {                                                                             \
+      const f32x4 v_ = xreg[k_];                                                                     \
+      unsigned char* row_ = xs + (BUF) * XBYTES + p_ * kPitchB;                                      \
+      if (F16) {                                                                                     \
+        bf16x4 hi_, lo_;                                                                             \
+        hi_[0] = (ET)v_[0];                                                                          \
+        hi_[1] = (ET)v_[1];                                                                          \
+        hi_[2] = (ET)v_[2];                                                                          \
+        hi_[3] = (ET)v_[3];                                                                          \
+        lo_[0] = (ET)(v_[0] - (float)hi_[0]);                                                        \
+        lo_[1] = (ET)(v_[1] - (float)hi_[1]);                                                        \
+        lo_[2] = (ET)(v_[2] - (float)hi_[2]);                                                        \
+        lo_[3] = (ET)(v_[3] - (float)hi_[3]);                                                        \
+        *reinterpret_cast<bf16x4*>(row_ + q_ * 8) = hi_;                                             \
+        *reinterpret_cast<bf16x4*>(row_ + q_ * 8 + 64) = lo_;                                        \
+      } else {                                                                                       \
+        *reinterpret_cast<f32x4*>(row_ + q_ * 16) = v_;                                              \
+      }                                                                                              \
+    }                                                                                                \
+  }
+    // weights of global phase PH = 3 * stage + r: chunk = stage % nchunks, tap row r
+#define WS_LOAD_W(SLOT, PH)                                                                          \
+  {                                                                                                  \
+    const int phw_ = (PH);                                                                           \
+    const int ck_ = (phw_ / 3) % nchunks, r_ = phw_ % 3;                                             \
+    _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                              \
+      const int u_ = min(ptid + k_ * 256, WUNITS - 1);                                               \
+      const int t_ = u_ / (NB * 8);                                                                  \
+      const int rem_ = u_ - t_ * (NB * 8);                                                           \
+      wreg[SLOT][k_] = wpk[(((size_t)ck_ * 9 + (r_ * 3 + t_)) * a.cout_pad + co0 + (rem_ >> 3)) * 8 + (rem_ & 7)]; \
+    }                                                                                                \
+  }
+#define WS_STORE_W(SLOT, BUF)                                                                        \
+  _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                                \
+    const int u_ = ptid + k_ * 256;                                                                  \
+    if (u_ < WUNITS) {                                                                               \
+      const int t_ = u_ / (NB * 8);                                                                  \
+      const int rem_ = u_ - t_ * (NB * 8);                                                           \
+      *reinterpret_cast<u32x4*>(ws + (BUF) * WROWB + (t_ * NB + (rem_ >> 3)) * kPitchB + (rem_ & 7) * 16) = wreg[SLOT][k_]; \
+    }                                                                                                \
+  }
+    const int nphases = 3 * nstages;
+    WS_LOAD_X(0, XU, 0)  // nstages >= 1: the grid never exceeds the tile count
+    WS_LOAD_W(0, 0)
+    WS_LOAD_W(1, 1)
+    WS_LOAD_W(2, 2)
+    WS_STORE_X(0, XU, 0)
+    WS_STORE_W(0, 0)
+    WS_LOAD_X(0, XU, min(1, nstages - 1))
+    __syncthreads();  // phase 0 is staged
+    // during phase (j, r): store W(phase + 1) and part r of input stage j + 1 into the buffers the
+    // consumers released at the last barrier; then refill those registers two / three phases ahead
+    for (int j = 0; j < nstages; ++j) {
+      const int xb = (j + 1) & 1;
+#define WS_PHASE(R)                                                                                  \
+  {                                                                                                  \
+    /* no conditionals: past the end the loads re-read the last stage / phase and the stores go to   \
+       buffers nobody reads any more -- straight-line code lets the compiler keep exact vmcnt counts \
+       (a conditional load forces a full drain at the join and collapses the prefetch depth) */      \
+    const int ph_ = 3 * j + (R);                                                                     \
+    WS_STORE_W(((R) + 1) % 3, (ph_ + 1) & 1)                                                         \
+    WS_LOAD_W((R), min(ph_ + 3, nphases - 1))                                                        \
+    WS_STORE_X((R) * XP, ((R) + 1) * XP, xb)                                                         \
+    WS_LOAD_X((R) * XP, ((R) + 1) * XP, min(j + 2, nstages - 1))                                     \
+    __syncthreads();                                                                                 \
+  }
+      WS_PHASE(0)
+      WS_PHASE(1)
+      WS_PHASE(2)
+#undef WS_PHASE
+    }
+#undef WS_LOAD_X
+#undef WS_STORE_X
+#undef WS_LOAD_W
+#undef WS_STORE_W
+    return;
+  }
+
+  // =============================== consumers ===============================
+  const int lr = lane & 15, g = lane >> 4;
+  int pbase[MF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m) {
+    int idx = (wave * MF + m) * 16 + lr;
+    if (idx >= npix_out) idx = 0;
+    const int r = idx / TC, c = idx - r * TC;
+    pbase[m] = (r * TCP + c) * kPitchB + g * 16;
+  }
+  const int wbase = lr * kPitchB + g * 16;
+  float bv[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) bv[nf] = a.bias ? a.bias[co0 + nf * 16 + lr] : 0.f;
+
+  __syncthreads();  // phase 0 is staged
+  int ph = 0;
+  for (int ti = 0; ti < ntiles_mine; ++ti) {
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) acc[m][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunks; ++c) {
+      const unsigned char* xb = xs + ((ti * nchunks + c) & 1) * XBYTES;
+#pragma unroll
+      for (int r = 0; r < 3; ++r, ++ph) {
+        const unsigned char* wb = ws + (ph & 1) * WROWB + wbase;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int toff = (r * TCP + kw) * kPitchB;
+          bf16x8 bh[NF], bl[NF];
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            bh[nf] = *reinterpret_cast<const bf16x8*>(wb + (kw * NB + nf * 16) * kPitchB);
+            bl[nf] = *reinterpret_cast<const bf16x8*>(wb + (kw * NB + nf * 16) * kPitchB + 64);
+          }
+#pragma unroll
+          for (int m = 0; m < MF; ++m) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xb + pbase[m] + toff);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(xb + pbase[m] + toff + 64);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+              acc[m][nf] = mfma16(al, bh[nf], acc[m][nf]);
+              acc[m][nf] = mfma16(ah, bl[nf], acc[m][nf]);
+              acc[m][nf] = mfma16(ah, bh[nf], acc[m][nf]);
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- epilogue of this tile (the producers are already staging the next one) ----
+    int t = blockIdx.x + ti * gridDim.x;
+    const int tx = t % tilesX;
+    t /= tilesX;
+    const int ty = t % tilesY;
+    const int n = t / tilesY;
+    const int y0 = ty * TR, x0 = tx * TC;
+    float s1[NF], s2[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      s1[nf] = 0.f;
+      s2[nf] = 0.f;
+    }
+    float* yimg = a.y + (size_t)n * a.Ho * a.Wo * a.ldy;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int idx = (wave * MF + m) * 16 + g * 4 + r4;
+        const int orow = idx / TC, ocol = idx - orow * TC;
+        const int oy = y0 + orow, ox = x0 + ocol;
+        if (idx < npix_out && oy < a.Ho && ox < a.Wo) {
+          float* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy + co0 + lr;
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            const float v = acc[m][nf][r4] * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];
+            if (co0 + nf * 16 + lr < a.cout_store) yp[nf * 16] = v;
+            s1[nf] += v;
+            s2[nf] += v * v;
+          }
+        }
+      }
+    }
+    if (a.stats) {
+      const size_t row = ((size_t)(blockIdx.x + ti * gridDim.x) * 4 + wave) * 2;
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        s1[nf] += __shfl_xor(s1[nf], 16);
+        s1[nf] += __shfl_xor(s1[nf], 32);
+        s2[nf] += __shfl_xor(s2[nf], 16);
+        s2[nf] += __shfl_xor(s2[nf], 32);
+        if (g == 0) {
+          a.stats[(row + 0) * a.cout_pad + co0 + nf * 16 + lr] = s1[nf];
+          a.stats[(row + 1) * a.cout_pad + co0 + nf * 16 + lr] = s2[nf];
+        }
+      }
+    }
+  }
+}
+
+static bool conv_ws_enabled() {
+  static const bool on = !(getenv("MIMO_CONV_WS") && atoi(getenv("MIMO_CONV_WS")) == 0);
+  return on;
+}
+
+int conv3x3_ws_stat_rows(int N, int Ho, int Wo) {
+  int TR, TC;
+  pick_tile_n(Ho, Wo, kWsNPix, kWsMaxPix, &TR, &TC);
+  return N * ceil_div(Ho, TR) * ceil_div(Wo, TC) * 4;
+}
+
+template <int NF, bool F16>
+static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
+  int TR, TC;
+  pick_tile_n(a.Ho, a.Wo, kWsNPix, kWsMaxPix, &TR, &TC);
+  const int tilesY = ceil_div(a.Ho, TR), tilesX = ceil_div(a.Wo, TC);
+  const int numTiles = a.N * tilesY * tilesX;
+  const int coTiles = a.cout_pad / (NF * 16);
+  if (rows) *rows = numTiles * 4;
+  // persistent: one workgroup per CU (LDS), every workgroup of a launch walks the same number of tiles
+  int gx = max(1, 256 / coTiles);
+  if (gx > numTiles) gx = numTiles;
+  const int per = ceil_div(numTiles, gx);
+  gx = ceil_div(numTiles, per);
+  dim3 grid(gx, coTiles);
+  hipLaunchKernelGGL((conv3x3_ws_kernel<NF, F16>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
 template <int MF, int NF, bool F16>
 static int launch_bf16x3(const ConvLaunch& a, int* rows, hipStream_t stream) {
   int TR, TC;
@@ -365,6 +671,14 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
   // NF <= 2: little MFMA work per tile -> 256-pixel tiles so that two workgroups share a CU and
   // one's loads / stores overlap the other's MFMAs (MIMO_CONV_BIGTILE_NF2=1 restores 512-pixel tiles)
   static const bool big_nf2 = getenv("MIMO_CONV_BIGTILE_NF2") && atoi(getenv("MIMO_CONV_BIGTILE_NF2")) != 0;
+  if (conv_ws_enabled() && a.Ho * a.Wo >= 256) {
+    switch (nf) {
+      case 4: return launch_ws<4, F16>(a, rows, stream);
+      case 3: return launch_ws<3, F16>(a, rows, stream);
+      case 2: return launch_ws<2, F16>(a, rows, stream);
+      default: return launch_ws<1, F16>(a, rows, stream);
+    }
+  }
   if (use_big_tile(a.Ho, a.Wo) && (nf >= 3 || big_nf2)) {
     switch (nf) {
       case 4: return launch_bf16x3<4, 4, F16>(a, rows, stream);

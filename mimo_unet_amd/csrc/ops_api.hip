@@ -79,7 +79,7 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   float* bp = t.get<float>(cout_pad);
   int* rm = t.ints(ident_map(cout_pad, cout));
   int* cm = t.ints(ident_map(cin_p, cin));
-  const int rows_cap = conv3x3_stat_rows(n, h, wd);
+  const int rows_cap = std::max(conv3x3_stat_rows(n, h, wd), conv3x3_ws_stat_rows(n, h, wd));
   float* partial = t.get<float>((size_t)rows_cap * 2 * cout_pad);
   double* sums = t.get<double>((size_t)kMaxChunks * 2 * cout_pad);
   if (!wf || !bp || !rm || !cm || !partial || !sums) {

@@ -102,9 +102,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
       ix_ = ix_ >= a.W ? 2 * a.W - 2 - ix_ : ix_;                                                   \
       iy_ = min(max(iy_, 0), a.H - 1);                                                              \
       ix_ = min(max(ix_, 0), a.W - 1);                                                              \
-      const bool ok_ = ci0 + 4 * qq_ < a.cin_p;                                                     \
-      const f32x4 v_ = *reinterpret_cast<const f32x4*>(ximg_ + ((size_t)iy_ * a.W + ix_) * a.ldx + (ok_ ? ci0 + 4 * qq_ : 0)); \
-      xa[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+      const bool ok_ = ci0 + 4 * qq_ < a.cin_p; /* masked-out units load from kZeroPage (common.h) */ \
+      xa[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg_ + ((size_t)iy_ * a.W + ix_) * a.ldx + ci0 + 4 * qq_ : kZeroPage); \
     }                                                                                               \
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
       const int u_ = tid + k_ * 256;                                                                \
@@ -115,10 +114,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
       const int half_ = qq_ / (CO / 8), ch_ = co0 + 8 * (qq_ - half_ * (CO / 8));                   \
       const int rc_ = min(32, a.cout_p - (ch_ & ~31));                                              \
       const bool ok_ = pix_ < kWgDPix && y_ < a.H && x_ < a.W && ch_ < a.cout_p;                    \
-      const unsigned short* s_ = reinterpret_cast<const unsigned short*>(dimg_ + (ok_ ? ((size_t)y_ * a.W + x_) * a.lddz : 0)) + \
-                                 (ok_ ? (ch_ >> 5) * 64 + half_ * rc_ + (ch_ & 31) : 0);            \
-      const f32x4 v_ = *reinterpret_cast<const f32x4*>(s_);                                         \
-      xd[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                                \
+      const unsigned short* s_ = reinterpret_cast<const unsigned short*>(dimg_ + ((size_t)y_ * a.W + x_) * a.lddz) + \
+                                 ((ch_ >> 5) * 64 + half_ * rc_ + (ch_ & 31));                      \
+      xd[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
     }                                                                                               \
   }
 #define WG_SPLIT_STORE(V, DST, CCH)                                                                 \
@@ -258,7 +256,9 @@ constexpr int kWsAPix = (kWsTR + 2) * kWgTCP;  // 136
 constexpr int kWsDPix = kWsTR * kWgTC;         // 64
 
 __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
-  constexpr int CI = 64, CO = 64, MI = 2, NI = 2;
+  // consumer wave = 16 ci x 64 co (MI = 1, NI = 4): an A fragment (re-read for every tap) then feeds 12
+  // MFMAs instead of 6 as in a 32x32 arrangement -> 52 instead of 80 transposed LDS reads per 108 MFMAs
+  constexpr int CI = 64, CO = 64, MI = 1, NI = 4;
   constexpr int PA = wg_pitch(CI), PD = wg_pitch(CO);
   constexpr int QA = CI / 4, QD = CO / 4;
   constexpr int XA = (kWsAPix * QA + 255) / 256, XD = (kWsDPix * QD + 255) / 256;  // per producer thread
@@ -317,16 +317,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       ix_ = max(ix_, -ix_);                                                                         \
       ix_ = max(min(ix_, W2 - ix_), 0);                                                             \
       const bool ok_ = a_ch[k_] >= 0;                                                               \
-      const f32x4 v_ = *reinterpret_cast<const f32x4*>(ximg_ + (iy_ * a.W + ix_) * a.ldx + max(a_ch[k_], 0)); \
-      XA_[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                               \
+      XA_[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg_ + (iy_ * a.W + ix_) * a.ldx + a_ch[k_] : kZeroPage); \
     }                                                                                               \
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
       const int y_ = y0_ + d_r[k_], x_ = x0_ + d_c[k_];                                             \
       const bool ok_ = d_ch[k_] >= 0 && y_ < a.H && x_ < a.W;                                       \
-      const unsigned short* s_ = reinterpret_cast<const unsigned short*>(dimg_ + (ok_ ? (y_ * a.W + x_) * a.lddz : 0)) + \
-                                 (ok_ ? d_ch[k_] : 0);                                              \
-      const f32x4 v_ = *reinterpret_cast<const f32x4*>(s_);                                         \
-      XD_[k_] = ok_ ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                               \
+      const unsigned short* s_ = reinterpret_cast<const unsigned short*>(dimg_ + (y_ * a.W + x_) * a.lddz) + d_ch[k_]; \
+      XD_[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
     }                                                                                               \
   }
 #define WS_SPLIT_STORE(V, DST, CCH)                                                                 \
@@ -384,7 +381,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   // =========================== consumers ===========================
   const int lr = lane & 15, g = lane >> 4;
   const int q = lr >> 2, p4 = lr & 3;
-  const int wn = wave & 1, wm = wave >> 1;
+  const int wn = 0, wm = wave;
+  static_assert(4 * MI * 16 == CI && NI * 16 == CO, "4 consumer waves stacked along ci");
   f32x4 acc[9][MI][NI];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -437,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1][mi], bh[ni], c, 0, 0, 0);
             acc[t][mi][ni] = c;
           }
-        if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 4 * MI * 2, 0);  // DS reads of tap t+1
+        if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 4 * MI, 0);      // DS reads of tap t+1
         __builtin_amdgcn_sched_group_barrier(0x008, 3 * MI * NI, 0);                // MFMAs of tap t
       }
 #undef WS_READ_A
