@@ -431,58 +431,68 @@ __global__ void wgrad_group_sum_kernel(const float* __restrict__ partial, int sp
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int cin_pad,
                                                            int cout_pad, const int* __restrict__ cin_map, int cin_p,
                                                            int cin, int cout, float* __restrict__ dw) {
+  // 8 output channels per pass: a 9 KB LDS tile, so the kernel fits next to the 145-159 KB workgroups of
+  // the persistent convolution kernels it runs beside (side stream) instead of waiting for their CUs
   constexpr int PITCH = 289;  // 32*9 + 1
-  __shared__ float tile[32 * PITCH];
+  constexpr int COB = 8;
+  __shared__ float tile[COB * PITCH];
   const int coTiles = (cout_pad + 31) / 32;  // cin_pad / cout_pad are multiples of 32 or 48
   const int ciT = blockIdx.x / coTiles, coT = blockIdx.x - ciT * coTiles;
-  const int ci0 = ciT * 32, co0 = coT * 32;
+  const int ci0 = ciT * 32;
   const size_t slab4 = (size_t)9 * cin_pad * cout_pad / 4;
-  // the [9][32 ci][32 co] tile = 2304 float4 units, 9 per thread: independent accumulators, so the
-  // loads of all units and slabs are in flight together (the kernel is pure latency otherwise)
-  float4 acc[9];
-  const float4* src[9];
+  for (int pass = 0; pass < 32 / COB; ++pass) {
+    const int co0 = coT * 32 + pass * COB;
+    if (co0 >= cout_pad) break;
+    // the [9][32 ci][8 co] sub-tile = 576 float4 units, up to 3 per thread: independent accumulators,
+    // so the loads of all units and slabs are in flight together (the kernel is pure latency otherwise)
+    float4 acc[3];
+    const float4* src[3];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const int u = threadIdx.x + k * 256;
-    const int row = u >> 3, c4 = u & 7;  // row = tap*32 + ci_local
-    const int tap = row >> 5, cil = row & 31;
-    const bool ok = ci0 + cil < cin_pad && co0 + 4 * c4 < cout_pad;
-    src[k] = ok ? reinterpret_cast<const float4*>(partial + ((size_t)tap * cin_pad + ci0 + cil) * cout_pad + co0 + 4 * c4)
-                : nullptr;
-    acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  for (int sidx = 0; sidx < splits; ++sidx) {
+    for (int k = 0; k < 3; ++k) {
+      const int u = threadIdx.x + k * 256;
+      const int row = u >> 1, c4 = u & 1;  // row = tap*32 + ci_local
+      const int tap = row >> 5, cil = row & 31;
+      const bool ok = u < 576 && ci0 + cil < cin_pad && co0 + 4 * c4 < cout_pad;
+      src[k] = ok ? reinterpret_cast<const float4*>(partial + ((size_t)tap * cin_pad + ci0 + cil) * cout_pad + co0 + 4 * c4)
+                  : nullptr;
+      acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int sidx = 0; sidx < splits; ++sidx) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      if (src[k]) {
-        const float4 v = src[k][(size_t)sidx * slab4];
-        acc[k].x += v.x;
-        acc[k].y += v.y;
-        acc[k].z += v.z;
-        acc[k].w += v.w;
+      for (int k = 0; k < 3; ++k) {
+        if (src[k]) {
+          const float4 v = src[k][(size_t)sidx * slab4];
+          acc[k].x += v.x;
+          acc[k].y += v.y;
+          acc[k].z += v.z;
+          acc[k].w += v.w;
+        }
       }
     }
-  }
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const int u = threadIdx.x + k * 256;
-    const int row = u >> 3, c4 = u & 7;
-    const int tap = row >> 5, cil = row & 31;
-    float* t = tile + (4 * c4) * PITCH + cil * 9 + tap;
-    t[0] = acc[k].x;
-    t[PITCH] = acc[k].y;
-    t[2 * PITCH] = acc[k].z;
-    t[3 * PITCH] = acc[k].w;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 32 * 288; i += 256) {
-    const int co = i / 288, j = i - co * 288;
-    const int cil = j / 9, tap = j - cil * 9;
-    const int cip = ci0 + cil;
-    if (co0 + co >= cout || cip >= cin_p) continue;
-    const int ci = cin_map ? cin_map[cip] : (cip < cin ? cip : -1);
-    if (ci < 0) continue;
-    dw[((size_t)(co0 + co) * cin + ci) * 9 + tap] = tile[co * PITCH + j];
+    for (int k = 0; k < 3; ++k) {
+      const int u = threadIdx.x + k * 256;
+      if (u < 576) {
+        const int row = u >> 1, c4 = u & 1;
+        const int tap = row >> 5, cil = row & 31;
+        float* t = tile + (4 * c4) * PITCH + cil * 9 + tap;
+        t[0] = acc[k].x;
+        t[PITCH] = acc[k].y;
+        t[2 * PITCH] = acc[k].z;
+        t[3 * PITCH] = acc[k].w;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < COB * 288; i += 256) {
+      const int co = i / 288, j = i - co * 288;
+      const int cil = j / 9, tap = j - cil * 9;
+      const int cip = ci0 + cil;
+      if (co0 + co >= cout || cip >= cin_p) continue;
+      const int ci = cin_map ? cin_map[cip] : (cip < cin ? cip : -1);
+      if (ci < 0) continue;
+      dw[((size_t)(co0 + co) * cin + ci) * 9 + tap] = tile[co * PITCH + j];
+    }
+    __syncthreads();
   }
 }
 
