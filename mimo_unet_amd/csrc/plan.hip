@@ -122,11 +122,13 @@ struct mimo_plan {
   double* s_sums = nullptr;
   size_t cap_act = 0, cap_pad = 0, cap_slab = 0, cap_partial = 0, cap_sums = 0;
 
-  // Weight gradients run on a side stream: wgrad(L) (matrix-pipe bound, little HBM traffic) overlaps
-  // the bandwidth-bound BatchNorm / gather kernels and the data gradient of the layers below it on the
-  // caller's stream.  dz ping-pongs between two buffers so that layer L-1 can write its dz while
-  // wgrad(L) still reads the other one.  MIMO_WGRAD_STREAM=0 puts everything back on one stream.
-  bool wg_async = true;
+  // MIMO_WGRAD_STREAM=1: weight gradients on a side stream — wgrad(L) (matrix-pipe bound, little HBM
+  // traffic) overlaps the bandwidth-bound BatchNorm / gather kernels and the data gradient of the layers
+  // below it on the caller's stream; dz ping-pongs between two buffers so that layer L-1 can write its dz
+  // while wgrad(L) still reads the other one.  Off by default: with the persistent one-workgroup-per-CU
+  // convolution kernels the two streams mostly time-share the CUs (measured +0.7 % images/s), and the
+  // per-kernel HIP-event durations the roofline is computed from become overlapped durations.
+  bool wg_async = false;
   hipStream_t wg_stream = nullptr;
   hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
   bool wg_pending[2] = {false, false};
@@ -495,7 +497,7 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&s_dz, cap_act));
     {
       const char* we = getenv("MIMO_WGRAD_STREAM");
-      wg_async = !(we && atoi(we) == 0);
+      wg_async = we && atoi(we) != 0;
       s_dz2[0] = s_dz;
       s_dz2[1] = s_dz;
       if (any_mixed_dz) {

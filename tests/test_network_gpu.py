@@ -429,3 +429,26 @@ def test_staged_backward_equals_monolithic_and_hook_ranges():
     names = dict(model.model.named_parameters())
     enc_numel = sum(p.numel() for n, p in names.items() if n.startswith("encoder."))
     assert enc_numel <= b0 <= enc_numel + 4 * len(names)  # encoder block (+16-byte alignment gaps)
+
+
+@pytest.mark.parametrize("name", ["mini_s2_step.npz", "cfg1_step.npz"])
+def test_side_stream_weight_gradients_match(name, monkeypatch):
+    """MIMO_WGRAD_STREAM=1 (weight gradients on a side stream with ping-pong dz buffers, plain and staged
+    backward) produces bit-identical gradients: same kernels, only the stream they run on changes."""
+    fx = load_npz(name)
+    cfg = cfg_from_meta(fx["meta"])
+    image, label, perms = (torch.from_numpy(fx[f"s0/{k}"]).cuda() for k in ("image", "label", "perms"))
+    grads = []
+    for mode in ("0", "1", "1-staged"):
+        monkeypatch.setenv("MIMO_WGRAD_STREAM", mode[0])
+        model = build_model(cfg, state_from(fx, "init/"))  # the variable is read when the plan is created
+        model.train()
+        if mode.endswith("staged"):
+            model.model.grad_ready_hook = lambda flat, b, e: None
+        for _ in range(2):  # second iteration: buffers of the first one are reused across the stream join
+            model.zero_grad()
+            out = model.training_step_with_perms(image, label, None, perms)
+            out["loss"].backward()
+        torch.cuda.synchronize()
+        grads.append(model.model.flat_gradients().clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
