@@ -357,7 +357,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
 // ---------------------------------------------------------------------------------------
 constexpr int kWsNPix = 256, kWsMaxPix = 360, kWsMF = 4;
 
-template <int NF, bool F16>
+template <int NF, bool F16, bool SWZ>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX,
                                                             int numTiles) {
   typedef typename Elem<F16>::T ET;
@@ -370,9 +370,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
   static_assert(XU % 3 == 0, "input tile staged in three equal parts");
   constexpr int WUNITS = 3 * NB * 8;
   constexpr int WU = (WUNITS + 255) / 256;
-  constexpr int XBYTES = kWsMaxPix * kPitchB, WROWB = 3 * NB * kPitchB;
-  __shared__ __attribute__((aligned(16))) unsigned char xs[2 * XBYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char ws[2 * WROWB];
+  // LDS row = [hi 32 | lo 32] 16-bit values = eight 16-byte slots.  SWZ: 128-byte rows with the slot index
+  // XORed with (row & 7) — ds_read_b128 by 16 consecutive rows is then conflict-free (the 16 lanes of a
+  // read group hit 16 distinct (row parity, slot) pairs = all 64 banks); else 144-byte padded rows, which
+  // are 2-way conflicting on that read (~46 % of the LDS cycles, profiles/r01/final/pmc_SQ_INSTS_LDS.csv).
+  constexpr int PITCH = SWZ ? 128 : kPitchB;
+  constexpr int XBYTES = kWsMaxPix * PITCH, WROWB = 3 * NB * PITCH;
+  __shared__ __attribute__((aligned(128))) unsigned char xs[2 * XBYTES];
+  __shared__ __attribute__((aligned(128))) unsigned char ws[2 * WROWB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -440,7 +445,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     const int p_ = u_ >> 3, q_ = u_ & 7;                                                             \
     if (p_ < npix_lds) {                                                                             \
       const f32x4 v_ = xreg[k_];                                                                     \
-      unsigned char* row_ = xs + (BUF) * XBYTES + p_ * kPitchB;                                      \
+      unsigned char* row_ = xs + (BUF) * XBYTES + p_ * PITCH;                                        \
+      const int sx_ = SWZ ? (p_ & 7) : 0; /* slot XOR of this row */                                 \
       if (F16) {                                                                                     \
         bf16x4 hi_, lo_;                                                                             \
         hi_[0] = (ET)v_[0];                                                                          \
@@ -451,10 +457,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
         lo_[1] = (ET)(v_[1] - (float)hi_[1]);                                                        \
         lo_[2] = (ET)(v_[2] - (float)hi_[2]);                                                        \
         lo_[3] = (ET)(v_[3] - (float)hi_[3]);                                                        \
-        *reinterpret_cast<bf16x4*>(row_ + q_ * 8) = hi_;                                             \
-        *reinterpret_cast<bf16x4*>(row_ + q_ * 8 + 64) = lo_;                                        \
+        *reinterpret_cast<bf16x4*>(row_ + (((q_ >> 1) ^ sx_) << 4) + (q_ & 1) * 8) = hi_;            \
+        *reinterpret_cast<bf16x4*>(row_ + ((((q_ >> 1) + 4) ^ sx_) << 4) + (q_ & 1) * 8) = lo_;      \
       } else {                                                                                       \
-        *reinterpret_cast<f32x4*>(row_ + q_ * 16) = v_;                                              \
+        *reinterpret_cast<f32x4*>(row_ + ((q_ ^ sx_) << 4)) = v_;                                    \
       }                                                                                              \
     }                                                                                                \
   }
@@ -476,7 +482,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     if (u_ < WUNITS) {                                                                               \
       const int t_ = u_ / (NB * 8);                                                                  \
       const int rem_ = u_ - t_ * (NB * 8);                                                           \
-      *reinterpret_cast<u32x4*>(ws + (BUF) * WROWB + (t_ * NB + (rem_ >> 3)) * kPitchB + (rem_ & 7) * 16) = wreg[SLOT][k_]; \
+      const int wrow_ = t_ * NB + (rem_ >> 3);                                                       \
+      *reinterpret_cast<u32x4*>(ws + (BUF) * WROWB + wrow_ * PITCH + (((rem_ & 7) ^ (SWZ ? (wrow_ & 7) : 0)) << 4)) = wreg[SLOT][k_]; \
     }                                                                                                \
   }
     const int nphases = 3 * nstages;
@@ -529,9 +536,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     int idx = (wave * MF + m) * 16 + lr;
     if (idx >= npix_out) idx = 0;
     const int r = idx / TC, c = idx - r * TC;
-    pbase[m] = (r * TCP + c) * kPitchB + g * 16;
+    pbase[m] = SWZ ? r * TCP + c : (r * TCP + c) * PITCH + g * 16;  // SWZ: tile row index; else byte offset
   }
-  const int wbase = lr * kPitchB + g * 16;
+  // weight rows: row & 7 == lr & 7 (row = tap * NB + nf * 16 + lr), so the swizzle is a per-lane constant;
+  // the lo half is slot + 4, i.e. the hi address with bit 6 flipped
+  const int wbase = SWZ ? lr * PITCH + ((g ^ (lr & 7)) << 4) : lr * PITCH + g * 16;
+  const int wlo = SWZ ? ((wbase ^ 64) - wbase) : 64;
   float bv[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) bv[nf] = a.bias ? a.bias[co0 + nf * 16 + lr] : 0.f;
@@ -551,14 +561,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
 
 #define C_READ_B(BS, KW)                                                                             \
   _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
-    bh[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * kPitchB);            \
-    bl[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * kPitchB + 64);       \
+    bh[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * PITCH);              \
+    bl[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * PITCH + wlo);        \
   }
 #define C_READ_A(AS, KW, M)                                                                          \
   {                                                                                                  \
-    const unsigned char* p_ = xb_ + pbase[M] + (r_ * TCP + (KW)) * kPitchB;                          \
-    ah[AS] = *reinterpret_cast<const bf16x8*>(p_);                                                   \
-    al[AS] = *reinterpret_cast<const bf16x8*>(p_ + 64);                                              \
+    if (SWZ) {                                                                                       \
+      const int row_ = pbase[M] + r_ * TCP + (KW);                                                   \
+      const int o_ = row_ * PITCH + ((g ^ (row_ & 7)) << 4);                                         \
+      ah[AS] = *reinterpret_cast<const bf16x8*>(xb_ + o_);                                           \
+      al[AS] = *reinterpret_cast<const bf16x8*>(xb_ + (o_ ^ 64));                                    \
+    } else {                                                                                         \
+      const unsigned char* p_ = xb_ + pbase[M] + (r_ * TCP + (KW)) * PITCH;                          \
+      ah[AS] = *reinterpret_cast<const bf16x8*>(p_);                                                 \
+      al[AS] = *reinterpret_cast<const bf16x8*>(p_ + 64);                                            \
+    }                                                                                                \
   }
 #define C_MFMA(AS, BS, M)                                                                            \
   _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
@@ -714,7 +731,13 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   const int per = ceil_div(numTiles, gx);
   gx = ceil_div(numTiles, per);
   dim3 grid(gx, coTiles);
-  hipLaunchKernelGGL((conv3x3_ws_kernel<NF, F16>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles);
+  // conflict-free swizzled rows measured the same step time as the padded rows (6.97 / 7.20 vs 6.89 / 7.20 ms
+  // forward / data gradient per step): the LDS array is not what the consumers wait for.  Opt-in.
+  static const bool swz = getenv("MIMO_CONV_WS_SWIZZLE") && atoi(getenv("MIMO_CONV_WS_SWIZZLE")) != 0;
+  if (swz)
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, F16, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles);
+  else
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, F16, false>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
