@@ -49,6 +49,22 @@ def make_model(c):
                          loss_buffer_size=10, loss_buffer_temperature=0.3)
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of a kernel class from the committed counter passes of this same command
+    (profiles/<round>/final/pmc_traffic.json, written from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs —
+    counters cannot be collected from inside the timed run).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "final", "pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as fh:
+            t = json.load(fh)
+        return int(t["classes"][kernel_class]["bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def cpu_baseline(c, batch=4, steps=2, threads=None):
     """The CPU oracle (restatement of the reference's step, pinned to reference goldens) on the
     host cores of this box: same network shape, bounded sample.  Thread count: torch's CPU
@@ -167,12 +183,15 @@ def main():
         sec = r["ms"] * 1e-3
         kernels[name] = {"avg_us": round(r["ms"] * 1e3 / r["launches"], 2), "launches_per_step": r["launches"] // args.steps,
                          "ms_per_step": round(r["ms"] / args.steps, 3), "tflops": round(r["flops"] / sec / 1e12, 2),
-                         "algorithmic_gbs": round(r["bytes"] / sec / 1e9, 1)}
+                         "algorithmic_gbs": round(r["bytes"] / sec / 1e9, 1),
+                         "algorithmic_bytes_per_launch": int(r["bytes"] / r["launches"])}
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     precision = os.environ.get("MIMO_PRECISION", "split16")
     peak = FP32_MFMA_PEAK_TFLOPS if precision == "fp32" else SPLIT16_PEAK_TFLOPS
+    traffic, traffic_src = pmc_traffic(dom) if (args.config == "cfg3" and precision == "split16") else (None, None)
     roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                 "arithmetic": ("f32-input MFMA" if precision == "fp32" else
                                "3x 16-bit MFMA per product (fp16 hi/lo forward, bf16 hi/lo gradients), fp32 accumulate; "
                                "peak = 2500 TFLOP/s dense 16-bit MFMA / 3"),
