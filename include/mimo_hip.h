@@ -98,6 +98,16 @@ typedef struct mimo_forward_args {
    *   [0]     center_dropout (model.py:213)        [N][8fS][H/16][W/16]  on down4's output
    *   [1 + s] final_dropouts[s] (model.py:277-281) [N][f][H][W]          in front of head s   */
   const float* const* elem_masks;
+  /* Inference fast path (no reference counterpart; what `torch.no_grad()` + `model.eval()` buys the
+   * reference is only skipped autograd bookkeeping):
+   *   no_grad != 0 with training == 0: no backward will follow this forward — eval-mode BatchNorm +
+   *     ReLU (+ Dropout2d multipliers) are folded into the convolution epilogue and the pre-activation
+   *     tensors are not stored; mimo_backward after such a forward fails with MIMO_ERR_STATE.
+   *   param_version: any value that changes whenever the bound parameters or BatchNorm buffers may have
+   *     changed (0 = unknown: re-derive everything).  While it stays the same, eval-mode forwards reuse
+   *     the packed weight copies and BatchNorm scale/shift of the previous call. */
+  int32_t no_grad;
+  int64_t param_version;
 } mimo_forward_args;
 int mimo_plan_num_double_convs(const mimo_plan* plan);
 int mimo_plan_double_conv_channels(const mimo_plan* plan, int index); /* Cout of DoubleConv #index */

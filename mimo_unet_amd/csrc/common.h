@@ -49,6 +49,12 @@ struct ConvLaunch {
   int N, Hi, Wi, ldx, cin_p;
   int Ho, Wo, ldy, cout_pad, cout_store;
   int off;
+  // inference epilogue (all null = plain conv output): y = relu(conv * ep_scale[c] + ep_shift[c]) * ep_mask[n][c]
+  // — eval-mode BatchNorm + ReLU (+ Dropout2d multipliers, [N][ep_mask_ld]) folded into the store
+  const float* ep_scale = nullptr;
+  const float* ep_shift = nullptr;
+  const float* ep_mask = nullptr;
+  int ep_mask_ld = 0;
 };
 // returns number of partial-stat rows (spatial blocks) through *rows when stats != nullptr
 int conv3x3_launch(const ConvLaunch& a, int* rows, hipStream_t stream);

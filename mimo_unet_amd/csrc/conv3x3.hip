@@ -182,12 +182,15 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvLaunch a, int TR,
   }
 
   // ---- epilogue: bias, store, per-channel sum / sum-of-squares for BatchNorm -------------
-  float bv[NFRAG], s1[NFRAG], s2[NFRAG];
+  float bv[NFRAG], s1[NFRAG], s2[NFRAG], esc[NFRAG], esh[NFRAG], emk[NFRAG];
 #pragma unroll
   for (int nf = 0; nf < NFRAG; ++nf) {
     bv[nf] = a.bias ? a.bias[co0 + nf * 16 + lr] : 0.f;
     s1[nf] = 0.f;
     s2[nf] = 0.f;
+    esc[nf] = a.ep_scale ? a.ep_scale[co0 + nf * 16 + lr] : 1.f;
+    esh[nf] = a.ep_scale ? a.ep_shift[co0 + nf * 16 + lr] : 0.f;
+    emk[nf] = (a.ep_mask && co0 + nf * 16 + lr < a.ep_mask_ld) ? a.ep_mask[(size_t)n * a.ep_mask_ld + co0 + nf * 16 + lr] : 1.f;
   }
   float* yimg = a.y + (size_t)n * a.Ho * a.Wo * a.ldy;
 #pragma unroll
@@ -202,7 +205,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvLaunch a, int TR,
         float* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy + co0 + lr;
 #pragma unroll
         for (int nf = 0; nf < NFRAG; ++nf) {
-          const float v = acc[m][nf][r4] + bv[nf];
+          float v = acc[m][nf][r4] + bv[nf];
+          if (a.ep_scale) v = fmaxf(fmaf(v, esc[nf], esh[nf]), 0.f) * emk[nf];
           if (co0 + nf * 16 + lr < a.cout_store) yp[nf * 16] = v;
           s1[nf] += v;
           s2[nf] += v * v;

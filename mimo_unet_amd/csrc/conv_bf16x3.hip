@@ -282,12 +282,15 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
   }
 
   // ---- epilogue: bias, store, BatchNorm partial sums -----------------------------------------
-  float bv[NF], s1[NF], s2[NF];
+  float bv[NF], s1[NF], s2[NF], esc[NF], esh[NF], emk[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
     bv[nf] = a.bias ? a.bias[co0 + nf * 16 + lr] : 0.f;
     s1[nf] = 0.f;
     s2[nf] = 0.f;
+    esc[nf] = a.ep_scale ? a.ep_scale[co0 + nf * 16 + lr] : 1.f;
+    esh[nf] = a.ep_scale ? a.ep_shift[co0 + nf * 16 + lr] : 0.f;
+    emk[nf] = (a.ep_mask && co0 + nf * 16 + lr < a.ep_mask_ld) ? a.ep_mask[(size_t)n * a.ep_mask_ld + co0 + nf * 16 + lr] : 1.f;
   }
   float* yimg = a.y + (size_t)n * a.Ho * a.Wo * a.ldy;
 #pragma unroll
@@ -301,7 +304,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
         float* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy + co0 + lr;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
-          const float v = acc[m][nf][r4] * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];
+          float v = acc[m][nf][r4] * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];
+          if (a.ep_scale) v = fmaxf(fmaf(v, esc[nf], esh[nf]), 0.f) * emk[nf];
           if (co0 + nf * 16 + lr < a.cout_store) yp[nf * 16] = v;
           s1[nf] += v;
           s2[nf] += v * v;
@@ -542,9 +546,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
   // the lo half is slot + 4, i.e. the hi address with bit 6 flipped
   const int wbase = SWZ ? lr * PITCH + ((g ^ (lr & 7)) << 4) : lr * PITCH + g * 16;
   const int wlo = SWZ ? ((wbase ^ 64) - wbase) : 64;
-  float bv[NF];
+  float bv[NF], esc[NF], esh[NF];
 #pragma unroll
-  for (int nf = 0; nf < NF; ++nf) bv[nf] = a.bias ? a.bias[co0 + nf * 16 + lr] : 0.f;
+  for (int nf = 0; nf < NF; ++nf) {
+    bv[nf] = a.bias ? a.bias[co0 + nf * 16 + lr] : 0.f;
+    esc[nf] = a.ep_scale ? a.ep_scale[co0 + nf * 16 + lr] : 1.f;
+    esh[nf] = a.ep_scale ? a.ep_shift[co0 + nf * 16 + lr] : 0.f;
+  }
   const int nphases = 3 * nstages;
 
   f32x4 acc[MF][NF];
@@ -626,6 +634,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
       s2[nf] = 0.f;                                                                                  \
     }                                                                                                \
     float* yimg = a.y + (size_t)n_ * a.Ho * a.Wo * a.ldy;                                            \
+    float emk[NF];                                                                                   \
+    _Pragma("unroll") for (int nf = 0; nf < NF; ++nf)                                                \
+      emk[nf] = (a.ep_mask && co0 + nf * 16 + lr < a.ep_mask_ld)                                     \
+                    ? a.ep_mask[(size_t)n_ * a.ep_mask_ld + co0 + nf * 16 + lr] : 1.f;               \
     _Pragma("unroll") for (int m = 0; m < MF; ++m) {                                                 \
       _Pragma("unroll") for (int r4 = 0; r4 < 4; ++r4) {                                             \
         const int idx = (wave * MF + m) * 16 + g * 4 + r4;                                           \
@@ -634,7 +646,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
         if (idx < npix_out && oy < a.Ho && ox < a.Wo) {                                              \
           float* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy + co0 + lr;                            \
           _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                        \
-            const float v = acc[m][nf][r4] * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];           \
+            float v = acc[m][nf][r4] * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];                 \
+            if (a.ep_scale) v = fmaxf(fmaf(v, esc[nf], esh[nf]), 0.f) * emk[nf];                     \
             if (co0 + nf * 16 + lr < a.cout_store) yp[nf * 16] = v;                                  \
             s1[nf] += v;                                                                             \
             s2[nf] += v * v;                                                                         \

@@ -198,6 +198,10 @@ struct mimo_plan {
 
   // per-call state
   bool fwd_done = false, fwd_training = false, had_perm = false, loss_done = false, bwd_stage0_done = false;
+  bool fwd_no_grad = false;       // last forward folded BN/ReLU into the conv epilogue: nothing saved for a backward
+  int64_t derived_version = -1;   // param_version the packed weights / eval scale+shift were derived from (-1: none)
+  bool derived_dgrad = false;     // ... including the data-gradient weight copies
+  bool need_derive = true;        // per-call: (re)pack weights and eval BN constants in this forward
   int64_t encoder_param_floats = 0;
   float* out = nullptr;
   const float *label = nullptr, *lmask = nullptr;
@@ -549,9 +553,19 @@ struct mimo_plan {
   }
 
   int convbn_forward(ConvBN& L, bool training, const float* mask, hipStream_t st) {
+    const bool fused = fwd_no_grad;  // inference: BN(eval) + ReLU (+ channel-dropout) in the conv epilogue
+    if (!training && need_derive)
+      MIMO_TRY(bn_eval_prepare_launch(L.Cout, L.cout_p, params + L.off_gamma, params + L.off_beta, bnbuf + L.off_rm,
+                                      bnbuf + L.off_rv, cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
     ConvLaunch a;
     a.x = L.in;
-    a.y = L.z;
+    a.y = fused ? L.a : L.z;
+    if (fused) {
+      a.ep_scale = L.scale;
+      a.ep_shift = L.shift;
+      a.ep_mask = mask;
+      a.ep_mask_ld = L.Cout;
+    }
     a.w = L.wf;
     a.bias = L.bias_p;
     a.stats = training ? s_partial : nullptr;
@@ -560,7 +574,7 @@ struct mimo_plan {
     a.Wi = a.Wo = L.W;
     a.ldx = L.ld_in;
     a.cin_p = L.cin_p;
-    a.ldy = L.cout_p;
+    a.ldy = fused ? L.ld_a : L.cout_p;
     a.cout_pad = L.cout_pad;
     a.cout_store = L.cout_p;
     a.off = 1;
@@ -579,11 +593,9 @@ struct mimo_plan {
       MIMO_TRY(bn_fwd_finalize_launch(s_sums, chunks, L.cout_pad, L.Cout, L.cout_p, P, params + L.off_gamma,
                                       params + L.off_beta, bnbuf + L.off_rm, bnbuf + L.off_rv, cfg.bn_momentum,
                                       cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
-    } else {
-      MIMO_TRY(bn_eval_prepare_launch(L.Cout, L.cout_p, params + L.off_gamma, params + L.off_beta, bnbuf + L.off_rm,
-                                      bnbuf + L.off_rv, cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
     }
-    MIMO_TRY(bn_relu_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, P, L.H * L.W, st));
+    if (!fused)
+      MIMO_TRY(bn_relu_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, P, L.H * L.W, st));
     return MIMO_OK;
   }
 
@@ -596,8 +608,10 @@ struct mimo_plan {
       Act *sk = dc->src0, *lo = dc->src1;
       MIMO_TRY(upcat_fwd_launch(sk->a, sk->ld, sk->Cp, lo->a, lo->ld, lo->Cp, N, h, w, lo->H, lo->W, dc->in_buf, st));
     }
-    MIMO_TRY(pack_layer(dc->c1, training, st));
-    MIMO_TRY(pack_layer(dc->c2, training, st));
+    if (need_derive) {
+      MIMO_TRY(pack_layer(dc->c1, training, st));
+      MIMO_TRY(pack_layer(dc->c2, training, st));
+    }
     MIMO_TRY(convbn_forward(dc->c1, training, nullptr, st));
     MIMO_TRY(convbn_forward(dc->c2, training, dc->mask, st));
     return MIMO_OK;
@@ -612,12 +626,21 @@ struct mimo_plan {
       set_error("mimo_forward: null argument");
       return MIMO_ERR_INVALID;
     }
+    // what has to be (re)derived from the parameters in this call, and whether anything is kept for a backward
+    const bool training_call = args->training != 0;
+    fwd_no_grad = !training_call && args->no_grad != 0;
+    need_derive = training_call || args->param_version == 0 || args->param_version != derived_version;
+    const int64_t version_after = training_call ? -1 : (args->param_version != 0 ? args->param_version : -1);
     const int64_t img = (int64_t)Ci * H * W;
     const bool x5 = args->stride_s == img && args->stride_n == (int64_t)S * img;
     const bool x4 = args->stride_s == 0 && args->stride_n == img;
-    if (!graph_enabled || args->training || prof_on || !(x5 || x4) || args->elem_masks) return forward_impl(args, st);
+    if (!graph_enabled || args->training || prof_on || !(x5 || x4) || args->elem_masks || need_derive) {
+      const int rc = forward_impl(args, st);
+      derived_version = rc == MIMO_OK ? version_after : -1;
+      return rc;
+    }
     // ---- stage the caller's tensors, (re)capture if the call shape changed, replay ----
-    uint64_t key = 1 | (x5 ? 2 : 0) | (args->perm ? 4 : 0);
+    uint64_t key = 1 | (x5 ? 2 : 0) | (args->perm ? 4 : 0) | (fwd_no_grad ? 8 : 0);
     for (size_t i = 0; i < dcs.size(); ++i)
       if (args->drop_masks && args->drop_masks[i]) key |= 1ull << (8 + i);
     MIMO_HIP_CHECK(hipMemcpyAsync(g_x, args->x, (size_t)N * (x5 ? S : 1) * img * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -861,6 +884,10 @@ struct mimo_plan {
       set_error("mimo_backward: gradient buffer not bound");
       return MIMO_ERR_STATE;
     }
+    if (fwd_no_grad) {
+      set_error("mimo_backward: the last forward ran with no_grad (inference epilogue, nothing saved)");
+      return MIMO_ERR_STATE;
+    }
     if (!dout && !dloss) {
       set_error("mimo_backward: need dout and/or dloss");
       return MIMO_ERR_INVALID;
@@ -987,6 +1014,7 @@ int mimo_plan_bind(mimo_plan* plan, float* params, float* grads, float* bn_buffe
     set_error("mimo_plan_bind: null argument");
     return MIMO_ERR_INVALID;
   }
+  if (plan->params != params || plan->bnbuf != bn_buffers) plan->derived_version = -1;  // other tensors: re-derive
   plan->params = params;
   plan->grads = grads;
   plan->bnbuf = bn_buffers;

@@ -101,10 +101,14 @@ class Plan:
 
     def forward(self, x: torch.Tensor, out: torch.Tensor, *, training: bool, perm: Optional[torch.Tensor] = None,
                 masks: Optional[Sequence[Optional[torch.Tensor]]] = None, broadcast_subnetworks: bool = False,
-                elem_masks: Optional[Sequence[Optional[torch.Tensor]]] = None) -> None:
+                elem_masks: Optional[Sequence[Optional[torch.Tensor]]] = None, no_grad: bool = False,
+                param_version: int = 0) -> None:
         """x: [N,S,Ci,H,W] (or [N,Ci,H,W] with perm / broadcast) contiguous fp32 on the plan's device.
         masks: per DoubleConv [N,C] Dropout2d multipliers; elem_masks: [center, final_0 .. final_{S-1}]
-        full-shape nn.Dropout multipliers (NCHW, fp32, contiguous) or None entries."""
+        full-shape nn.Dropout multipliers (NCHW, fp32, contiguous) or None entries.
+        no_grad (eval mode only): no backward follows — BatchNorm/ReLU run in the conv epilogue.
+        param_version: changes whenever parameters / BN buffers may have changed (0 = unknown); equal
+        versions let eval-mode calls reuse the packed weights of the previous call."""
         g = self.geom
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         if x.dim() == 5:
@@ -124,7 +128,8 @@ class Plan:
             elem_arr = (C.c_void_p * len(elem_masks))(*[L.ptr(m) or None for m in elem_masks])
         args = L.ForwardArgs(x.data_ptr(), stride_n, stride_s, L.ptr(perm) or None, int(training),
                              C.cast(mask_arr, C.POINTER(C.c_void_p)) if mask_arr is not None else None, out.data_ptr(),
-                             C.cast(elem_arr, C.POINTER(C.c_void_p)) if elem_arr is not None else None)
+                             C.cast(elem_arr, C.POINTER(C.c_void_p)) if elem_arr is not None else None,
+                             int(bool(no_grad) and not training), int(param_version))
         L.check(self.lib.mimo_forward(self.handle, C.byref(args), L.current_stream()), "mimo_forward")
 
     def loss_forward(self, label: torch.Tensor, mask: Optional[torch.Tensor], perm: Optional[torch.Tensor],

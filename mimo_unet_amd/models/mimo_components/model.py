@@ -183,6 +183,10 @@ class MimoUNet(nn.Module):
         self.elem_mask_override: Optional[Dict[str, torch.Tensor]] = None
         # called as hook(flat_grads, begin, end) when gradients [begin, end) are final (see ddp.FlatGradientAllReducer)
         self.grad_ready_hook = None
+        # bumped by everything that rewrites the flat parameter / buffer storage behind torch's back
+        # (FlatAdam's HIP kernel, the engine's running-stat update); together with the tensors' own
+        # torch version counters it forms mimo_forward_args.param_version
+        self._param_epoch = 1
 
     # ---- execution order of the DoubleConvs == mimo_plan's (engine) order -----------------
     def double_convs(self) -> List[DoubleConv]:
@@ -303,10 +307,22 @@ class MimoUNet(nn.Module):
         masks = self._dropout_masks(n, x.device)
         elem_masks = self._elem_dropout_masks(n, x.shape[-2], x.shape[-1], x.device)
         # make sure the flat storage exists before the parameters are handed to autograd
-        self._plan_for(x, perm)
+        plan = self._plan_for(x, perm)
+        if not bn_training and label is None and not torch.is_grad_enabled():
+            # inference (eval mode under torch.no_grad()): no autograd node, BatchNorm + ReLU folded into the
+            # convolution epilogue, packed weights reused while the parameters have not changed
+            out = torch.empty(n, self.num_subnetworks, self.out_channels, plan.height, plan.width, device=x.device,
+                              dtype=torch.float32)
+            plan.bind(self._flat_params, self._flat_grads, self._flat_buffers)
+            plan.forward(x, out, training=False, perm=perm, masks=masks, elem_masks=elem_masks, no_grad=True,
+                         param_version=self._param_version())
+            plan.generation += 1
+            self._inference_keep = (x, perm, masks, elem_masks)  # the plan still points at the mask tensors
+            return out, torch.zeros(0, device=x.device, dtype=torch.float32)
         out, loss = _NetFunction.apply(self, x, label, lmask, perm, masks, bn_training, elem_masks, *self._param_list)
         if bn_training:
             self._bump_batch_counters()
+            self._param_epoch += 1  # the engine updated the running statistics in place
         return out, loss
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -350,6 +366,15 @@ class MimoUNet(nn.Module):
                 v.add_(saved[off: off + v.numel()].view(v.shape))
             else:
                 p.grad.add_(v)
+
+    def mark_parameters_changed(self) -> None:
+        """Call after writing the flat parameter / buffer storage through a raw pointer."""
+        self._param_epoch += 1
+
+    def _param_version(self) -> int:
+        if self._flat_params is None:
+            return 0
+        return (self._param_epoch << 40) + (self._flat_params._version << 20) + self._flat_buffers._version + 1
 
     # flat views for the fused optimiser / gradient all-reduce
     def flat_parameters(self) -> torch.Tensor:

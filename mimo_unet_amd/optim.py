@@ -36,6 +36,8 @@ class FlatAdam(torch.optim.Optimizer):
         self._step += 1
         adam_step(p, g, self._m, self._v, lr=float(grp["lr"]), betas=grp["betas"], eps=grp["eps"],
                   weight_decay=grp["weight_decay"], step=self._step, grad_scale=self.grad_scale)
+        if hasattr(self.net, "mark_parameters_changed"):
+            self.net.mark_parameters_changed()  # the kernel wrote the parameters through a raw pointer
         return loss
 
     def zero_grad(self, set_to_none: bool = True):

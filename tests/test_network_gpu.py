@@ -452,3 +452,59 @@ def test_side_stream_weight_gradients_match(name, monkeypatch):
         torch.cuda.synchronize()
         grads.append(model.model.flat_gradients().clone())
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+def test_inference_path_matches_eval_forward_and_tracks_parameter_changes():
+    """Eval mode under torch.no_grad() takes the inference path (BatchNorm + ReLU + Dropout2d multipliers
+    in the convolution epilogue, packed weights cached on the parameter version): bit-identical to the
+    grad-enabled eval forward, and never stale after an optimiser step, a training forward (running
+    statistics) or load_state_dict."""
+    fx = load_npz("mc_dropout.npz")
+    Ci, Co, S, f, N, H, W, passes = (int(v) for v in fx["meta"])
+    p = float(fx["p"])
+    cfg = O.NetConfig(Ci, Co, S, f)
+    state = state_from(fx, "state/")
+    model = build_model(cfg, state, dropout=(p, p, p))
+    model.eval()
+    x = repeat_sub(torch.from_numpy(fx["x"]).cuda(), S)
+    prefixes = [s[0] for s in O.double_conv_specs(cfg)]
+    model.model.mask_override = {j: torch.from_numpy(fx[f"pass0/mask{j}"]) for j in range(len(prefixes))}
+
+    def both():
+        a1, a2 = model(x)                      # autograd-capable eval forward (z kept, separate BN/ReLU pass)
+        with torch.no_grad():
+            b1, b2 = model(x)                  # inference path
+            c1, c2 = model(x)                  # again: cached weights / graph replay
+        assert torch.equal(a1, b1) and torch.equal(a2, b2) and torch.equal(b1, c1) and torch.equal(b2, c2)
+        return b1.clone()
+
+    r0 = both()
+    assert rel_err(r0.cpu(), fx["p1"][:, :S]) < TOL                      # pass 0 of the golden ensemble
+    # optimiser step through the raw-pointer kernel
+    model.train()
+    opt = model.configure_optimizers()["optimizer"]
+    y = torch.rand(N, S, Co // 2, H, W, device="cuda")
+    p1, p2 = model(x)
+    model.loss_fn.forward(p1, p2, y).backward()
+    opt.step()
+    model.eval()
+    r1 = both()
+    assert not torch.equal(r0, r1)
+    fresh = build_model(cfg, {k[len("model."):]: v for k, v in model.state_dict().items()}, dropout=(p, p, p))
+    fresh.eval()
+    fresh.model.mask_override = model.model.mask_override
+    with torch.no_grad():
+        f1, _ = fresh(x)
+    assert torch.equal(f1, r1)
+    # load_state_dict back to the original weights
+    model.load_state_dict({"model." + k: v for k, v in state.items()})
+    assert torch.equal(both(), r0)
+    # backward after an inference forward is refused, after a grad-enabled eval forward it works
+    xg = x.clone().requires_grad_(True)
+    q1, q2 = model(xg)
+    (q1.sum() + q2.sum()).backward()
+    assert torch.isfinite(xg.grad).all()
+
+
+def repeat_sub(x, S):
+    return x[:, None].repeat(1, S, 1, 1, 1).contiguous()
