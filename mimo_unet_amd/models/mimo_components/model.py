@@ -260,18 +260,42 @@ class MimoUNet(nn.Module):
 
     # ---- dropout masks (Dropout2d: one Bernoulli per (sample, channel), components.py:29) --
     def _dropout_masks(self, n: int, device) -> Optional[List[Optional[torch.Tensor]]]:
-        masks, any_mask = [], False
-        for i, dc in enumerate(self.double_convs()):
-            d = dc.dropout
-            m = None
-            if self.mask_override is not None and i in self.mask_override:
-                m = self.mask_override[i].to(device=device, dtype=torch.float32).contiguous()
-            elif d.p > 0.0 and d.training:
-                c = dc.double_conv[3].out_channels
-                m = torch.bernoulli(torch.full((n, c), 1.0 - d.p, device=device)).div_(1.0 - d.p)
-            any_mask |= m is not None
-            masks.append(m)
-        return masks if any_mask else None
+        dcs = self.double_convs()
+        if self.mask_override is not None:
+            masks, any_mask = [], False
+            for i, dc in enumerate(dcs):
+                d = dc.dropout
+                m = None
+                if i in self.mask_override:
+                    m = self.mask_override[i].to(device=device, dtype=torch.float32).contiguous()
+                elif d.p > 0.0 and d.training:
+                    c = dc.double_conv[3].out_channels
+                    m = torch.bernoulli(torch.full((n, c), 1.0 - d.p, device=device)).div_(1.0 - d.p)
+                any_mask |= m is not None
+                masks.append(m)
+            return masks if any_mask else None
+        # all sites in two launches: one Bernoulli draw over a flat [site][n][C] buffer with per-element keep
+        # probabilities, one multiply by 1/(1-p); the per-site masks are contiguous views of it
+        active = tuple((dc.dropout.p if dc.dropout.training else 0.0) for dc in dcs)
+        if not any(p > 0.0 for p in active):
+            return None
+        key = (n, str(device), active)
+        cache = getattr(self, "_mask_plan", None)
+        if cache is None or cache[0] != key:
+            chans = [dc.double_conv[3].out_channels for dc in dcs]
+            offs, total = [], 0
+            for c, p in zip(chans, active):
+                offs.append(total if p > 0.0 else -1)
+                total += n * c if p > 0.0 else 0
+            keep = torch.empty(total, device=device, dtype=torch.float32)
+            for c, p, o in zip(chans, active, offs):
+                if o >= 0:
+                    keep[o: o + n * c] = 1.0 - p
+            cache = (key, keep, 1.0 / keep, offs, chans)
+            self._mask_plan = cache
+        _, keep, inv_keep, offs, chans = cache
+        flat = torch.bernoulli(keep).mul_(inv_keep)
+        return [flat[o: o + n * c].view(n, c) if o >= 0 else None for o, c in zip(offs, chans)]
 
     # ---- element-wise dropout (nn.Dropout: center after down4, final in front of each head) ----
     def _elem_dropout_masks(self, n: int, h: int, w: int, device) -> Optional[List[Optional[torch.Tensor]]]:
