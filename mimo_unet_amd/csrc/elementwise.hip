@@ -68,18 +68,51 @@ __device__ __forceinline__ float4 quad_block_sum(float4 v, const PQ& t, float4* 
 // gradient on the reflect-padded domain folded back onto the image (transpose of reflect pad):
 // pad row -1 lands on row 1, pad row H on row H-2 (same for columns).
 __device__ __forceinline__ float4 fold_read(const float* dxpad, int ldp, int n, int y, int x, int H, int W, int ch) {
-  int ry[3], rx[3], ny = 1, nx = 1;
-  ry[0] = y;
-  rx[0] = x;
-  if (y == 1) ry[ny++] = -1;
-  if (y == H - 2) ry[ny++] = H;
-  if (x == 1) rx[nx++] = -1;
-  if (x == W - 2) rx[nx++] = W;
-  float4 s = f4zero();
   const float* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + ch;
-  for (int i = 0; i < ny; ++i)
-    for (int j = 0; j < nx; ++j) s = f4add(s, ld4(base + ((size_t)(ry[i] + 1) * (W + 2) + (rx[j] + 1)) * ldp));
+  float4 s = ld4(base + ((size_t)(y + 1) * (W + 2) + (x + 1)) * ldp);  // interior pixels: this one load
+  const bool ya = y == 1, yb = y == H - 2, xa = x == 1, xb = x == W - 2;
+  if (ya | yb | xa | xb) {  // rows 1 / H-2 and columns 1 / W-2 also receive the reflected border
+    const int ry[3] = {y, -1, H}, rx[3] = {x, -1, W};
+    const bool vy[3] = {true, ya, yb}, vx[3] = {true, xa, xb};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (i + j > 0 && vy[i] && vx[j]) s = f4add(s, ld4(base + ((size_t)(ry[i] + 1) * (W + 2) + (rx[j] + 1)) * ldp));
+  }
   return s;
+}
+
+// (n, y, x) of a pixel index that advances by a fixed stride: two integer divisions once per thread
+// instead of two per visited pixel (they cost more VALU than the 48-64 bytes the pixel moves)
+struct PixIter {
+  int n, y, x, dn, dy, dx;
+};
+__device__ __forceinline__ PixIter pix_iter(int p0, int pstep, int H, int W) {
+  PixIter it;
+  const int HW = H * W;
+  it.n = p0 / HW;
+  int r = p0 - it.n * HW;
+  it.y = r / W;
+  it.x = r - it.y * W;
+  it.dn = pstep / HW;
+  r = pstep - it.dn * HW;
+  it.dy = r / W;
+  it.dx = r - it.dy * W;
+  return it;
+}
+__device__ __forceinline__ void pix_next(PixIter& it, int H, int W) {
+  it.x += it.dx;
+  it.y += it.dy;
+  it.n += it.dn;
+  if (it.x >= W) {
+    it.x -= W;
+    ++it.y;
+  }
+  if (it.y >= H) {
+    it.y -= H;
+    ++it.n;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -446,11 +479,9 @@ __global__ void fold_slice_kernel(const float* __restrict__ dxpad, int ldp, int 
   const PQ t = pixquad(Cv);
   if (!t.active) return;
   const int P = N * H * W;
-  for (int p = t.p; p < P; p += t.pstep) {
-    const int n = p / (H * W);
-    const int r = p - n * H * W;
-    const int y = r / W, x = r - y * W;
-    float4 v = fold_read(dxpad, ldp, n, y, x, H, W, choff + 4 * t.q);
+  PixIter it = pix_iter(t.p, t.pstep, H, W);
+  for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
+    float4 v = fold_read(dxpad, ldp, it.n, it.y, it.x, H, W, choff + 4 * t.q);
     float* dst = da + (size_t)p * ldda + 4 * t.q;
     if (accumulate) v = f4add(v, ld4(dst));
     st4(dst, v);
@@ -549,15 +580,13 @@ int up_bwd_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, i
 // dy = (gradient arriving at the activation) * dropout mask * [relu input > 0], evaluated on the fly by
 // both passes (never stored): the source is a plain NHWC buffer or the padded-domain dgrad output
 __device__ __forceinline__ float4 relu_grad4(const float* da, int ldda, const float* dxpad, int ldp, const float* mask, int C,
-                                             int p, int q, int H, int W, float4 v, float4 sc, float4 sh) {
+                                             int p, const PixIter& it, int q, int H, int W, float4 v, float4 sc, float4 sh) {
   float4 g;
-  const int n = p / (H * W);
+  const int n = it.n;
   if (da) {
     g = ld4(da + (size_t)p * ldda + 4 * q);
   } else {
-    const int r = p - n * H * W;
-    const int y = r / W, x = r - y * W;
-    g = fold_read(dxpad, ldp, n, y, x, H, W, 4 * q);
+    g = fold_read(dxpad, ldp, n, it.y, it.x, H, W, 4 * q);
   }
   if (mask) {
     const float4 m = mask4(mask, n, C, 4 * q);
@@ -585,9 +614,10 @@ __global__ void bnrelu_bwd_reduce_kernel(const float* __restrict__ da, int ldda,
   if (t.active) {
     const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q), mu = ld4(mean + 4 * t.q), is = ld4(invstd + 4 * t.q);
     const int P = N * H * W;
-    for (int p = t.p; p < P; p += t.pstep) {
+    PixIter it = pix_iter(t.p, t.pstep, H, W);
+    for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
       const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
-      const float4 g = relu_grad4(da, ldda, dxpad, ldp, mask, C, p, t.q, H, W, v, sc, sh);
+      const float4 g = relu_grad4(da, ldda, dxpad, ldp, mask, C, p, it, t.q, H, W, v, sc, sh);
       a1 = f4add(a1, g);
       a2.x += g.x * (v.x - mu.x) * is.x;
       a2.y += g.y * (v.y - mu.y) * is.y;
@@ -691,9 +721,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, cons
     const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q), mu = ld4(mean + 4 * t.q), is = ld4(invstd + 4 * t.q);
     const float4 k1 = ld4(c1 + 4 * t.q), k2 = ld4(c2 + 4 * t.q);
     const int P = N * H * W;
-    for (int p = t.p; p < P; p += t.pstep) {
+    PixIter it = pix_iter(t.p, t.pstep, H, W);
+    for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
       const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
-      const float4 g = relu_grad4(da, ldda, dxpad, ldp, mask, C, p, t.q, H, W, v, sc, sh);
+      const float4 g = relu_grad4(da, ldda, dxpad, ldp, mask, C, p, it, t.q, H, W, v, sc, sh);
       float4 r;
       r.x = sc.x * (g.x - k1.x - (v.x - mu.x) * is.x * k2.x);
       r.y = sc.y * (g.y - k1.y - (v.y - mu.y) * is.y * k2.y);
