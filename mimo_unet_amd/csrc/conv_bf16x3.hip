@@ -357,7 +357,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
 //   tile = 256 output pixels (4 consumers x 4 fragments of 16 pixels) x NF*16 output channels
 //   LDS  = 2 input tiles (360 x 144 B) + 2 weight tap rows (3 x NB x 144 B) <= 159 KB
 //   one workgroup barrier per phase (tap row of a 32-channel chunk)
-// BatchNorm partial sums: one row per (tile, consumer wave) — no cross-wave LDS reduction.
+// BatchNorm partial sums: accumulated in registers over the workgroup's tiles, one row per (workgroup,
+// consumer wave) — no cross-wave LDS reduction, 4 x gridDim.x rows for the column reduction that follows.
 // ---------------------------------------------------------------------------------------
 constexpr int kWsNPix = 256, kWsMaxPix = 360, kWsMF = 4;
 
@@ -554,6 +555,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     esh[nf] = a.ep_scale ? a.ep_shift[co0 + nf * 16 + lr] : 0.f;
   }
   const int nphases = 3 * nstages;
+  // BatchNorm partial sums: accumulated over all tiles of this (persistent) workgroup, written once —
+  // one row per (workgroup, consumer wave) instead of one per (tile, wave)
+  float s1[NF], s2[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    s1[nf] = 0.f;
+    s2[nf] = 0.f;
+  }
 
   f32x4 acc[MF][NF];
 #pragma unroll
@@ -622,17 +631,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
 #define C_EPILOGUE(TI)                                                                               \
   {                                                                                                  \
     int t_ = blockIdx.x + (TI) * gridDim.x;                                                          \
-    const size_t row_ = ((size_t)t_ * 4 + wave) * 2;                                                 \
     const int tx_ = t_ % tilesX;                                                                     \
     t_ /= tilesX;                                                                                    \
     const int ty_ = t_ % tilesY;                                                                     \
     const int n_ = t_ / tilesY;                                                                      \
     const int y0_ = ty_ * TR, x0_ = tx_ * TC;                                                        \
-    float s1[NF], s2[NF];                                                                            \
-    _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                              \
-      s1[nf] = 0.f;                                                                                  \
-      s2[nf] = 0.f;                                                                                  \
-    }                                                                                                \
     float* yimg = a.y + (size_t)n_ * a.Ho * a.Wo * a.ldy;                                            \
     float emk[NF];                                                                                   \
     _Pragma("unroll") for (int nf = 0; nf < NF; ++nf)                                                \
@@ -652,18 +655,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
             s1[nf] += v;                                                                             \
             s2[nf] += v * v;                                                                         \
           }                                                                                          \
-        }                                                                                            \
-      }                                                                                              \
-    }                                                                                                \
-    if (a.stats) {                                                                                   \
-      _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                            \
-        s1[nf] += __shfl_xor(s1[nf], 16);                                                            \
-        s1[nf] += __shfl_xor(s1[nf], 32);                                                            \
-        s2[nf] += __shfl_xor(s2[nf], 16);                                                            \
-        s2[nf] += __shfl_xor(s2[nf], 32);                                                            \
-        if (g == 0) {                                                                                \
-          a.stats[(row_ + 0) * a.cout_pad + co0 + nf * 16 + lr] = s1[nf];                            \
-          a.stats[(row_ + 1) * a.cout_pad + co0 + nf * 16 + lr] = s2[nf];                            \
         }                                                                                            \
       }                                                                                              \
     }                                                                                                \
@@ -709,6 +700,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     C_MFMA(1, 0, 3)
   }
   C_EPILOGUE(ti)
+  if (a.stats) {
+    const size_t row = ((size_t)blockIdx.x * 4 + wave) * 2;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      s1[nf] += __shfl_xor(s1[nf], 16);
+      s1[nf] += __shfl_xor(s1[nf], 32);
+      s2[nf] += __shfl_xor(s2[nf], 16);
+      s2[nf] += __shfl_xor(s2[nf], 32);
+      if (g == 0) {
+        a.stats[(row + 0) * a.cout_pad + co0 + nf * 16 + lr] = s1[nf];
+        a.stats[(row + 1) * a.cout_pad + co0 + nf * 16 + lr] = s2[nf];
+      }
+    }
+  }
   __syncthreads();  // matches the producers' last barrier
 #undef C_READ_A
 #undef C_READ_B
@@ -724,11 +729,7 @@ static bool conv_ws_enabled() {
   return on;
 }
 
-int conv3x3_ws_stat_rows(int N, int Ho, int Wo) {
-  int TR, TC;
-  pick_tile_n(Ho, Wo, kWsNPix, kWsMaxPix, &TR, &TC);
-  return N * ceil_div(Ho, TR) * ceil_div(Wo, TC) * 4;
-}
+int conv3x3_ws_stat_rows(int, int, int) { return 256 * 4; }  // <= 256 persistent workgroups x 4 consumer waves
 
 template <int NF, bool F16>
 static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
@@ -737,12 +738,12 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   const int tilesY = ceil_div(a.Ho, TR), tilesX = ceil_div(a.Wo, TC);
   const int numTiles = a.N * tilesY * tilesX;
   const int coTiles = a.cout_pad / (NF * 16);
-  if (rows) *rows = numTiles * 4;
   // persistent: one workgroup per CU (LDS), every workgroup of a launch walks the same number of tiles
   int gx = max(1, 256 / coTiles);
   if (gx > numTiles) gx = numTiles;
   const int per = ceil_div(numTiles, gx);
   gx = ceil_div(numTiles, per);
+  if (rows) *rows = gx * 4;  // one partial-statistics row per (workgroup, consumer wave)
   dim3 grid(gx, coTiles);
   // conflict-free swizzled rows measured the same step time as the padded rows (6.97 / 7.20 vs 6.89 / 7.20 ms
   // forward / data gradient per step): the LDS array is not what the consumers wait for.  Opt-in.

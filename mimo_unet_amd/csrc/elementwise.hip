@@ -342,10 +342,9 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ a, int lda, int N, 
   if (!t.active) return;
   const int Ho = H / 2, Wo = W / 2;
   const int P = N * Ho * Wo;
-  for (int p = t.p; p < P; p += t.pstep) {
-    const int n = p / (Ho * Wo);
-    const int r = p - n * Ho * Wo;
-    const int oy = r / Wo, ox = r - oy * Wo;
+  PixIter it = pix_iter(t.p, t.pstep, Ho, Wo);
+  for (int p = t.p; p < P; p += t.pstep, pix_next(it, Ho, Wo)) {
+    const int n = it.n, oy = it.y, ox = it.x;
     const float* src = a + (((size_t)n * H + 2 * oy) * W + 2 * ox) * lda + 4 * t.q;
     const float4 v = f4max(f4max(ld4(src), ld4(src + lda)), f4max(ld4(src + (size_t)W * lda), ld4(src + (size_t)(W + 1) * lda)));
     st4(out + (size_t)p * ldo + 4 * t.q, v);
@@ -367,6 +366,11 @@ struct Lerp {
   float l0, l1;
 };
 __device__ __forceinline__ Lerp lerp_src(int dst, int in, int out) {
+  // no fma contraction in here: torch rounds src = scale * dst to fp32 and then subtracts i0 (checked
+  // against F.interpolate on the CPU); an fma keeps the exact product and moves lambda by up to an ulp of
+  // src (4e-6 at src ~ 50, 2e-6 relative on the output) — and whether the compiler contracts depends on
+  // the surrounding code, so it is pinned here
+#pragma clang fp contract(off)
   const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
   const float src = scale * (float)dst;
   Lerp r;
@@ -385,14 +389,13 @@ __global__ void upcat_fwd_kernel(const float* __restrict__ skip, int lds, int cs
   if (!t.active) return;
   const int ldo = 4 * Cv;
   const int P = N * H * W;
-  for (int p = t.p; p < P; p += t.pstep) {
+  PixIter it = pix_iter(t.p, t.pstep, H, W);
+  for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
     float4 v;
     if (t.q < csv) {
       v = ld4(skip + (size_t)p * lds + 4 * t.q);
     } else {
-      const int n = p / (H * W);
-      const int r = p - n * H * W;
-      const int y = r / W, x = r - y * W;
+      const int n = it.n, y = it.y, x = it.x;
       const int uy = y - padT, ux = x - padL;
       v = f4zero();
       if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w) {
@@ -443,10 +446,9 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int ch
   if (!t.active) return;
   const int Hp = H / 2, Wp = W / 2;
   const int P = N * H * W;
-  for (int p = t.p; p < P; p += t.pstep) {
-    const int n = p / (H * W);
-    const int r = p - n * H * W;
-    const int y = r / W, x = r - y * W;
+  PixIter it = pix_iter(t.p, t.pstep, H, W);
+  for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
+    const int n = it.n, y = it.y, x = it.x;
     float4 v = f4zero();
     if (y < 2 * Hp && x < 2 * Wp) {
       const int py = y >> 1, px = x >> 1;
@@ -539,10 +541,9 @@ __global__ void up_bwd_kernel(const float* __restrict__ dxpad, int ldp, int chof
   const PQ t = pixquad(Cv);
   if (!t.active) return;
   const int P = N * h * w;
-  for (int p = t.p; p < P; p += t.pstep) {
-    const int n = p / (h * w);
-    const int r = p - n * h * w;
-    const int iy = r / w, ix = r - iy * w;
+  PixIter it = pix_iter(t.p, t.pstep, h, w);
+  for (int p = t.p; p < P; p += t.pstep, pix_next(it, h, w)) {
+    const int n = it.n, iy = it.y, ix = it.x;
     float4 v = f4zero();
     for (int oy = max(0, 2 * iy - 2); oy <= min(2 * h - 1, 2 * iy + 2); ++oy) {
       const float wy = lerp_weight(oy, iy, h);
