@@ -116,7 +116,10 @@ def main():
     dev = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # MIMO_BENCH_FORCE_DIST=1: take the data-parallel code path (RCCL init, bucketed all-reduce overlapped with
+    # the encoder backward, barrier, max-over-ranks) even with one rank — a functional check on a 1-GPU box
+    force_dist = world == 1 and os.environ.get("MIMO_BENCH_FORCE_DIST", "0") != "0" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -136,7 +139,7 @@ def main():
     batch = {"image": image, "label": label}
 
     from mimo_unet_amd.ddp import FlatGradientAllReducer
-    reducer = FlatGradientAllReducer() if world > 1 else None
+    reducer = FlatGradientAllReducer() if dist is not None else None
     if reducer is not None:
         reducer.attach(model.model)  # all-reduce of the core/decoder gradients overlaps the encoder backward
 
@@ -153,25 +156,24 @@ def main():
         step(i)
     plan = next(iter(model.model._plans.values()))
     plan.profile(True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = plan.profile_read()
     plan.profile(False)
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -211,7 +213,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(c)
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
