@@ -158,6 +158,20 @@ int mimo_adam_step(float* params, const float* grads, float* exp_avg, float* exp
 int mimo_uncertainties(const float* p1, const float* p2, int32_t n, int32_t s, int32_t c, int64_t hw,
                        int32_t loss_kind, float* mean, float* aleatoric, float* epistemic, mimo_stream stream);
 
+/* ---- validation epilogue: replaces, after the forward, the tail of MimoUnetModel.validation_step
+ * (mimo_unet.py:153-183): compute_uncertainties, sqrt of the variances, calculate_dist_param(log=True) +
+ * the combined NLL on the ensemble mean, the error map, compute_regression_metrics (metrics.py:22-34:
+ * r2 / mae / mse / rmse) and the two logged uncertainty means — one pass over the logits.
+ * out [N,S,2*Ct,HW] logits, label [N,Ct,HW], mask [N,1,HW] or NULL.
+ * mean / aleatoric_std / epistemic_std / err: [N,Ct,HW] each.
+ * scalars: device [8] = combined NLL, mae, mse, rmse, r2, mean clip(aleatoric_std,0,5),
+ *          mean clip(epistemic_std,0,5), element count.
+ * scratch: device doubles [scratch_blocks * 8], scratch_blocks >= 1 (1024 is enough for any size). */
+int mimo_validation_epilogue(const float* out, const float* label, const float* mask, int32_t n, int32_t s, int32_t ct,
+                             int64_t hw, int32_t loss_kind, float eps_min, float eps_max, float* mean,
+                             float* aleatoric_std, float* epistemic_std, float* err, float* scalars, double* scratch,
+                             int32_t scratch_blocks, mimo_stream stream);
+
 /* ---- single-operator entry points (NHWC, channel-padded) used by the parity tests -------
  * They run the same kernels the plan runs.  x [N,H,W,cin_p], w OIHW [cout][cin][3][3]. */
 int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, float* z, double* stats,

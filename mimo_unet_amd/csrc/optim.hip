@@ -76,7 +76,119 @@ __global__ void uncertainty_kernel(const float* __restrict__ p1, const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Validation epilogue (mimo_unet.py:146-183 after the forward, metrics.py:22-34): one pass over the
+// logits produces the ensemble mean, the aleatoric / epistemic standard deviations, the error map and
+// the sums behind the combined NLL, mae / mse / rmse / r2 and the logged uncertainty means; a
+// one-workgroup second pass turns the per-workgroup partials (double) into the eight scalars.
+// ---------------------------------------------------------------------------------------
+constexpr int kValSums = 8;  // nll, err^2, |err|, y, y^2, clip(alea_std), clip(epi_std), (unused)
+
+__global__ void val_epilogue_kernel(const float* __restrict__ out, const float* __restrict__ label,
+                                    const float* __restrict__ mask, int N, int S, int Ct, int64_t hw, int kind, float eps_min,
+                                    float eps_max, float* __restrict__ mean, float* __restrict__ alea_std,
+                                    float* __restrict__ epi_std, float* __restrict__ err, double* __restrict__ partial) {
+  __shared__ double red[kValSums][256];
+  const int64_t chw = (int64_t)Ct * hw, total = (int64_t)N * chw;
+  double acc[kValSums];
+#pragma unroll
+  for (int k = 0; k < kValSums; ++k) acc[k] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / chw, r = i - n * chw;  // r = c * hw + pixel
+    const float* a = out + n * S * 2 * chw + r;   // p1[n][s][c] at stride 2*chw per subnetwork
+    const float* b = a + chw;                     // p2 = channels Ct .. 2Ct-1 of the same subnetwork
+    float sm = 0.f, sa = 0.f;
+    for (int s = 0; s < S; ++s) {
+      sm += a[(int64_t)s * 2 * chw];
+      const float e = expf(b[(int64_t)s * 2 * chw]);
+      const float sd = kind == MIMO_LOSS_LAPLACE_NLL ? e * 1.41421356237309515f : sqrtf(e);
+      sa += sd * sd;
+    }
+    const float mu = sm / (float)S;
+    float se = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float d = a[(int64_t)s * 2 * chw] - mu;
+      se += d * d;
+    }
+    const float av = sa / (float)S, ev = S > 1 ? se / (float)(S - 1) : 0.f;
+    const float as = sqrtf(av), es = sqrtf(ev), cs = sqrtf(av + ev);
+    const float y = label[i];
+    const float d = mu - y;
+    // combined NLL: calculate_dist_param(std, log=True) then forward() clamps exp() of it again
+    float prm = kind == MIMO_LOSS_LAPLACE_NLL ? cs / 1.41421356237309515f : cs * cs;
+    prm = fminf(fmaxf(prm, eps_min), eps_max);
+    const float sc = fminf(fmaxf(expf(logf(prm)), eps_min), eps_max);
+    float nll = logf(sc) + (kind == MIMO_LOSS_LAPLACE_NLL ? fabsf(d) : d * d) / sc;
+    if (mask) nll *= mask[n * hw + (r % hw)];
+    mean[i] = mu;
+    alea_std[i] = as;
+    epi_std[i] = es;
+    err[i] = d;
+    acc[0] += nll;
+    acc[1] += (double)d * d;
+    acc[2] += fabsf(d);
+    acc[3] += y;
+    acc[4] += (double)y * y;
+    acc[5] += fminf(fmaxf(as, 0.f), 5.f);
+    acc[6] += fminf(fmaxf(es, 0.f), 5.f);
+  }
+#pragma unroll
+  for (int k = 0; k < kValSums; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+#pragma unroll
+      for (int k = 0; k < kValSums; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x < kValSums) partial[(size_t)blockIdx.x * kValSums + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// scalars: [0] combined NLL (mean), [1] mae, [2] mse, [3] rmse, [4] r2, [5] mean clip(aleatoric_std, 0, 5),
+//          [6] mean clip(epistemic_std, 0, 5), [7] element count
+__global__ void val_finalize_kernel(const double* __restrict__ partial, int blocks, double count, float* __restrict__ scalars) {
+  __shared__ double tot[kValSums];
+  if (threadIdx.x < kValSums) {
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * kValSums + threadIdx.x];
+    tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double mse = tot[1] / count;
+    const double ss_tot = tot[4] - tot[3] * tot[3] / count;
+    scalars[0] = (float)(tot[0] / count);
+    scalars[1] = (float)(tot[2] / count);
+    scalars[2] = (float)mse;
+    scalars[3] = (float)sqrt(mse);
+    scalars[4] = (float)(1.0 - tot[1] / ss_tot);
+    scalars[5] = (float)(tot[5] / count);
+    scalars[6] = (float)(tot[6] / count);
+    scalars[7] = (float)count;
+  }
+}
+
 }  // namespace mimo
+
+extern "C" int mimo_validation_epilogue(const float* out, const float* label, const float* mask, int32_t n, int32_t s,
+                                        int32_t ct, int64_t hw, int32_t loss_kind, float eps_min, float eps_max, float* mean,
+                                        float* aleatoric_std, float* epistemic_std, float* err, float* scalars,
+                                        double* scratch, int32_t scratch_blocks, mimo_stream stream) {
+  using namespace mimo;
+  if (!out || !label || !mean || !aleatoric_std || !epistemic_std || !err || !scalars || !scratch || n < 1 || s < 1 ||
+      ct < 1 || hw < 1 || scratch_blocks < 1) {
+    set_error("mimo_validation_epilogue: invalid argument");
+    return MIMO_ERR_INVALID;
+  }
+  const int64_t total = (int64_t)n * ct * hw;
+  const int blocks = (int)std::min<int64_t>(std::min<int64_t>(ceil_div64(total, 256), 1024), scratch_blocks);
+  hipLaunchKernelGGL(val_epilogue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, label, mask, n, s, ct, hw,
+                     loss_kind, eps_min, eps_max, mean, aleatoric_std, epistemic_std, err, scratch);
+  MIMO_KERNEL_CHECK();
+  hipLaunchKernelGGL(val_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, blocks, (double)total, scalars);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
 
 extern "C" int mimo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,

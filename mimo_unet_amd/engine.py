@@ -180,3 +180,28 @@ def uncertainties(p1: torch.Tensor, p2: torch.Tensor, loss: str = "laplace_nll")
     L.check(lib.mimo_uncertainties(p1.data_ptr(), p2.data_ptr(), n, s, c, h * w, L.LOSS_KINDS[loss], outs[0].data_ptr(),
                                    outs[1].data_ptr(), outs[2].data_ptr(), L.current_stream()), "mimo_uncertainties")
     return tuple(outs)
+
+
+VAL_SCALARS = ("nll_combined", "mae", "mse", "rmse", "r2", "aleatoric_std_mean", "epistemic_std_mean", "count")
+
+
+def validation_epilogue(out: torch.Tensor, label: torch.Tensor, mask: Optional[torch.Tensor], loss: str = "laplace_nll",
+                        eps_min: float = 1e-5, eps_max: float = 1e3):
+    """Logits [N,S,2*Ct,H,W] + label [N,Ct,H,W] (+ mask [N,1,H,W]) -> (mean, aleatoric_std, epistemic_std,
+    err) maps [N,Ct,H,W] and a device tensor of the eight scalars named in VAL_SCALARS — the tail of
+    MimoUnetModel.validation_step (mimo_unet.py:153-183) in one pass."""
+    lib = L.load()
+    out, label = out.contiguous(), label.contiguous().float()
+    n, s, co, h, w = out.shape
+    ct = co // 2
+    assert label.shape == (n, ct, h, w), (label.shape, out.shape)
+    mask = None if mask is None else mask.contiguous().float()
+    maps = [torch.empty(n, ct, h, w, device=out.device, dtype=torch.float32) for _ in range(4)]
+    scalars = torch.empty(8, device=out.device, dtype=torch.float32)
+    blocks = 1024
+    scratch = torch.empty(blocks * 8, device=out.device, dtype=torch.float64)
+    L.check(lib.mimo_validation_epilogue(out.data_ptr(), label.data_ptr(), L.ptr(mask) or None, n, s, ct, h * w,
+                                         L.LOSS_KINDS[loss], eps_min, eps_max, maps[0].data_ptr(), maps[1].data_ptr(),
+                                         maps[2].data_ptr(), maps[3].data_ptr(), scalars.data_ptr(), scratch.data_ptr(),
+                                         blocks, L.current_stream()), "mimo_validation_epilogue")
+    return maps[0], maps[1], maps[2], maps[3], scalars

@@ -332,7 +332,7 @@ class MimoUNet(nn.Module):
         elem_masks = self._elem_dropout_masks(n, x.shape[-2], x.shape[-1], x.device)
         # make sure the flat storage exists before the parameters are handed to autograd
         plan = self._plan_for(x, perm)
-        if not bn_training and label is None and not torch.is_grad_enabled():
+        if not bn_training and not torch.is_grad_enabled():
             # inference (eval mode under torch.no_grad()): no autograd node, BatchNorm + ReLU folded into the
             # convolution epilogue, packed weights reused while the parameters have not changed
             out = torch.empty(n, self.num_subnetworks, self.out_channels, plan.height, plan.width, device=x.device,
@@ -342,7 +342,11 @@ class MimoUNet(nn.Module):
                          param_version=self._param_version())
             plan.generation += 1
             self._inference_keep = (x, perm, masks, elem_masks)  # the plan still points at the mask tensors
-            return out, torch.zeros(0, device=x.device, dtype=torch.float32)
+            if label is None:
+                return out, torch.zeros(0, device=x.device, dtype=torch.float32)
+            loss = torch.empty(self.num_subnetworks, device=x.device, dtype=torch.float32)
+            plan.loss_forward(label, lmask, perm, loss)  # per-subnetwork mean NLL (validation)
+            return out, loss
         out, loss = _NetFunction.apply(self, x, label, lmask, perm, masks, bn_training, elem_masks, *self._param_list)
         if bn_training:
             self._bump_batch_counters()

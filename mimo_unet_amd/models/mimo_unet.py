@@ -18,6 +18,7 @@ from typing import Any, Dict, Literal, Optional, Tuple
 
 import torch
 
+from ..engine import validation_epilogue
 from ..lightning_compat import LightningModule
 from ..losses import UncertaintyLoss
 from ..metrics import compute_regression_metrics
@@ -64,6 +65,7 @@ class MimoUnetModel(LightningModule):
         self.decoder_dropout_rate = decoder_dropout_rate
 
         self.loss_fn = UncertaintyLoss.from_name(loss)
+        self.loss_name = loss
         self.weight_decay = weight_decay
         self.learning_rate = learning_rate
         self.seed = seed
@@ -142,25 +144,23 @@ class MimoUnetModel(LightningModule):
         S = self.num_subnetworks
         with torch.no_grad():
             out, val_loss = self._val_forward(image, label, mask)
-            half = self.out_channels // 2
-            p1, p2 = out[:, :, :half, ...], out[:, :, half:, ...]
-            y_pred_mean, aleatoric_var, epistemic_var = compute_uncertainties(self.loss_fn, p1, p2)
+            # uncertainties, combined NLL on the ensemble mean, error map and the regression metrics in one pass
+            # (engine.validation_epilogue; the reference runs ~15 full-tensor torch ops here)
             y_mean = label
-            combined_std = torch.sqrt(aleatoric_var + epistemic_var)
-            aleatoric_std = torch.sqrt(aleatoric_var)
-            epistemic_std = torch.sqrt(epistemic_var)
-            combined_log_scale = self.loss_fn.calculate_dist_param(std=combined_std, log=True)
-            val_loss_combined = self.loss_fn.forward(p1.mean(dim=1), combined_log_scale, y_mean, mask=mask, reduce_mean=True)
-            self._log_val_loss(val_loss, val_loss_combined)
-            self._log_metrics(y_pred=y_pred_mean, y_true=y_mean, stage="val")
-            self._log_uncertainties(aleatoric_std, epistemic_std)
+            y_pred_mean, aleatoric_std, epistemic_std, err_map, sc = validation_epilogue(
+                out, label, mask, self.loss_name, self.loss_fn.eps_min, self.loss_fn.eps_max)
+            self._log_val_loss(val_loss, sc[0])
+            for i, name in ((4, "r2"), (1, "mae"), (2, "mse"), (3, "rmse")):
+                self._log(f"metric_val/{name}", sc[i], on_step=False, on_epoch=True)
+            self._log("metric_val/aleatoric_std_mean", sc[5])
+            self._log("metric_val/epistemic_std_mean", sc[6])
         return {
             "loss": val_loss.mean(),
             "label": y_mean,
             "preds": y_pred_mean,
             "aleatoric_std_map": aleatoric_std,
             "epistemic_std_map": epistemic_std,
-            "err_map": y_pred_mean - y_mean,
+            "err_map": err_map,
             "mask": mask,
         }
 

@@ -378,6 +378,15 @@ def test_validation_step_matches_oracle():
     for s in range(S):
         assert abs(model.logged[f"val_loss_{s}"].item() - float(val_loss[s])) <= TOL * abs(float(val_loss[s]))
     assert set(out) == {"loss", "label", "preds", "aleatoric_std_map", "epistemic_std_map", "err_map", "mask"}
+    # the fused epilogue's logged scalars: compute_regression_metrics (metrics.py:22-34) and the uncertainty means
+    yh, y = mean.flatten().double(), label.flatten().double()
+    ref = {"mae": (yh - y).abs().mean(), "mse": ((yh - y) ** 2).mean(), "rmse": ((yh - y) ** 2).mean().sqrt(),
+           "r2": 1 - ((y - yh) ** 2).sum() / ((y - y.mean()) ** 2).sum()}
+    for k, v in ref.items():
+        assert abs(model.logged[f"metric_val/{k}"].item() - float(v)) <= TOL * max(abs(float(v)), 1e-3), k
+    for k, t in (("aleatoric_std_mean", alea.sqrt()), ("epistemic_std_mean", epi.sqrt())):
+        v = float(t.clip(0, 5).mean())
+        assert abs(model.logged[f"metric_val/{k}"].item() - v) <= TOL * abs(v), k
 
 
 def test_deep_ensemble_of_two_checkpoints(tmp_path):

@@ -164,3 +164,34 @@ def test_uncertainties(S, kind):
     torch.cuda.synchronize()
     for o, r in zip(outs, ref):
         assert rel_err(o.cpu(), r) < 1e-5
+
+
+@pytest.mark.parametrize("S", [1, 3])
+@pytest.mark.parametrize("kind", ["laplace_nll", "gaussian_nll"])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_validation_epilogue(S, kind, use_mask):
+    """mimo_validation_epilogue against the oracle's restatement of the validation_step tail
+    (mimo_unet.py:153-183) and the regression metrics (metrics.py:22-34)."""
+    from mimo_unet_amd.engine import VAL_SCALARS, validation_epilogue
+    g = torch.Generator().manual_seed(10 * S + use_mask)
+    N, Ct, H, W = 3, 2, 9, 7
+    out = torch.randn(N, S, 2 * Ct, H, W, generator=g)
+    out[0, 0, Ct, 0, 0] = -20.0  # clamp extremes of the dispersion parameter
+    out[0, 0, Ct, 0, 1] = 9.0
+    label = torch.randn(N, Ct, H, W, generator=g)
+    mask = (torch.rand(N, 1, H, W, generator=g) > 0.3).float() if use_mask else None
+    p1, p2 = out[:, :, :Ct], out[:, :, Ct:]
+    mean, alea, epi = O.compute_uncertainties(kind, p1, p2)
+    comb = O.calculate_dist_param(kind, torch.sqrt(alea + epi), log=True)
+    nll = O.loss_forward(kind, p1.mean(dim=1), comb, label, mask=mask)
+    yh, y = mean.flatten().double(), label.flatten().double()
+    ref = {"nll_combined": nll, "mae": (yh - y).abs().mean(), "mse": ((yh - y) ** 2).mean(),
+           "rmse": ((yh - y) ** 2).mean().sqrt(), "r2": 1 - ((y - yh) ** 2).sum() / ((y - y.mean()) ** 2).sum(),
+           "aleatoric_std_mean": alea.sqrt().clip(0, 5).mean(), "epistemic_std_mean": epi.sqrt().clip(0, 5).mean(),
+           "count": float(N * Ct * H * W)}
+    m, a, e, err, sc = validation_epilogue(out.cuda(), label.cuda(), None if mask is None else mask.cuda(), kind)
+    torch.cuda.synchronize()
+    assert rel_err(m.cpu(), mean) < 1e-5 and rel_err(a.cpu(), alea.sqrt()) < 1e-5
+    assert rel_err(e.cpu(), epi.sqrt()) < 1e-4 and rel_err(err.cpu(), mean - label) < 1e-5
+    for i, name in enumerate(VAL_SCALARS):
+        assert abs(sc[i].item() - float(ref[name])) <= 1e-4 * max(abs(float(ref[name])), 1e-3), name
