@@ -450,3 +450,34 @@ def ensemble_forward(cfg: NetConfig, st: Dict[str, Tensor], x: Tensor, loss_kind
         p2s.append(b)
     p1, p2 = torch.cat(p1s, dim=1), torch.cat(p2s, dim=1)
     return (p1, p2) if raw else compute_uncertainties(loss_kind, p1, p2)
+
+
+# ---------------------------------------------------------------------------------------
+# Evidential regression variant (mimo/models/evidential_unet.py:74-96, mimo/losses.py:195-271)
+# ---------------------------------------------------------------------------------------
+def evidential_forward(cfg: NetConfig, st: Dict[str, Tensor], x: Tensor, *, training: bool,
+                       masks: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """EvidentialUnetModel.forward — evidential_unet.py:74-96.  x [B,Ci,H,W] -> [B,4,H,W] =
+    (gamma, v, alpha, beta); the backbone is the S=1 MIMO U-Net with four output channels."""
+    assert cfg.num_subnetworks == 1 and cfg.out_channels == 4
+    out = mimo_unet_forward(cfg, st, x[:, None], training=training, masks=masks)[:, 0]
+    mu, logv, logalpha, logbeta = torch.unbind(out, dim=1)
+    return torch.stack([mu, F.softplus(logv), F.softplus(logalpha) + 1, F.softplus(logbeta)], dim=1)
+
+
+def evidential_loss(ev: Tensor, y: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    """EvidentialLoss.forward(reduce_mean=False) — losses.py:202-247: sum-of-squares NIG loss plus the
+    evidence regulariser, per pixel [B,H,W]."""
+    mu, v, alpha, beta = torch.unbind(ev, dim=1)
+    t = y.squeeze(1)
+    coeff = torch.exp(torch.lgamma(alpha - 0.5)) / (4 * torch.exp(torch.lgamma(alpha)) * v * torch.sqrt(beta))
+    sos = coeff * (2 * beta * (1 + v) + (2 * alpha - 1) * v * (t - mu) ** 2)
+    reg = (t - mu) ** 2 * (2 * alpha + v)
+    loss = sos + reg
+    return loss * mask if mask is not None else loss
+
+
+def evidential_vars(ev: Tensor) -> Tuple[Tensor, Tensor]:
+    """aleatoric_var, epistemic_var — losses.py:259-271."""
+    _, v, alpha, beta = torch.unbind(ev, dim=1)
+    return beta / (alpha - 1), beta / (v * (alpha - 1))

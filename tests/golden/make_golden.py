@@ -29,7 +29,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
-from mimo.losses import GaussianNLL, LaplaceNLL  # noqa: E402
+from mimo.losses import EvidentialLoss, GaussianNLL, LaplaceNLL  # noqa: E402
 from mimo.models.mimo_components.loss_buffer import LossBuffer  # noqa: E402
 from mimo.models.mimo_components.model import MimoUNet  # noqa: E402
 from mimo.models.utils import apply_input_transform, compute_uncertainties, repeat_subnetworks  # noqa: E402
@@ -263,6 +263,42 @@ def elem_dropout_fixture():
     print("elem_dropout.npz")
 
 
+def evidential_fixture():
+    """EvidentialUnetModel (evidential_unet.py:74-118) on the real MimoUNet + EvidentialLoss: the class
+    itself needs lightning, so its forward glue (unsqueeze, softplus heads) is restated here; backbone
+    and loss are the reference's.  One training-mode forward + backward."""
+    Ci, f, N, H, W = 3, 4, 2, 32, 32
+    torch.manual_seed(31)
+    net = MimoUNet(in_channels=Ci, out_channels=4, num_subnetworks=1, filter_base_count=f)
+    net.train()
+    g = torch.Generator().manual_seed(32)
+    fx = {"meta": np.array([Ci, 4, 1, f, N, H, W])}
+    for k, v in net.state_dict().items():
+        fx["init/" + k] = npd(v)
+    x = torch.rand(N, Ci, H, W, generator=g).requires_grad_(True)
+    y = torch.rand(N, 1, H, W, generator=g)
+    mask = (torch.rand(N, H, W, generator=g) > 0.2).float()
+    out = net(torch.unsqueeze(x, dim=1)).squeeze(dim=1)
+    mu, logv, logalpha, logbeta = torch.unbind(out, axis=1)
+    sp = torch.nn.Softplus()
+    ev = torch.stack([mu, sp(logv), sp(logalpha) + 1, sp(logbeta)], dim=1)
+    crit = EvidentialLoss(coeff=1.0)
+    loss = crit(ev, y, mask=mask)
+    loss.mean().backward()
+    fx["x"], fx["y"], fx["mask"], fx["ev"], fx["loss"], fx["dx"] = npd(x), npd(y), npd(mask), npd(ev), npd(loss), npd(x.grad)
+    fx["aleatoric_var"], fx["epistemic_var"] = npd(crit.aleatoric_var(ev)), npd(crit.epistemic_var(ev))
+    for k, p in net.named_parameters():
+        fx["grad/" + k] = npd(p.grad)
+    # loss extremes on hand-made NIG parameters
+    e2 = torch.tensor([[[0.3]], [[1e-3]], [[1.0001]], [[1e-4]]]).reshape(1, 4, 1, 1).repeat(1, 1, 1, 3)
+    e2[0, 1, 0, 1], e2[0, 2, 0, 1], e2[0, 3, 0, 1] = 5.0, 9.0, 4.0
+    e2[0, 1, 0, 2], e2[0, 2, 0, 2], e2[0, 3, 0, 2] = 0.5, 1.5, 0.7
+    y2 = torch.tensor([0.1, -2.0, 0.3]).reshape(1, 1, 1, 3)
+    fx["ext/ev"], fx["ext/y"], fx["ext/loss"] = npd(e2), npd(y2), npd(crit(e2, y2))
+    np.savez_compressed(os.path.join(HERE, "evidential.npz"), **fx)
+    print("evidential.npz")
+
+
 if __name__ == "__main__":
     # BASELINE config[0]: synthetic 3ch 64x64, S=1, fbc=8, batch 4
     train_fixture("cfg1_step.npz", Ci=3, Co=2, S=1, f=8, N=4, H=64, W=64, use_mask=False, steps=3, seed=1)
@@ -275,3 +311,4 @@ if __name__ == "__main__":
     loss_fixture()
     mc_dropout_fixture()
     elem_dropout_fixture()
+    evidential_fixture()

@@ -172,3 +172,19 @@ def test_gradient_allreduce_gloo_world2():
     assert n0 == n1 == 4 and s0 == s1 == 0.5
     assert torch.allclose(r0, l0 + l1) and torch.equal(r0, r1)          # every rank holds the sum
     assert torch.allclose(r0 * s0, (l0 + l1) / 2)                        # optimiser sees the mean of the shard grads
+
+
+def test_evidential_loss_class_matches_golden():
+    """mimo.losses.EvidentialLoss (host mirror) on the reference's golden NIG parameters."""
+    from mimo.losses import EvidentialLoss
+    from tests.helpers import load_npz
+    fx = load_npz("evidential.npz")
+    crit = EvidentialLoss(coeff=1.0)
+    ev, y, mask = (torch.from_numpy(fx[k]) for k in ("ev", "y", "mask"))
+    np.testing.assert_allclose(crit(ev, y, mask=mask).numpy(), fx["loss"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(crit.aleatoric_var(ev).numpy(), fx["aleatoric_var"], rtol=1e-6)
+    np.testing.assert_allclose(crit.epistemic_var(ev).numpy(), fx["epistemic_var"], rtol=1e-6)
+    np.testing.assert_allclose(crit(torch.from_numpy(fx["ext/ev"]), torch.from_numpy(fx["ext/y"])).numpy(), fx["ext/loss"],
+                               rtol=1e-5)
+    assert torch.equal(crit.mode(ev), ev[:, 0]) and crit.num_distribution_params == 4
+    assert float(crit(ev, y, reduce_mean=True)) == float(crit(ev, y).mean())

@@ -517,3 +517,39 @@ def test_inference_path_matches_eval_forward_and_tracks_parameter_changes():
 
 def repeat_sub(x, S):
     return x[:, None].repeat(1, S, 1, 1, 1).contiguous()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_evidential_model_golden(precision):
+    """EvidentialUnetModel (evidential_unet.py:13-145) on the HIP backbone: NIG outputs, per-pixel loss,
+    variances, input gradient and every parameter gradient against the reference; validation_step keys."""
+    from mimo.models.evidential_unet import EvidentialUnetModel
+    fx = load_npz("evidential.npz")
+    Ci, Co, S, f, N, H, W = (int(v) for v in fx["meta"])
+    m = EvidentialUnetModel(in_channels=Ci, out_channels=Co, filter_base_count=f, center_dropout_rate=0.0,
+                            final_dropout_rate=0.0, encoder_dropout_rate=0.0, core_dropout_rate=0.0,
+                            decoder_dropout_rate=0.0, weight_decay=0.0, learning_rate=1e-3, seed=0)
+    m.load_state_dict({"model." + k: v for k, v in state_from(fx, "init/").items()})
+    m.model.set_precision(precision)
+    m = m.cuda()
+    m.train()
+    x = torch.from_numpy(fx["x"]).cuda().requires_grad_(True)
+    y, mask = torch.from_numpy(fx["y"]).cuda(), torch.from_numpy(fx["mask"]).cuda()
+    out = m.training_step({"image": x, "label": y, "mask": mask}, 0)
+    out["loss"].backward()
+    np.testing.assert_allclose(out["loss"].item(), fx["loss"].mean(), rtol=TOL)
+    assert rel_err(out["preds"][:, 0].detach().cpu(), fx["ev"][:, 0]) < TOL
+    assert rel_err(out["aleatoric_std_map"][:, 0].detach().cpu() ** 2, fx["aleatoric_var"]) < TOL
+    assert set(out) == {"loss", "label", "preds", "aleatoric_std_map", "err_map", "mask"}
+    e_dx = rel_err(x.grad.cpu(), fx["dx"])
+    grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    worst = check_grads(grads, {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")},
+                        flip_robust=(precision != "fp32"))
+    print(f"evidential [{precision}]: dx {e_dx:.2e} worst grad {worst[1]:.2e} at {worst[0]}")
+    assert e_dx < (TOL if precision == "fp32" else 5e-2)
+    m.eval()
+    v = m.validation_step({"image": x.detach(), "label": y, "mask": mask}, 0)
+    assert set(v) == {"loss", "label", "preds", "aleatoric_std_map", "epistemic_std_map", "err_map", "mask"}
+    assert all(torch.isfinite(t).all() for t in v.values() if isinstance(t, torch.Tensor))
+    opt = m.configure_optimizers()["optimizer"]
+    opt.step()  # fused Adam over the flat buffer

@@ -190,6 +190,31 @@ def test_elementwise_center_final_dropout():
             assert rel_err(p.grad, fx["grad/" + k]) < 2e-4, k
 
 
+def test_evidential_model_and_loss():
+    """S=1, four-channel backbone + softplus NIG heads + EvidentialLoss (evidential_unet.py:74-118,
+    losses.py:195-271): outputs, per-pixel loss, variances and every gradient against the reference."""
+    fx = load_npz("evidential.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    st = state_from(fx, "init/")
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items() if not O.is_buffer(k)}
+    x = torch.from_numpy(fx["x"]).requires_grad_(True)
+    ev = O.evidential_forward(cfg, {**st, **params}, x, training=True)
+    assert rel_err(ev, fx["ev"]) < TOL
+    loss = O.evidential_loss(ev, torch.from_numpy(fx["y"]), torch.from_numpy(fx["mask"]))
+    assert rel_err(loss, fx["loss"]) < 1e-5
+    al, ep = O.evidential_vars(ev)
+    assert rel_err(al, fx["aleatoric_var"]) < 1e-5 and rel_err(ep, fx["epistemic_var"]) < 1e-5
+    loss.mean().backward()
+    assert rel_err(x.grad, fx["dx"]) < 1e-4
+    for k, p in params.items():
+        if k.endswith(("double_conv.0.bias", "double_conv.3.bias")):
+            assert float(p.grad.abs().max()) < 1e-5, k  # zero gradient in front of a training-mode BatchNorm
+        else:
+            assert rel_err(p.grad, fx["grad/" + k]) < 2e-4, k
+    ext = O.evidential_loss(torch.from_numpy(fx["ext/ev"]), torch.from_numpy(fx["ext/y"]))
+    np.testing.assert_allclose(ext.numpy(), fx["ext/loss"], rtol=1e-5)
+
+
 def test_param_inventory_matches_reference_state_dict():
     fx = load_npz("cfg1_step.npz")
     cfg = cfg_from_meta(fx["meta"])
