@@ -2,7 +2,9 @@
 
 Mirrors the interface of the reference's
 ``mimo/models/mimo_components/loss_buffer.py:3-74`` (``LossBuffer``,
-``softmax_temperature``).  [S]-sized host arithmetic; not on the GPU path."""
+``softmax_temperature``).  [S]-sized arithmetic.  Unlike the reference's CPU tensor, the ring follows
+the device of the losses it is fed, so a training step needs no device-to-host copy (and no host sync)
+between its forward and its backward."""
 import torch
 
 
@@ -26,12 +28,14 @@ class LossBuffer:
     def add(self, loss: torch.Tensor) -> None:
         if self.buffer_size == 0:
             return
-        self.buffer[self.index] = loss.detach().to(self.buffer.device)
+        if self.buffer.device != loss.device:
+            self.buffer = self.buffer.to(loss.device)  # once: the ring lives where the losses are produced
+        self.buffer[self.index] = loss.detach()
         self.index = (self.index + 1) % self.buffer_size
 
     def get_mean(self) -> torch.Tensor:
         if self.buffer_size == 0:
-            return torch.zeros(self.subnetworks)
+            return torch.zeros(self.subnetworks, device=self.buffer.device)
         return self.buffer.mean(dim=0)
 
     def get_weights(self) -> torch.Tensor:

@@ -117,7 +117,7 @@ def test_train_steps_match_reference_golden(name, precision):
             assert d.max() <= 2.02 * budget + 1e-5 * np.abs(v).max(), (name_, d.max())  # two runs, opposite signs
             rms_bound = (0.1 if d.size >= 256 else 1.0) * budget  # few-element tensors: rms ~ max (one Adam sign flip)
             assert np.sqrt((d ** 2).mean()) <= rms_bound, (name_, np.sqrt((d ** 2).mean()))
-    np.testing.assert_allclose(model.loss_buffer.buffer.numpy(), fx["final/loss_buffer"], rtol=TOL, atol=1e-6)
+    np.testing.assert_allclose(model.loss_buffer.buffer.cpu().numpy(), fx["final/loss_buffer"], rtol=TOL, atol=1e-6)
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
