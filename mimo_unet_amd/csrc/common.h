@@ -94,6 +94,18 @@ size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad);
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map,
                         int cin_p, int cin, int cout, float* dw, hipStream_t stream);
 
+// All weight repacks of a step in ONE launch (a per-layer launch each cost more in dispatch gaps than in
+// work): a device table of jobs, blockIdx.y = job.  kind 0: fp32 [tap][rows_pad][cols]; 1 / 2: fp16 / bf16
+// (hi, lo) pairs [chunk][tap][rows_pad][hi 32 | lo 32]; bias_n > 0 additionally copies the layer's bias.
+struct PackJob {
+  int64_t w_off, bias_off;  // float offsets into the bound parameter buffer
+  void* dst;
+  float* bias_dst;
+  const int *row_map, *col_map;
+  int kind, cout, cin, rows_pad, cols, transposed, total, bias_n;
+};
+int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream);
+
 // weight packing: torch OIHW -> [9][rows_pad][cols] (see conv3x3.hip)
 int pack_weights_launch(const float* w, float* dst, int cout, int cin, int rows_pad, int cols,
                         const int* row_map, const int* col_map, int transposed, hipStream_t stream);

@@ -847,6 +847,63 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, typename
   }
 }
 
+// one launch for every repack of a step (PackJob, common.h); element formulas as in the kernels above / in
+// pack_weights_kernel (conv3x3.hip)
+__global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* __restrict__ params) {
+  const PackJob j = jobs[blockIdx.y];
+  const float* w = params + j.w_off;
+  if (blockIdx.x == 0 && j.bias_n > 0)
+    for (int i = threadIdx.x; i < j.bias_n; i += blockDim.x) j.bias_dst[i] = params[j.bias_off + i];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j.total; i += gridDim.x * blockDim.x) {
+    int row, col, tap, k = 0, chunk = 0;
+    if (j.kind == 0) {
+      col = i % j.cols;
+      const int rest = i / j.cols;
+      row = rest % j.rows_pad;
+      tap = rest / j.rows_pad;
+    } else {
+      k = i & 31;
+      int rest = i >> 5;
+      row = rest % j.rows_pad;
+      rest /= j.rows_pad;
+      tap = rest % 9;
+      chunk = rest / 9;
+      col = chunk * 32 + k;
+    }
+    float v = 0.f;
+    if (col < j.cols) {
+      const int rm = j.row_map[row], cm = j.col_map[col];
+      if (rm >= 0 && cm >= 0) {
+        const int co = j.transposed ? cm : rm, ci = j.transposed ? rm : cm;
+        const int kh = j.transposed ? 2 - tap / 3 : tap / 3, kw = j.transposed ? 2 - tap % 3 : tap % 3;
+        v = w[(((size_t)co * j.cin + ci) * 3 + kh) * 3 + kw];
+      }
+    }
+    if (j.kind == 0) {
+      reinterpret_cast<float*>(j.dst)[i] = v;
+    } else if (j.kind == 1) {
+      v *= kF16WeightScale;
+      const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+      _Float16* d = reinterpret_cast<_Float16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 64;
+      d[k] = hi;
+      d[32 + k] = lo;
+    } else {
+      const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+      __bf16* d = reinterpret_cast<__bf16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 64;
+      d[k] = hi;
+      d[32 + k] = lo;
+    }
+  }
+}
+
+int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream) {
+  if (njobs <= 0) return MIMO_OK;
+  const int gx = max(1, min(ceil_div(max_total, 256 * 8), 256));
+  hipLaunchKernelGGL(pack_jobs_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev, params);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
 int pack_weights_bf16x3_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
                                const int* row_map, const int* col_map, int transposed, hipStream_t stream) {
   const int nchunks = ceil_div(cols, 32);

@@ -196,6 +196,10 @@ struct mimo_plan {
   std::vector<float*> g_masks;
   std::vector<const float*> g_mask_ptrs;
 
+  // weight repack job tables (device): [0, n_fwd_jobs) forward packs (+ bias copies), then the data-gradient packs
+  PackJob* pack_jobs = nullptr;
+  int n_fwd_jobs = 0, n_all_jobs = 0, pack_max_total = 0;
+
   // per-call state
   bool fwd_done = false, fwd_training = false, had_perm = false, loss_done = false, bwd_stage0_done = false;
   bool fwd_no_grad = false;       // last forward folded BN/ReLU into the conv epilogue: nothing saved for a backward
@@ -522,6 +526,49 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&s_partial, cap_partial));
     MIMO_TRY(dalloc(&s_sums, cap_sums));
     MIMO_TRY(dalloc(&s_losspart, (size_t)S * 512));
+    // ---- weight repack job tables ----
+    {
+      std::vector<PackJob> jobs, dg;
+      for (auto& dc : dcs)
+        for (ConvBN* L : {&dc->c1, &dc->c2}) {
+          PackJob j{};
+          j.w_off = L->off_w;
+          j.bias_off = L->off_b;
+          j.bias_dst = L->bias_p;
+          j.bias_n = L->Cout;
+          j.cout = L->Cout;
+          j.cin = L->Cin;
+          j.rows_pad = L->cout_pad;
+          j.cols = L->cin_p;
+          j.row_map = L->fwd_row_map;
+          j.col_map = L->cin_map;
+          j.transposed = 0;
+          j.kind = L->fwd_split ? 1 : 0;
+          j.dst = L->fwd_split ? L->wf16 : (void*)L->wf;
+          j.total = L->fwd_split ? ceil_div(j.cols, 32) * 9 * j.rows_pad * 32 : 9 * j.rows_pad * j.cols;
+          jobs.push_back(j);
+          PackJob d{};
+          d.w_off = L->off_w;
+          d.bias_n = 0;
+          d.cout = L->Cout;
+          d.cin = L->Cin;
+          d.rows_pad = L->dg_rows;
+          d.cols = L->cout_p;
+          d.row_map = L->dg_row_map;
+          d.col_map = L->dg_col_map;
+          d.transposed = 1;
+          d.kind = L->dg_split ? 2 : 0;
+          d.dst = L->dg_split ? L->wd16 : (void*)L->wd;
+          d.total = L->dg_split ? ceil_div(d.cols, 32) * 9 * d.rows_pad * 32 : 9 * d.rows_pad * d.cols;
+          dg.push_back(d);
+        }
+      n_fwd_jobs = (int)jobs.size();
+      jobs.insert(jobs.end(), dg.begin(), dg.end());
+      n_all_jobs = (int)jobs.size();
+      for (auto& j : jobs) pack_max_total = std::max(pack_max_total, j.total);
+      MIMO_TRY(dalloc(&pack_jobs, jobs.size()));
+      MIMO_HIP_CHECK(hipMemcpy(pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+    }
     // hipGraph staging
     const char* ge = getenv("MIMO_HIP_GRAPH");
     graph_enabled = !(ge && atoi(ge) == 0);
@@ -536,20 +583,10 @@ struct mimo_plan {
   }
 
   // ------------------------------------------------------------------ forward ------------
-  int pack_layer(ConvBN& L, bool with_dgrad, hipStream_t st) {
-    const float* w = params + L.off_w;
-    if (L.fwd_split)
-      MIMO_TRY(pack_weights_bf16x3_launch(w, L.wf16, 1, L.Cout, L.Cin, L.cout_pad, L.cin_p, L.fwd_row_map, L.cin_map, 0, st));
-    else
-      MIMO_TRY(pack_weights_launch(w, L.wf, L.Cout, L.Cin, L.cout_pad, L.cin_p, L.fwd_row_map, L.cin_map, 0, st));
-    if (with_dgrad) {
-      if (L.dg_split)
-        MIMO_TRY(pack_weights_bf16x3_launch(w, L.wd16, 0, L.Cout, L.Cin, L.dg_rows, L.cout_p, L.dg_row_map, L.dg_col_map, 1, st));
-      else
-        MIMO_TRY(pack_weights_launch(w, L.wd, L.Cout, L.Cin, L.dg_rows, L.cout_p, L.dg_row_map, L.dg_col_map, 1, st));
-    }
-    MIMO_HIP_CHECK(hipMemcpyAsync(L.bias_p, params + L.off_b, L.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return MIMO_OK;
+  // every layer's forward weight layout (+ bias copy) and, with_dgrad, the transposed data-gradient layout:
+  // one launch over the job table
+  int pack_all(bool with_dgrad, hipStream_t st) {
+    return pack_jobs_launch(pack_jobs, with_dgrad ? n_all_jobs : n_fwd_jobs, pack_max_total, params, st);
   }
 
   int convbn_forward(ConvBN& L, bool training, const float* mask, hipStream_t st) {
@@ -608,10 +645,7 @@ struct mimo_plan {
       Act *sk = dc->src0, *lo = dc->src1;
       MIMO_TRY(upcat_fwd_launch(sk->a, sk->ld, sk->Cp, lo->a, lo->ld, lo->Cp, N, h, w, lo->H, lo->W, dc->in_buf, st));
     }
-    if (need_derive) {
-      MIMO_TRY(pack_layer(dc->c1, training, st));
-      MIMO_TRY(pack_layer(dc->c2, training, st));
-    }
+
     MIMO_TRY(convbn_forward(dc->c1, training, nullptr, st));
     MIMO_TRY(convbn_forward(dc->c2, training, dc->mask, st));
     return MIMO_OK;
@@ -703,6 +737,7 @@ struct mimo_plan {
     elem_masks.assign(1 + S, nullptr);
     if (args->elem_masks)
       for (int i = 0; i <= S; ++i) elem_masks[i] = args->elem_masks[i];
+    if (need_derive) MIMO_TRY(pack_all(training, st));
     for (int s = 0; s < S; ++s)
       MIMO_TRY(pack_input_launch(args->x, args->stride_n, args->stride_s, args->perm, s, N, Ci, H, W, enc_in[s]->in_buf,
                                  Ci_p, st));
@@ -915,10 +950,7 @@ struct mimo_plan {
     for (auto& dc : dcs) dc->out.grad_writes = 0;
     x2cat.grad_writes = 0;
     if (!fwd_training) {  // eval-mode forward skipped the dgrad weight packing
-      for (auto& dc : dcs) {
-        MIMO_TRY(pack_layer(dc->c1, true, st));
-        MIMO_TRY(pack_layer(dc->c2, true, st));
-      }
+      MIMO_TRY(pack_all(true, st));
     }
     const int fp = pad_channels(f);
     for (int s = S - 1; s >= 0; --s) {
