@@ -1,0 +1,30 @@
+"""Opt-in / fallback kernel variants selected by environment variables that the library reads once per
+process: each runs the convolution parity tests (and one golden training step) in a child process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VARIANTS = {
+    "conv_ws_off": {"MIMO_CONV_WS": "0"},               # non-specialised split convolution on every image size
+    "conv_ws_swizzle": {"MIMO_CONV_WS_SWIZZLE": "1"},   # XOR-swizzled 128-byte LDS rows
+    "wgrad_ws_off": {"MIMO_WGRAD_WS": "0"},             # 4-wave weight gradient for 64x64 tiles too
+    "wgrad_split_mode0": {"MIMO_WGRAD_SPLIT_MODE": "0"},
+    "side_stream": {"MIMO_WGRAD_STREAM": "1"},
+    "no_graph": {"MIMO_HIP_GRAPH": "0"},
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_kernel_variant(name):
+    env = dict(os.environ, **VARIANTS[name])
+    sel = ("tests/test_ops_gpu.py::test_conv3x3_forward_dgrad_wgrad "
+           "tests/test_network_gpu.py::test_train_steps_match_reference_golden "
+           "tests/test_network_gpu.py::test_mc_dropout_ensemble_golden").split()
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "split16 or mc_dropout", *sel],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
