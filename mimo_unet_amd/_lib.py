@@ -40,7 +40,7 @@ class ForwardArgs(C.Structure):
 
 
 LOSS_KINDS = {"laplace_nll": 0, "gaussian_nll": 1}
-PRECISIONS = {"fp32": 0, "split16": 1}
+PRECISIONS = {"fp32": 0, "split16": 1, "bf16": 2}
 
 _lib = None
 

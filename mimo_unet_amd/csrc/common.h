@@ -59,8 +59,9 @@ struct ConvLaunch {
 // returns number of partial-stat rows (spatial blocks) through *rows when stats != nullptr
 int conv3x3_launch(const ConvLaunch& a, int* rows, hipStream_t stream);
 // split 16-bit variant (conv_bf16x3.hip): same ConvLaunch, reads a.wpk instead of a.w.
-// f16 = 1: fp16 hi/lo (forward, fp32-class products); f16 = 0: bf16 hi/lo (gradients)
-int conv3x3_bf16x3_launch(const ConvLaunch& a, int f16, int* rows, hipStream_t stream);
+// mode 0: split16 data gradient (bf16 pairs, pre-split input); 1: split16 forward (fp16 pairs);
+// 2: bf16 forward (one MFMA per product); 3: bf16 data gradient
+int conv3x3_bf16x3_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t stream);
 int pack_weights_bf16x3_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
                                const int* row_map, const int* col_map, int transposed, hipStream_t stream);
 int conv3x3_pick_nfrag(int cout);            // fragments (of 16 output channels) per workgroup
@@ -81,6 +82,7 @@ struct WgradLaunch {
   int cin_p, cout_p;      // valid channel extents in x / dz (multiples of 4)
   int cin_pad, cout_pad;  // multiples of 32
   int splits;
+  int np = 3;  // split kernels: MFMAs per product block — 3 (hi/lo pairs, fp32-class) or 1 (bf16 compute)
 };
 int wgrad_launch(const WgradLaunch& a, hipStream_t stream);
 // split-bf16 variant (wgrad_split.hip): cin_pad / cout_pad must be multiples of its (CI, CO) tile

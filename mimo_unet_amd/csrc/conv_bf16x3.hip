@@ -53,6 +53,18 @@ __device__ __forceinline__ f32x4_ mfma16(Elem<true>::V8 a, Elem<true>::V8 b, f32
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 constexpr float kF16WeightScale = 256.f;  // 2^8, exact
+
+// Kernel modes (template parameter MODE of the convolution kernels and launchers):
+//   0  split16 data gradient : bf16 (hi, lo) pairs, input pre-split (dz),       3 MFMAs per product
+//   1  split16 forward       : fp16 (hi, lo) pairs, fp32 input split on the way, 3 MFMAs per product
+//   2  bf16 forward          : bf16 hi only,        fp32 input rounded on the way, 1 MFMA per product
+//   3  bf16 data gradient    : bf16 hi only,        input pre-split (lo ignored),  1 MFMA per product
+// (modes 2 / 3 = mimo_precision BF16: "bf16 compute, fp32 accumulate"; the LDS rows keep the
+// [hi 32 | lo 32] image and simply leave the lo half unused)
+#define MIMO_CONV_MODE_CONSTANTS                                                    \
+  constexpr bool F16 = MODE == 1;              /* element type fp16 (else bf16) */   \
+  constexpr bool CVT = MODE == 1 || MODE == 2; /* loader converts fp32 input */      \
+  constexpr int NP = MODE >= 2 ? 1 : 3;        /* MFMAs per product block */
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -88,8 +100,9 @@ struct TileCfg {
   static constexpr int MAXPIX = MF == 4 ? 640 : 360;
 };
 
-template <int MF, int NF, bool F16>
+template <int MF, int NF, int MODE>
 __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX) {
+  MIMO_CONV_MODE_CONSTANTS
   typedef typename Elem<F16>::T ET;
   typedef typename Elem<F16>::V8 bf16x8;
   typedef typename Elem<F16>::V4 bf16x4;
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
     const int p_ = min(u_ >> 3, npix_lds - 1), q_ = u_ & 7;                                     \
     const int o_ = goff[p_];                                                                    \
     /* masked-out units are loaded from kZeroPage (common.h), never selected after the load */   \
-    if (F16) { /* fp32 input: unit q_ = 4 channels */                                           \
+    if (CVT) { /* fp32 input: unit q_ = 4 channels */                                           \
       const int ch_ = (CHUNK) * 32 + 4 * q_;                                                    \
       const bool ok_ = o_ >= 0 && ch_ < a.cin_p;                                                \
       xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg + o_ + ch_ : kZeroPage);            \
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
     const int p_ = u_ >> 3, q_ = u_ & 7;                                                        \
     if (p_ < npix_lds) {                                                                        \
       const f32x4 v_ = xreg[k_];                                                                \
-      if (F16) {                                                                                \
+      if (CVT) {                                                                                \
         bf16x4 hi_, lo_;                                                                        \
         hi_[0] = (ET)v_[0];                                                                     \
         hi_[1] = (ET)v_[1];                                                                     \
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
         lo_[3] = (ET)(v_[3] - (float)hi_[3]);                                                   \
         unsigned char* d_ = xs + p_ * kPitchB + q_ * 8;                                         \
         *reinterpret_cast<bf16x4*>(d_) = hi_;                                                   \
-        *reinterpret_cast<bf16x4*>(d_ + 64) = lo_;                                              \
+        if (NP == 3) *reinterpret_cast<bf16x4*>(d_ + 64) = lo_;                                 \
       } else { /* the row image [hi 32 | lo 32] is the global layout: plain 16-byte copy */     \
         *reinterpret_cast<f32x4*>(xs + p_ * kPitchB + q_ * 16) = v_;                            \
       }                                                                                         \
@@ -255,16 +268,19 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
           bh[nf] = *reinterpret_cast<const bf16x8*>(wb + (kw * NB + nf * 16) * kPitchB);
-          bl[nf] = *reinterpret_cast<const bf16x8*>(wb + (kw * NB + nf * 16) * kPitchB + 64);
+          if (NP == 3) bl[nf] = *reinterpret_cast<const bf16x8*>(wb + (kw * NB + nf * 16) * kPitchB + 64);
         }
 #pragma unroll
         for (int m = 0; m < MF; ++m) {
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xs + pbase[m] + toff);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(xs + pbase[m] + toff + 64);
+          bf16x8 al = ah;
+          if (NP == 3) al = *reinterpret_cast<const bf16x8*>(xs + pbase[m] + toff + 64);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) {
-            acc[m][nf] = mfma16(al, bh[nf], acc[m][nf]);
-            acc[m][nf] = mfma16(ah, bl[nf], acc[m][nf]);
+            if (NP == 3) {
+              acc[m][nf] = mfma16(al, bh[nf], acc[m][nf]);
+              acc[m][nf] = mfma16(ah, bl[nf], acc[m][nf]);
+            }
             acc[m][nf] = mfma16(ah, bh[nf], acc[m][nf]);
           }
         }
@@ -362,9 +378,10 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
 // ---------------------------------------------------------------------------------------
 constexpr int kWsNPix = 256, kWsMaxPix = 360, kWsMF = 4;
 
-template <int NF, bool F16, bool SWZ>
+template <int NF, int MODE, bool SWZ>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX,
                                                             int numTiles) {
+  MIMO_CONV_MODE_CONSTANTS
   typedef typename Elem<F16>::T ET;
   typedef typename Elem<F16>::V8 bf16x8;
   typedef typename Elem<F16>::V4 bf16x4;
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
       }                                                                                              \
       const int q_ = (ptid + k_ * 256) & 7;                                                          \
       const int o_ = in_ ? (iy_ * a.Wi + ix_) * a.ldx : 0;                                           \
-      if (F16) {                                                                                     \
+      if (CVT) {                                                                                     \
         const int ch_ = ck_ * 32 + 4 * q_;                                                           \
         const bool ok_ = in_ && ch_ < a.cin_p;                                                       \
         xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg_ + o_ + ch_ : kZeroPage);              \
@@ -452,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
       const f32x4 v_ = xreg[k_];                                                                     \
       unsigned char* row_ = xs + (BUF) * XBYTES + p_ * PITCH;                                        \
       const int sx_ = SWZ ? (p_ & 7) : 0; /* slot XOR of this row */                                 \
-      if (F16) {                                                                                     \
+      if (CVT) {                                                                                     \
         bf16x4 hi_, lo_;                                                                             \
         hi_[0] = (ET)v_[0];                                                                          \
         hi_[1] = (ET)v_[1];                                                                          \
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
         lo_[2] = (ET)(v_[2] - (float)hi_[2]);                                                        \
         lo_[3] = (ET)(v_[3] - (float)hi_[3]);                                                        \
         *reinterpret_cast<bf16x4*>(row_ + (((q_ >> 1) ^ sx_) << 4) + (q_ & 1) * 8) = hi_;            \
-        *reinterpret_cast<bf16x4*>(row_ + ((((q_ >> 1) + 4) ^ sx_) << 4) + (q_ & 1) * 8) = lo_;      \
+        if (NP == 3) *reinterpret_cast<bf16x4*>(row_ + ((((q_ >> 1) + 4) ^ sx_) << 4) + (q_ & 1) * 8) = lo_; \
       } else {                                                                                       \
         *reinterpret_cast<f32x4*>(row_ + ((q_ ^ sx_) << 4)) = v_;                                    \
       }                                                                                              \
@@ -572,14 +589,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
   // The order is pinned with sched_group_barriers for the data gradient only: measured 7.9 -> 7.3 ms per
   // step there, but 6.9 -> 7.4 ms for the forward, whose producers carry the fp32 -> fp16 split and share
   // the SIMD's vector issue with the MFMAs (a v_mfma_16x16x32 holds it for 8 of its 16 cycles).
-  constexpr bool PINNED = !F16;
+  constexpr bool PINNED = !CVT;
+  constexpr int RA = NP == 3 ? 2 : 1, RB = NF * RA;  // LDS reads per A fragment / per tap's B fragments
   // register sets: A fragments alternate per 16-pixel fragment m, B fragments per tap
   bf16x8 ah[2], al[2], bh[2][NF], bl[2][NF];
 
 #define C_READ_B(BS, KW)                                                                             \
   _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
     bh[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * PITCH);              \
-    bl[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * PITCH + wlo);        \
+    if (NP == 3) bl[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * PITCH + wlo); \
   }
 #define C_READ_A(AS, KW, M)                                                                          \
   {                                                                                                  \
@@ -587,23 +605,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
       const int row_ = pbase[M] + r_ * TCP + (KW);                                                   \
       const int o_ = row_ * PITCH + ((g ^ (row_ & 7)) << 4);                                         \
       ah[AS] = *reinterpret_cast<const bf16x8*>(xb_ + o_);                                           \
-      al[AS] = *reinterpret_cast<const bf16x8*>(xb_ + (o_ ^ 64));                                    \
+      if (NP == 3) al[AS] = *reinterpret_cast<const bf16x8*>(xb_ + (o_ ^ 64));                       \
     } else {                                                                                         \
       const unsigned char* p_ = xb_ + pbase[M] + (r_ * TCP + (KW)) * PITCH;                          \
       ah[AS] = *reinterpret_cast<const bf16x8*>(p_);                                                 \
-      al[AS] = *reinterpret_cast<const bf16x8*>(p_ + 64);                                            \
+      if (NP == 3) al[AS] = *reinterpret_cast<const bf16x8*>(p_ + 64);                               \
     }                                                                                                \
   }
 #define C_MFMA(AS, BS, M)                                                                            \
   _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
-    acc[M][nf] = mfma16(al[AS], bh[BS][nf], acc[M][nf]);                                             \
-    acc[M][nf] = mfma16(ah[AS], bl[BS][nf], acc[M][nf]);                                             \
+    if (NP == 3) {                                                                                   \
+      acc[M][nf] = mfma16(al[AS], bh[BS][nf], acc[M][nf]);                                           \
+      acc[M][nf] = mfma16(ah[AS], bl[BS][nf], acc[M][nf]);                                           \
+    }                                                                                                \
     acc[M][nf] = mfma16(ah[AS], bh[BS][nf], acc[M][nf]);                                             \
   }
 #define C_PIN(NREADS)                                                                                \
   if (PINNED) {                                                                                      \
     __builtin_amdgcn_sched_group_barrier(0x100, (NREADS), 0); /* DS reads issued ahead */            \
-    __builtin_amdgcn_sched_group_barrier(0x008, 3 * NF, 0);   /* MFMAs of the current fragment */    \
+    __builtin_amdgcn_sched_group_barrier(0x008, NP * NF, 0);  /* MFMAs of the current fragment */    \
   }
   // one tap: fragment m+1 (or fragment 0 of the next tap, with that tap's B set) is read under the
   // MFMAs of fragment m; LAST = last tap of the phase (its fragment 3 is multiplied after the barrier)
@@ -614,17 +634,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
       C_READ_B((BS) ^ 1, (KW) + 1)                                                                   \
     }                                                                                                \
     C_MFMA(0, BS, 0)                                                                                 \
-    C_PIN((LAST) ? 2 : 2 + 2 * NF)                                                                   \
+    C_PIN((LAST) ? RA : RA + RB)                                                                     \
     C_READ_A(0, KW, 2)                                                                               \
     C_MFMA(1, BS, 1)                                                                                 \
-    C_PIN(2)                                                                                         \
+    C_PIN(RA)                                                                                        \
     C_READ_A(1, KW, 3)                                                                               \
     C_MFMA(0, BS, 2)                                                                                 \
-    C_PIN(2)                                                                                         \
+    C_PIN(RA)                                                                                        \
     if (!(LAST)) {                                                                                   \
       C_READ_A(0, (KW) + 1, 0)                                                                       \
       C_MFMA(1, BS, 3)                                                                               \
-      C_PIN(2)                                                                                       \
+      C_PIN(RA)                                                                                      \
     }                                                                                                \
   }
   // bias, store, BatchNorm partial sums of tile TI (its accumulators are complete), then clear them
@@ -673,7 +693,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     C_READ_A(0, 0, 0)                                                                                \
     if (!(FIRST)) {                                                                                  \
       C_MFMA(1, P, 3)                                                                                \
-      C_PIN(2 + 2 * NF)                                                                              \
+      C_PIN(RA + RB)                                                                                 \
       if (tile_done) {                                                                               \
         C_EPILOGUE(ti)                                                                               \
         ++ti;                                                                                        \
@@ -731,7 +751,7 @@ static bool conv_ws_enabled() {
 
 int conv3x3_ws_stat_rows(int, int, int) { return 256 * 4; }  // <= 256 persistent workgroups x 4 consumer waves
 
-template <int NF, bool F16>
+template <int NF, int MODE>
 static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   int TR, TC;
   pick_tile_n(a.Ho, a.Wo, kWsNPix, kWsMaxPix, &TR, &TC);
@@ -749,21 +769,21 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   // forward / data gradient per step): the LDS array is not what the consumers wait for.  Opt-in.
   static const bool swz = getenv("MIMO_CONV_WS_SWIZZLE") && atoi(getenv("MIMO_CONV_WS_SWIZZLE")) != 0;
   if (swz)
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, F16, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles);
   else
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, F16, false>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
 
-template <int MF, int NF, bool F16>
+template <int MF, int NF, int MODE>
 static int launch_bf16x3(const ConvLaunch& a, int* rows, hipStream_t stream) {
   int TR, TC;
   pick_tile_n(a.Ho, a.Wo, TileCfg<MF>::NPIX, TileCfg<MF>::MAXPIX, &TR, &TC);
   const int tilesY = ceil_div(a.Ho, TR), tilesX = ceil_div(a.Wo, TC);
   if (rows) *rows = a.N * tilesY * tilesX;
   dim3 grid(a.N * tilesY * tilesX, a.cout_pad / (NF * 16));
-  hipLaunchKernelGGL((conv3x3_bf16x3_kernel<MF, NF, F16>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX);
+  hipLaunchKernelGGL((conv3x3_bf16x3_kernel<MF, NF, MODE>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -771,7 +791,7 @@ static int launch_bf16x3(const ConvLaunch& a, int* rows, hipStream_t stream) {
 // MF = 4 (512-pixel tiles) when the image is large enough to fill them, else 2.
 static bool use_big_tile(int Ho, int Wo) { return Ho * Wo >= 1024; }
 
-template <bool F16>
+template <int MODE>
 static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t stream) {
   const int nfr = a.cout_pad / 16;
   int nf = 4;
@@ -781,35 +801,40 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
   static const bool big_nf2 = getenv("MIMO_CONV_BIGTILE_NF2") && atoi(getenv("MIMO_CONV_BIGTILE_NF2")) != 0;
   if (conv_ws_enabled() && a.Ho * a.Wo >= 256) {
     switch (nf) {
-      case 4: return launch_ws<4, F16>(a, rows, stream);
-      case 3: return launch_ws<3, F16>(a, rows, stream);
-      case 2: return launch_ws<2, F16>(a, rows, stream);
-      default: return launch_ws<1, F16>(a, rows, stream);
+      case 4: return launch_ws<4, MODE>(a, rows, stream);
+      case 3: return launch_ws<3, MODE>(a, rows, stream);
+      case 2: return launch_ws<2, MODE>(a, rows, stream);
+      default: return launch_ws<1, MODE>(a, rows, stream);
     }
   }
   if (use_big_tile(a.Ho, a.Wo) && (nf >= 3 || big_nf2)) {
     switch (nf) {
-      case 4: return launch_bf16x3<4, 4, F16>(a, rows, stream);
-      case 3: return launch_bf16x3<4, 3, F16>(a, rows, stream);
-      case 2: return launch_bf16x3<4, 2, F16>(a, rows, stream);
-      default: return launch_bf16x3<4, 1, F16>(a, rows, stream);
+      case 4: return launch_bf16x3<4, 4, MODE>(a, rows, stream);
+      case 3: return launch_bf16x3<4, 3, MODE>(a, rows, stream);
+      case 2: return launch_bf16x3<4, 2, MODE>(a, rows, stream);
+      default: return launch_bf16x3<4, 1, MODE>(a, rows, stream);
     }
   }
   switch (nf) {
-    case 4: return launch_bf16x3<2, 4, F16>(a, rows, stream);
-    case 3: return launch_bf16x3<2, 3, F16>(a, rows, stream);
-    case 2: return launch_bf16x3<2, 2, F16>(a, rows, stream);
-    default: return launch_bf16x3<2, 1, F16>(a, rows, stream);
+    case 4: return launch_bf16x3<2, 4, MODE>(a, rows, stream);
+    case 3: return launch_bf16x3<2, 3, MODE>(a, rows, stream);
+    case 2: return launch_bf16x3<2, 2, MODE>(a, rows, stream);
+    default: return launch_bf16x3<2, 1, MODE>(a, rows, stream);
   }
 }
 
-// f16 != 0: fp16 hi/lo (forward; weights packed with f16 = 1); else bf16 hi/lo (data gradient)
-int conv3x3_bf16x3_launch(const ConvLaunch& a, int f16, int* rows, hipStream_t stream) {
-  if (!a.wpk || a.ldx % 4 != 0 || a.cout_pad % 16 != 0 || a.Hi < 2 || a.Wi < 2) {
-    set_error("conv3x3 split: bad geometry");
+// mode: see MIMO_CONV_MODE_CONSTANTS (0 split16 dgrad, 1 split16 forward, 2 bf16 forward, 3 bf16 dgrad)
+int conv3x3_bf16x3_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t stream) {
+  if (!a.wpk || a.ldx % 4 != 0 || a.cout_pad % 16 != 0 || a.Hi < 2 || a.Wi < 2 || mode < 0 || mode > 3) {
+    set_error("conv3x3 split: bad geometry or mode");
     return MIMO_ERR_INVALID;
   }
-  return f16 ? conv3x3_split_dispatch<true>(a, rows, stream) : conv3x3_split_dispatch<false>(a, rows, stream);
+  switch (mode) {
+    case 0: return conv3x3_split_dispatch<0>(a, rows, stream);
+    case 1: return conv3x3_split_dispatch<1>(a, rows, stream);
+    case 2: return conv3x3_split_dispatch<2>(a, rows, stream);
+    default: return conv3x3_split_dispatch<3>(a, rows, stream);
+  }
 }
 
 // ---------------------------------------------------------------------------------------

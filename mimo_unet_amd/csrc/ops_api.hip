@@ -73,7 +73,8 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   hipStream_t st = (hipStream_t)stream;
   Temp t;
   const int cout_pad = conv3x3_cout_pad(cout);
-  const bool split = precision == MIMO_PREC_SPLIT16;
+  const bool split = precision == MIMO_PREC_SPLIT16 || precision == MIMO_PREC_BF16;
+  const bool bf16 = precision == MIMO_PREC_BF16;
   float* wf = t.get<float>((size_t)9 * cout_pad * cin_p);
   void* wpk = t.get<uint16_t>((size_t)ceil_div(cin_p, 32) * 9 * cout_pad * 64);
   float* bp = t.get<float>(cout_pad);
@@ -87,7 +88,7 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
     return MIMO_ERR_HIP;
   }
   MIMO_TRY(pack_weights_launch(w, wf, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
-  if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, 1, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
+  if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, bf16 ? 0 : 1, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
   if (bias) MIMO_HIP_CHECK(hipMemcpyAsync(bp, bias, cout * sizeof(float), hipMemcpyDeviceToDevice, st));
   ConvLaunch a;
   a.x = x;
@@ -107,7 +108,7 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   a.wpk = wpk;
   int rows = 0;
   if (split)
-    MIMO_TRY(conv3x3_bf16x3_launch(a, 1, &rows, st));
+    MIMO_TRY(conv3x3_bf16x3_launch(a, bf16 ? 2 : 1, &rows, st));
   else
     MIMO_TRY(conv3x3_launch(a, &rows, st));
   if (stats) {
@@ -125,7 +126,8 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
   hipStream_t st = (hipStream_t)stream;
   Temp t;
   const int rows_pad = conv3x3_cout_pad(cin_p);
-  const bool split = precision == MIMO_PREC_SPLIT16;
+  const bool split = precision == MIMO_PREC_SPLIT16 || precision == MIMO_PREC_BF16;
+  const bool bf16 = precision == MIMO_PREC_BF16;
   float* wdp = t.get<float>((size_t)9 * rows_pad * cout_p);
   void* wpk = t.get<uint16_t>((size_t)ceil_div(cout_p, 32) * 9 * rows_pad * 64);
   int* rm = t.ints(ident_map(rows_pad, cin));
@@ -166,7 +168,7 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
   a.off = 2;
   a.wpk = wpk;
   if (split)
-    MIMO_TRY(conv3x3_bf16x3_launch(a, 0, nullptr, st));
+    MIMO_TRY(conv3x3_bf16x3_launch(a, bf16 ? 3 : 0, nullptr, st));
   else
     MIMO_TRY(conv3x3_launch(a, nullptr, st));
   MIMO_TRY(fold_slice_launch(dxpad, cin_p, 0, dx, cin_p, n, h, wd, cin_p, 0, st));
@@ -179,7 +181,8 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
                           mimo_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   Temp t;
-  const bool split = precision == MIMO_PREC_SPLIT16;
+  const bool split = precision == MIMO_PREC_SPLIT16 || precision == MIMO_PREC_BF16;
+  const bool bf16 = precision == MIMO_PREC_BF16;
   WgradLaunch a;
   a.x = x;
   a.dz = dz;
@@ -215,6 +218,7 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
     }
     MIMO_TRY(split_pairs_launch(dz, dzs, (int64_t)n * h * wd, cout_p, st));
     a.dz = dzs;
+    a.np = bf16 ? 1 : 3;
     MIMO_TRY(wgrad_split_launch(a, st));
   } else {
     MIMO_TRY(wgrad_launch(a, st));

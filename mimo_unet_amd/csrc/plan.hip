@@ -276,7 +276,8 @@ struct mimo_plan {
     L.N = n;
     L.H = h;
     L.W = w;
-    L.wg_split = cfg.precision == MIMO_PREC_SPLIT16;
+    const bool mfma16 = cfg.precision == MIMO_PREC_SPLIT16 || cfg.precision == MIMO_PREC_BF16;
+    L.wg_split = mfma16;
     if (L.wg_split) {
       int CI, CO;
       wgrad_split_tiles(L.cin_p, L.cout_p, &CI, &CO);
@@ -298,8 +299,8 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&L.wd, (size_t)9 * L.dg_rows * L.cout_p));
     MIMO_TRY(dalloc(&L.bias_p, L.cout_pad));
     // split-bf16 MFMA needs a K chunk of 32 channels; the 2..4-channel image conv stays on the fp32 kernel
-    L.fwd_split = cfg.precision == MIMO_PREC_SPLIT16 && L.cin_p >= 16;
-    L.dg_split = cfg.precision == MIMO_PREC_SPLIT16 && L.cout_p >= 16;
+    L.fwd_split = mfma16 && L.cin_p >= 16;
+    L.dg_split = mfma16 && L.cout_p >= 16;
     if (L.wg_split && !L.dg_split) any_mixed_dz = true;
     if (L.fwd_split) {
       uint16_t* q = nullptr;
@@ -543,7 +544,7 @@ struct mimo_plan {
           j.row_map = L->fwd_row_map;
           j.col_map = L->cin_map;
           j.transposed = 0;
-          j.kind = L->fwd_split ? 1 : 0;
+          j.kind = L->fwd_split ? (cfg.precision == MIMO_PREC_BF16 ? 2 : 1) : 0;
           j.dst = L->fwd_split ? L->wf16 : (void*)L->wf;
           j.total = L->fwd_split ? ceil_div(j.cols, 32) * 9 * j.rows_pad * 32 : 9 * j.rows_pad * j.cols;
           jobs.push_back(j);
@@ -620,7 +621,7 @@ struct mimo_plan {
     a.wpk = L.wf16;
     prof_begin(MIMO_PROF_CONV_FWD, st);
     if (L.fwd_split)
-      MIMO_TRY(conv3x3_bf16x3_launch(a, 1, &rows, st));
+      MIMO_TRY(conv3x3_bf16x3_launch(a, cfg.precision == MIMO_PREC_BF16 ? 2 : 1, &rows, st));
     else
       MIMO_TRY(conv3x3_launch(a, &rows, st));
     prof_end(MIMO_PROF_CONV_FWD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
@@ -843,7 +844,7 @@ struct mimo_plan {
       a.wpk = L.wd16;
       prof_begin(MIMO_PROF_CONV_DGRAD, st);
       if (L.dg_split)
-        MIMO_TRY(conv3x3_bf16x3_launch(a, 0, nullptr, st));
+        MIMO_TRY(conv3x3_bf16x3_launch(a, cfg.precision == MIMO_PREC_BF16 ? 3 : 0, nullptr, st));
       else
         MIMO_TRY(conv3x3_launch(a, nullptr, st));
       prof_end(MIMO_PROF_CONV_DGRAD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
@@ -867,6 +868,7 @@ struct mimo_plan {
     wg.cin_pad = L.wg_cin_pad;
     wg.cout_pad = L.wg_cout_pad;
     wg.splits = L.wg_splits;
+    wg.np = cfg.precision == MIMO_PREC_BF16 ? 1 : 3;
     prof_begin(MIMO_PROF_CONV_WGRAD, ws);
     if (L.wg_split)
       MIMO_TRY(wgrad_split_launch(wg, ws));

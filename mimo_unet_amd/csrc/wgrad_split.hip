@@ -49,7 +49,7 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int MI, int NI, int WM, int WN, int WK>
+template <int MI, int NI, int WM, int WN, int WK, int NP>
 __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
   constexpr int CI = 16 * MI * WM, CO = 16 * NI * WN;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
       /* dz is pre-split, per 32-channel chunk [hi rc | lo rc] bf16: unit = 8 channels, 16 bytes */ \
       const int half_ = qq_ / (CO / 8), ch_ = co0 + 8 * (qq_ - half_ * (CO / 8));                   \
       const int rc_ = min(32, a.cout_p - (ch_ & ~31));                                              \
-      const bool ok_ = pix_ < kWgDPix && y_ < a.H && x_ < a.W && ch_ < a.cout_p;                    \
+      const bool ok_ = pix_ < kWgDPix && y_ < a.H && x_ < a.W && ch_ < a.cout_p && (NP == 3 || half_ == 0); \
       const unsigned short* s_ = reinterpret_cast<const unsigned short*>(dimg_ + ((size_t)y_ * a.W + x_) * a.lddz) + \
                                  ((ch_ >> 5) * 64 + half_ * rc_ + (ch_ & 31));                      \
       xd[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
       lo_[e_] = (__bf16)((V)[e_] - (float)hi_[e_]);                                                 \
     }                                                                                               \
     *reinterpret_cast<bf16x4*>(DST) = hi_;                                                          \
-    *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                                            \
+    if (NP == 3) *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                               \
   }
 #define WG_STORE()                                                                                  \
   {                                                                                                 \
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         bh[ni] = tr_read8(d0 + ni * 32, d0 + ni * 32 + 4 * PD);
-        bl[ni] = tr_read8(d0 + ni * 32 + 2 * CO, d0 + ni * 32 + 2 * CO + 4 * PD);
+        if (NP == 3) bl[ni] = tr_read8(d0 + ni * 32 + 2 * CO, d0 + ni * 32 + 2 * CO + 4 * PD);
       }
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
@@ -184,12 +184,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             const bf16x8 ah = tr_read8(a0 + mi * 32, a1 + mi * 32);
-            const bf16x8 al = tr_read8(a0 + mi * 32 + 2 * CI, a1 + mi * 32 + 2 * CI);
+            bf16x8 al = ah;
+            if (NP == 3) al = tr_read8(a0 + mi * 32 + 2 * CI, a1 + mi * 32 + 2 * CI);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
               f32x4 c = acc[kh * 3 + kw][mi][ni];
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ni], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ni], c, 0, 0, 0);
+              if (NP == 3) {
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ni], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ni], c, 0, 0, 0);
+              }
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ni], c, 0, 0, 0);
               acc[kh * 3 + kw][mi][ni] = c;
             }
@@ -255,6 +258,7 @@ constexpr int kWsTR = 2;
 constexpr int kWsAPix = (kWsTR + 2) * kWgTCP;  // 136
 constexpr int kWsDPix = kWsTR * kWgTC;         // 64
 
+template <int NP>
 __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
   // consumer wave = 16 ci x 64 co (MI = 1, NI = 4): an A fragment (re-read for every tap) then feeds 12
   // MFMAs instead of 6 as in a 32x32 arrangement -> 52 instead of 80 transposed LDS reads per 108 MFMAs
@@ -296,7 +300,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       d_r[k] = pix / kWgTC;
       d_c[k] = pix % kWgTC;
       const int ch = co0 + 8 * c8, rc = min(32, a.cout_p - (ch & ~31));  // chunk record [hi rc | lo rc]
-      d_ch[k] = (pix < kWsDPix && ch < a.cout_p) ? (ch >> 5) * 64 + half * rc + (ch & 31) : -1;  // in bf16 units
+      d_ch[k] = (pix < kWsDPix && ch < a.cout_p && (NP == 3 || half == 0)) ? (ch >> 5) * 64 + half * rc + (ch & 31)
+                                                                            : -1;  // in bf16 units
       d_dst[k] = pix < kWsDPix ? ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + half * 2 * CO + c8 * 16 : -1;
     }
     const int H2 = 2 * a.H - 2, W2 = 2 * a.W - 2;
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       lo_[e_] = (__bf16)((V)[e_] - (float)hi_[e_]);                                                 \
     }                                                                                               \
     *reinterpret_cast<bf16x4*>(DST) = hi_;                                                          \
-    *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                                            \
+    if (NP == 3) *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                               \
   }
 #define WS_STORE(XA_, XD_, BUF)                                                                      \
   {                                                                                                 \
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         bh[ni] = tr_read8(d0 + ni * 32, d0 + ni * 32 + 4 * PD);
-        bl[ni] = tr_read8(d0 + ni * 32 + 2 * CO, d0 + ni * 32 + 2 * CO + 4 * PD);
+        if (NP == 3) bl[ni] = tr_read8(d0 + ni * 32 + 2 * CO, d0 + ni * 32 + 2 * CO + 4 * PD);
       }
       // tap-level software pipeline: the 8 transposed reads of tap t+1 are issued before the 12 MFMAs of
       // tap t (LDS latency ~130 cycles vs 192 cycles of MFMA per tap); the sched_group_barriers pin that
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     const unsigned char* a1_ = as_ + row1_ * PA + ((row1_ >> 3) & 1) * 32 + acol;             \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                       \
       ah[SLOT][mi] = tr_read8(a0_ + mi * 32, a1_ + mi * 32);                                  \
-      al[SLOT][mi] = tr_read8(a0_ + mi * 32 + 2 * CI, a1_ + mi * 32 + 2 * CI);                \
+      if (NP == 3) al[SLOT][mi] = tr_read8(a0_ + mi * 32 + 2 * CI, a1_ + mi * 32 + 2 * CI);  \
     }                                                                                         \
   }
       WS_READ_A(0, 0)
@@ -430,13 +435,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
             f32x4 c = acc[t][mi][ni];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t & 1][mi], bh[ni], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1][mi], bl[ni], c, 0, 0, 0);
+            if (NP == 3) {
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t & 1][mi], bh[ni], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1][mi], bl[ni], c, 0, 0, 0);
+            }
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1][mi], bh[ni], c, 0, 0, 0);
             acc[t][mi][ni] = c;
           }
-        if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 4 * MI, 0);      // DS reads of tap t+1
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * MI * NI, 0);                // MFMAs of tap t
+        if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, (NP == 3 ? 4 : 2) * MI, 0);  // DS reads of tap t+1
+        __builtin_amdgcn_sched_group_barrier(0x008, NP * MI * NI, 0);                            // MFMAs of tap t
       }
 #undef WS_READ_A
     }
@@ -517,12 +524,18 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
   const int numTiles = a.N * tilesY * tilesX;
   dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
   if (ws) {
-    hipLaunchKernelGGL(wgrad_split_ws_kernel, grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles);
+    if (a.np == 1)
+      hipLaunchKernelGGL(wgrad_split_ws_kernel<1>, grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles);
+    else
+      hipLaunchKernelGGL(wgrad_split_ws_kernel<3>, grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles);
     MIMO_KERNEL_CHECK();
     return MIMO_OK;
   }
-#define WG_LAUNCH(MI, NI, WM, WN, WK) \
-  hipLaunchKernelGGL((wgrad_split_kernel<MI, NI, WM, WN, WK>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles)
+#define WG_LAUNCH(MI, NI, WM, WN, WK)                                                                                  \
+  if (a.np == 1)                                                                                                       \
+    hipLaunchKernelGGL((wgrad_split_kernel<MI, NI, WM, WN, WK, 1>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles); \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((wgrad_split_kernel<MI, NI, WM, WN, WK, 3>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles)
   const int key = CI * 100 + CO;
   switch (key) {
     case 3232: WG_LAUNCH(2, 2, 1, 1, 4); break;

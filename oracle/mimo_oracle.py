@@ -129,9 +129,55 @@ def init_state(cfg: NetConfig, seed: int) -> Dict[str, Tensor]:
 # --------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------
+_CONV_OPERANDS = "fp32"
+
+
+class conv_operands:
+    """Context manager: ``with conv_operands("bf16"):`` makes every 3x3 convolution round its operands to
+    bf16 — input and weight in the forward, the upstream gradient too in the data / weight gradients —
+    with fp32 accumulation and an fp32 bias: the arithmetic of the engine's MIMO_PREC_BF16 mode (what
+    autocast does to a conv in the reference's ``precision="16-mixed"`` runs, scripts/train/train_ndvi.py:71).
+    No reference fixture pins this mode: it is the pinned fp32 restatement with roundings inserted."""
+
+    def __init__(self, kind: str):
+        assert kind in ("fp32", "bf16")
+        self.kind = kind
+
+    def __enter__(self):
+        global _CONV_OPERANDS
+        self.prev, _CONV_OPERANDS = _CONV_OPERANDS, self.kind
+
+    def __exit__(self, *exc):
+        global _CONV_OPERANDS
+        _CONV_OPERANDS = self.prev
+
+
+class _RoundedConv(torch.autograd.Function):
+    """The engine's MIMO_PREC_BF16 policy per convolution (plan.hip init_convbn): the forward runs on the
+    bf16 MFMA when the padded input has >= 16 channels (C_in > 8), the data gradient when the padded output
+    has >= 16 channels (C_out > 8), the weight gradient always; the other cases stay exact fp32."""
+
+    @staticmethod
+    def forward(ctx, xp, w):
+        r = lambda t: t.bfloat16().float()
+        ctx.save_for_backward(xp, w)
+        return F.conv2d(r(xp), r(w)) if w.shape[1] > 8 else F.conv2d(xp, w)
+
+    @staticmethod
+    def backward(ctx, dz):
+        r = lambda t: t.bfloat16().float()
+        xp, w = ctx.saved_tensors
+        dx = torch.nn.grad.conv2d_input(xp.shape, r(w), r(dz)) if w.shape[0] > 8 else torch.nn.grad.conv2d_input(xp.shape, w, dz)
+        return dx, torch.nn.grad.conv2d_weight(r(xp), w.shape, r(dz))
+
+
 def conv3x3_reflect(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
     """Conv2d(k=3, padding=1, padding_mode='reflect') — components.py:23,26."""
-    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b)
+    xp = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    if _CONV_OPERANDS == "bf16":
+        z = _RoundedConv.apply(xp, w)
+        return z if b is None else z + b[None, :, None, None]
+    return F.conv2d(xp, w, b)
 
 
 def conv_bn_relu(x: Tensor, st: Dict[str, Tensor], conv: str, bn: str, training: bool) -> Tensor:

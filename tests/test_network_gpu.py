@@ -553,3 +553,56 @@ def test_evidential_model_golden(precision):
     assert all(torch.isfinite(t).all() for t in v.values() if isinstance(t, torch.Tensor))
     opt = m.configure_optimizers()["optimizer"]
     opt.step()  # fused Adam over the flat buffer
+
+
+@pytest.mark.parametrize("name", ["cfg1_step.npz", "mini_s2_step.npz"])
+def test_bf16_precision_mode(name):
+    """MIMO_PREC_BF16 (bf16 MFMA operands, fp32 accumulate / storage — SURVEY §8a row U, BASELINE config 4's
+    arithmetic).  The kernels themselves are checked to 2e-6 against rounded-operand references in
+    test_ops_gpu.py.  Here: (a) eval-mode forward against the oracle with the engine's rounding policy
+    (`O.conv_operands("bf16")`): same arithmetic up to fp32 summation order, but a 1e-7 difference can move an
+    activation across a bf16 rounding boundary (4e-3 jump), so the agreement is ~3e-5, not 1e-7; (b) a
+    training step against the fp32 reference golden and the bf16 oracle at bf16 tolerance — training-mode
+    BatchNorm on these tiny batches amplifies the rounding-boundary noise ~400x, which bounds what any
+    bf16 implementation can reproduce."""
+    fx = load_npz(name)
+    cfg = cfg_from_meta(fx["meta"])
+    lr, wd = float(fx["lr"]), float(fx["wd"])
+    image, label, perms = (torch.from_numpy(fx[f"s0/{k}"]) for k in ("image", "label", "perms"))
+    mask = torch.from_numpy(fx["s0/mask"]) if "s0/mask" in fx else None
+    S, N, half = cfg.num_subnetworks, image.shape[0], cfg.out_channels // 2
+    model = build_model(cfg, state_from(fx, "init/"), loss=str(fx["loss_kind"]), lr=lr, wd=wd, T=float(fx["temperature"]),
+                        precision="bf16")
+    # (a) eval forward
+    x = torch.stack([image[perms[s]] for s in range(S)], dim=1)
+    model.eval()
+    with torch.no_grad():
+        p1, p2 = model(x.cuda())
+        with O.conv_operands("bf16"):
+            o16 = O.mimo_unet_forward(cfg, state_from(fx, "init/"), x, training=False)
+        o32 = O.mimo_unet_forward(cfg, state_from(fx, "init/"), x, training=False)
+    hip = torch.cat([p1, p2], dim=2).cpu()
+    e16, e32 = rel_err(hip, o16), rel_err(hip, o32)
+    # (b) training step
+    ts = O.TrainState(cfg=cfg, st=state_from(fx, "init/"), loss_kind=str(fx["loss_kind"]), lr=lr, weight_decay=wd,
+                      loss_buffer=O.LossBuffer(S, float(fx["temperature"]), 10))
+    with O.conv_operands("bf16"):
+        ref = O.train_step(ts, image, label, mask, perms, apply_optimizer=False)
+    model.train()
+    out = model.training_step_with_perms(image.cuda(), label.cuda(), None if mask is None else mask.cuda(), perms.cuda())
+    out["loss"].backward()
+    preds = out["preds"].view(N, S, half, *image.shape[-2:]).cpu()
+    t16, t32 = rel_err(preds, ref["out"][:, :, :half]), rel_err(preds, torch.from_numpy(fx["s0/out"])[:, :, :half])
+    dot = n1 = n2 = 0.0
+    for k, p in model.named_parameters():
+        if is_prebn_bias(k):
+            continue
+        g, r = p.grad.detach().cpu().double(), torch.from_numpy(fx["s0/grad/" + k[len("model."):]]).double()
+        dot, n1, n2 = dot + float((g * r).sum()), n1 + float((g * g).sum()), n2 + float((r * r).sum())
+    cos = dot / (n1 * n2) ** 0.5
+    print(f"bf16 {name}: eval fwd vs bf16 oracle {e16:.2e} (vs fp32 {e32:.2e}); train out vs bf16 oracle {t16:.2e}, "
+          f"vs fp32 golden {t32:.2e}; gradient cosine vs fp32 golden {cos:.4f}")
+    assert e16 < 3e-4 and e16 < e32 and e32 < 2e-2
+    assert t16 < 1e-1 and t32 < 1e-1 and cos > 0.9
+    np.testing.assert_allclose(out["loss"].item(), float(ref["total"]), rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(out["loss"].item(), fx["s0/total"], rtol=5e-2, atol=5e-3)

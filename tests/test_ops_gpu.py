@@ -42,14 +42,15 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "split16"])
+@pytest.mark.parametrize("precision", ["fp32", "split16", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv3x3_forward_dgrad_wgrad(case, precision):
     """fp32: f32-input MFMA (exact fp32 products).  split16: fp16 hi/lo forward (~2^-22 per product),
-    bf16 hi/lo data and weight gradients (~1e-5 per product) -> tolerance 1e-4."""
+    bf16 hi/lo data and weight gradients (~1e-5 per product) -> tolerance 1e-4.  bf16: operands rounded to
+    bf16 (2^-9 each), fp32 accumulation -> 2e-2 of the tensor's scale."""
     L = _lib()
     prec = L.PRECISIONS[precision]
-    tol = TOL if precision == "fp32" else 1e-4
+    tol = {"fp32": TOL, "split16": 1e-4, "bf16": 2e-2}[precision]
     lib = L.load()
     N, H, W, Ci, Co = case
     g = torch.Generator().manual_seed(sum(case))
@@ -90,7 +91,8 @@ def test_conv3x3_forward_dgrad_wgrad(case, precision):
     errs["wgrad"] = rel_err(dwd.cpu(), wr.grad)
     errs["bgrad"] = rel_err(dbd.cpu(), br.grad)
     print("conv", precision, case, {k: f"{v:.2e}" for k, v in errs.items()})
-    bad = {k: v for k, v in errs.items() if not v < (TOL if k in ("bgrad", "sum", "sumsq") else tol)}
+    stat_tol = TOL if precision != "bf16" else 2e-2  # the statistics are sums of the (bf16-product) outputs
+    bad = {k: v for k, v in errs.items() if not v < (TOL if k == "bgrad" else stat_tol if k in ("sum", "sumsq") else tol)}
     assert not bad, bad
 
 
@@ -195,3 +197,40 @@ def test_validation_epilogue(S, kind, use_mask):
     assert rel_err(e.cpu(), epi.sqrt()) < 1e-4 and rel_err(err.cpu(), mean - label) < 1e-5
     for i, name in enumerate(VAL_SCALARS):
         assert abs(sc[i].item() - float(ref[name])) <= 1e-4 * max(abs(float(ref[name])), 1e-3), name
+
+
+@pytest.mark.parametrize("case", [(1, 64, 64, 30, 30), (2, 16, 16, 45, 30), (1, 16, 16, 120, 240), (2, 32, 32, 21, 42),
+                                  (1, 6, 7, 16, 33)], ids=lambda c: "x".join(map(str, c)))
+def test_bf16_conv_kernels_against_rounded_operand_reference(case):
+    """MIMO_PREC_BF16 kernels compute exactly conv(round_bf16(x), round_bf16(w)) (and the matching data /
+    weight gradients with round_bf16(dz)) with fp32 accumulation: 2e-6, not "bf16 tolerance"."""
+    L = _lib()
+    lib = L.load()
+    prec = L.PRECISIONS["bf16"]
+    N, H, W, Ci, Co = case
+    r = lambda t: t.bfloat16().float()
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3.0 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    dz = torch.randn(N, Co, H, W, generator=g)
+    xp = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    z_ref = F.conv2d(r(xp), r(w)) + b[None, :, None, None]
+    xr = x.clone().requires_grad_(True)
+    F.pad(xr, (1, 1, 1, 1), mode="reflect").backward(torch.nn.grad.conv2d_input(xp.shape, r(w), r(dz)))
+    dw_ref = torch.nn.grad.conv2d_weight(r(xp), w.shape, r(dz))
+    cip, cop, st = pad8(Ci), pad8(Co), L.current_stream()
+    xd, wd_, bd, dzd = to_nhwc(x, cip), w.cuda().contiguous(), b.cuda(), to_nhwc(dz, cop)
+    zd = torch.zeros(N, H, W, cop, device="cuda")
+    stats = torch.zeros(2, Co, dtype=torch.float64, device="cuda")
+    dxd = torch.zeros(N, H, W, cip, device="cuda")
+    dwd, dbd = torch.zeros(Co, Ci, 3, 3, device="cuda"), torch.zeros(Co, device="cuda")
+    L.check(lib.mimo_op_conv3x3_forward(xd.data_ptr(), wd_.data_ptr(), bd.data_ptr(), zd.data_ptr(), stats.data_ptr(), N, H, W,
+                                        Ci, cip, Co, cop, prec, st))
+    L.check(lib.mimo_op_conv3x3_dgrad(dzd.data_ptr(), wd_.data_ptr(), dxd.data_ptr(), N, H, W, Ci, cip, Co, cop, prec, st))
+    L.check(lib.mimo_op_conv3x3_wgrad(xd.data_ptr(), dzd.data_ptr(), dwd.data_ptr(), dbd.data_ptr(), N, H, W, Ci, cip, Co, cop,
+                                      prec, st))
+    torch.cuda.synchronize()
+    errs = (rel_err(from_nhwc(zd, Co), z_ref), rel_err(from_nhwc(dxd, Ci), xr.grad), rel_err(dwd.cpu(), dw_ref))
+    print("bf16 exact", case, ["%.2e" % e for e in errs])
+    assert max(errs) < 2e-6
