@@ -33,6 +33,10 @@ CONFIGS = {
     # BASELINE.json configs[1]
     "cfg2": dict(name="cfg2: NYUv2-shape synthetic 3->1 ch, 256x256, S=2, fbc=21, laplace_nll, batch 64 per GPU",
                  Ci=3, Co=2, S=2, f=21, H=256, W=256, batch=64),
+    # BASELINE.json configs[3] geometry (S=4 head-width stress; 128 global / 8 GPUs); run with MIMO_PRECISION=bf16
+    # for its arithmetic
+    "cfg4": dict(name="cfg4: synthetic 2->1 ch, 256x256, S=4, fbc=30, laplace_nll, batch 16 per GPU",
+                 Ci=2, Co=2, S=4, f=30, H=256, W=256, batch=16),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the vector rate
 # split16 arithmetic: every algorithmic product is three 16-bit MFMAs (hi.hi + hi.lo + lo.hi), so the
