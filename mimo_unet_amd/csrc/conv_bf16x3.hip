@@ -380,7 +380,7 @@ constexpr int kWsNPix = 256, kWsMaxPix = 360, kWsMF = 4;
 
 template <int NF, int MODE, bool SWZ>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX,
-                                                            int numTiles) {
+                                                            int numTiles, int xcd_order) {
   MIMO_CONV_MODE_CONSTANTS
   typedef typename Elem<F16>::T ET;
   typedef typename Elem<F16>::V8 bf16x8;
@@ -407,7 +407,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
   const int npix_lds = TRP * TCP, npix_out = TR * TC;
   const int co0 = blockIdx.y * NB;
   const int nchunks = (a.cin_p + 31) / 32;
-  const int ntiles_mine = (int)blockIdx.x < numTiles ? (numTiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the 32
+  // workgroups of an XCD take 32 CONSECUTIVE tiles per round — vertically adjacent tile rows, whose halo
+  // rows they share, then meet in one L2 instead of eight
+  const int vbx = (xcd_order && gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8)
+                                                     : (int)blockIdx.x;
+  const int ntiles_mine = vbx < numTiles ? (numTiles - 1 - vbx) / (int)gridDim.x + 1 : 0;
   const int nstages = ntiles_mine * nchunks;  // input-tile stages (tile, chunk); 3 phases each
 
   if (wave >= 4) {
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
   {                                                                                                  \
     const int st_ = (STAGE);                                                                         \
     const int ti_ = st_ / nchunks, ck_ = st_ - ti_ * nchunks;                                        \
-    int t_ = blockIdx.x + ti_ * gridDim.x;                                                           \
+    int t_ = vbx + ti_ * gridDim.x;                                                                  \
     const int tx_ = t_ % tilesX;                                                                     \
     t_ /= tilesX;                                                                                    \
     const int ty_ = t_ % tilesY;                                                                     \
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
   // bias, store, BatchNorm partial sums of tile TI (its accumulators are complete), then clear them
 #define C_EPILOGUE(TI)                                                                               \
   {                                                                                                  \
-    int t_ = blockIdx.x + (TI) * gridDim.x;                                                          \
+    int t_ = vbx + (TI) * gridDim.x;                                                                 \
     const int tx_ = t_ % tilesX;                                                                     \
     t_ /= tilesX;                                                                                    \
     const int ty_ = t_ % tilesY;                                                                     \
@@ -768,10 +773,11 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   // conflict-free swizzled rows measured the same step time as the padded rows (6.97 / 7.20 vs 6.89 / 7.20 ms
   // forward / data gradient per step): the LDS array is not what the consumers wait for.  Opt-in.
   static const bool swz = getenv("MIMO_CONV_WS_SWIZZLE") && atoi(getenv("MIMO_CONV_WS_SWIZZLE")) != 0;
+  static const int xcd = !(getenv("MIMO_CONV_XCD_ORDER") && atoi(getenv("MIMO_CONV_XCD_ORDER")) == 0);
   if (swz)
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd);
   else
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
