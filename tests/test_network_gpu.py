@@ -231,7 +231,7 @@ def _oracle_run(cfg, st, image, label, mask, perms, lb_w, loss, dtype):
     return ts, O.train_step(ts, cast(image), cast(label), cast(mask), perms, apply_optimizer=False)
 
 
-def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, precision="split16"):
+def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, precision="split16", small_net=False):
     """One training step (forward, loss, backward) of the HIP path against the CPU oracle.
 
     Outputs, losses and BatchNorm buffers: 1e-3 relative against the fp32 oracle.
@@ -242,7 +242,9 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, prec
     scripts/diag_grad_noise.py).  The gradient check is therefore anchored on the fp64 oracle:
     the HIP error must stay within the fp32 noise floor measured in the same test
     (rms error <= 1e-3 + 5x the fp32 oracle's rms error, per tensor), and the whole gradient
-    must agree in direction and size (cosine > 0.9999, global rel-L2 < 2e-2)."""
+    must agree in direction and size (cosine > 0.9999, global rel-L2 < 2e-2).  small_net: networks with a
+    handful of channels, where one flipped mask moves every upstream tensor by a few 1e-3 (seen in both
+    precision modes and, smaller, between the fp32 and fp64 oracles): per-tensor floor 5e-3, cosine > 0.9995."""
     g = torch.Generator().manual_seed(seed)
     st = O.init_state(cfg, seed)
     for k in st:  # non-trivial BN affine parameters
@@ -277,7 +279,7 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, prec
         eo = float((ref["grads"][k].double() - g64).norm() / g64.norm())
         if eh > worst[1]:
             worst = (k, eh, eo)
-        assert eh <= 1e-3 + 5.0 * eo, (k, eh, eo)
+        assert eh <= (5e-3 if small_net else 1e-3) + 5.0 * eo, (k, eh, eo)
         dot += float((grads[k] * g64).sum())
         nh += float((grads[k] ** 2).sum())
         nr += float((g64 ** 2).sum())
@@ -286,7 +288,7 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, prec
     print(f"[{precision}] out {e_out:.2e} loss {e_loss:.2e} bn-buffers {e_buf:.2e}; grads vs fp64: cos {cos:.7f} rel-L2 {rel_l2:.2e}; "
           f"worst tensor {worst[0]} hip {worst[1]:.2e} (fp32 oracle {worst[2]:.2e})")
     assert e_out < TOL and e_loss < TOL and e_buf < TOL
-    assert cos > 0.9999 and rel_l2 < 2e-2
+    assert cos > (0.9995 if small_net else 0.9999) and rel_l2 < (3e-2 if small_net else 2e-2)
     return e_out, worst
 
 
@@ -311,6 +313,22 @@ def test_s4_gaussian_vs_oracle():
     e_out, worst = _oracle_vs_hip(O.NetConfig(2, 2, 4, 6), N=3, H=48, W=64, seed=7, loss="gaussian_nll")
     print(f"S4: out err {e_out:.2e}; worst grad {worst}")
     assert e_out < TOL
+
+
+@pytest.mark.parametrize("case", [
+    # (Ci, Co, S, f, N, H, W, loss, mask)  — each exercises a path the BASELINE-shaped cases do not
+    (3, 2, 2, 6, 2, 50, 70, "laplace_nll", True),     # odd sizes: floor pooling + zero F.pad in up-sampling, backward too
+    (2, 2, 3, 5, 2, 100, 100, "laplace_nll", False),  # odd S, odd filter count (channel padding everywhere)
+    (3, 2, 1, 8, 1, 64, 64, "laplace_nll", False),    # batch 1
+    (3, 4, 2, 8, 2, 32, 48, "gaussian_nll", True),    # two targets (Co = 4) with a mask
+    (1, 2, 1, 16, 2, 64, 64, "laplace_nll", False),   # single input channel, S = 1
+    (2, 2, 2, 34, 1, 64, 96, "laplace_nll", False),   # widths 34 / 68 / 136 / 272 / 544: 48-wide tiles, 3 co tiles
+], ids=lambda c: "-".join(map(str, c[:7])))
+def test_more_geometries_vs_oracle(case):
+    Ci, Co, S, f, N, H, W, loss, with_mask = case
+    e_out, worst = _oracle_vs_hip(O.NetConfig(Ci, Co, S, f), N=N, H=H, W=W, seed=sum(case[:7]), loss=loss,
+                                  with_mask=with_mask, small_net=f < 16)
+    print(f"{case}: out err {e_out:.2e}; worst grad {worst}")
 
 
 def test_full_size_properties():
