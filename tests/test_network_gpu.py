@@ -231,7 +231,8 @@ def _oracle_run(cfg, st, image, label, mask, perms, lb_w, loss, dtype):
     return ts, O.train_step(ts, cast(image), cast(label), cast(mask), perms, apply_optimizer=False)
 
 
-def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, precision="split16", small_net=False):
+def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, precision="split16", small_net=False,
+                   repetitions=1, irp=0.0):
     """One training step (forward, loss, backward) of the HIP path against the CPU oracle.
 
     Outputs, losses and BatchNorm buffers: 1e-3 relative against the fp32 oracle.
@@ -255,7 +256,7 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, prec
     image = torch.rand(N, cfg.in_channels, H, W, generator=g)
     label = torch.rand(N, cfg.out_channels // 2, H, W, generator=g)
     mask = (torch.rand(N, 1, H, W, generator=g) > 0.3).float() if with_mask else None
-    perms = O.draw_perms(N, cfg.num_subnetworks, generator=g)
+    perms = O.draw_perms(N, cfg.num_subnetworks, irp, repetitions, generator=g)  # [S, N * repetitions]
     model = build_model(cfg, st, loss=loss, precision=precision)
     model.train()
     lb_w = torch.tensor([0.7 + 0.6 * s / max(cfg.num_subnetworks - 1, 1) for s in range(cfg.num_subnetworks)])
@@ -265,7 +266,7 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, prec
     ts32, ref = _oracle_run(cfg, st, image, label, mask, perms, lb_w, loss, torch.float32)
     _, ref64 = _oracle_run(cfg, st, image, label, mask, perms, lb_w, loss, torch.float64)
     half = cfg.out_channels // 2
-    preds = out["preds"].view(N, cfg.num_subnetworks, half, H, W).cpu()
+    preds = out["preds"].view(N * repetitions, cfg.num_subnetworks, half, H, W).cpu()
     e_out = rel_err(preds, ref["out"][:, :, :half])
     e_loss = abs(out["loss"].item() - float(ref["total"])) / abs(float(ref["total"]))
     sd = model.state_dict()
@@ -329,6 +330,14 @@ def test_more_geometries_vs_oracle(case):
     e_out, worst = _oracle_vs_hip(O.NetConfig(Ci, Co, S, f), N=N, H=H, W=W, seed=sum(case[:7]), loss=loss,
                                   with_mask=with_mask, small_net=f < 16)
     print(f"{case}: out err {e_out:.2e}; worst grad {worst}")
+
+
+def test_batch_repetitions_and_input_repetition_vs_oracle():
+    """apply_input_transform with batch_repetitions = 2 and input_repetition_probability = 0.5 (utils.py:27-48):
+    the transformed batch is 2N wide and half of its rows show every subnetwork the same image."""
+    e_out, worst = _oracle_vs_hip(O.NetConfig(3, 2, 2, 16), N=3, H=48, W=64, seed=11, with_mask=True, repetitions=2, irp=0.5,
+                                  small_net=True)
+    print(f"repetitions: out err {e_out:.2e}; worst grad {worst}")
 
 
 def test_full_size_properties():
