@@ -1,0 +1,47 @@
+"""Derive profiles/<round>/final/pmc_traffic.json (HBM bytes per launch per convolution class, per step in
+total) from the FETCH_SIZE / WRITE_SIZE counter summaries written by scripts/collect_profiles.sh.
+
+    python scripts/pmc_traffic.py profiles/r01/final [steps_executed=3]"""
+import csv
+import json
+import sys
+
+D = sys.argv[1].rstrip("/") + "/"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+
+
+def load(f):
+    return {r["kernel"]: (int(r["dispatches"]), {k: float(v) for k, v in r.items() if k not in ("kernel", "dispatches")})
+            for r in csv.DictReader(open(f))}
+
+
+def cls(k):
+    if "conv3x3_ws_kernel" in k or "conv3x3_bf16x3_kernel" in k:
+        mode = int(k.split("<")[1].split(",")[2 if "bf16x3" in k else 1].strip(" >"))  # MODE template argument
+        return "conv3x3_fwd" if mode in (1, 2) else "conv3x3_dgrad"
+    return "conv3x3_wgrad" if "wgrad_split" in k else None
+
+
+F, W = load(D + "pmc_FETCH_SIZE.csv"), load(D + "pmc_WRITE_SIZE.csv")
+agg, tot_r, tot_w = {}, 0.0, 0.0
+for k, (n, c) in F.items():
+    if "rocclr" in k:
+        continue  # one-off zero fills at plan creation
+    r = c["FETCH_SIZE"] * 1024 * 2  # KB; x2: gfx950 tallies a wide coalesced read at half its bytes
+    w = W.get(k, (0, {"WRITE_SIZE": 0.0}))[1]["WRITE_SIZE"] * 1024
+    tot_r, tot_w = tot_r + r, tot_w + w
+    c_ = cls(k)
+    if c_:
+        a = agg.setdefault(c_, {"launches": 0, "read": 0.0, "write": 0.0})
+        a["launches"] += n
+        a["read"] += r
+        a["write"] += w
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
+                 "--warmup 1 --no-cpu-baseline; FETCH_SIZE in KB x2 (gfx950: a wide coalesced read is tallied at half its "
+                 "bytes, MI355X_MICROARCH.md HBM section), WRITE_SIZE in KB; summed over the executed steps",
+       "steps": steps, "total_gb_per_step": {"read": round(tot_r / steps / 1e9, 2), "write": round(tot_w / steps / 1e9, 2)},
+       "classes": {c_: {"launches_per_step": a["launches"] / steps, "read_bytes_per_launch": round(a["read"] / a["launches"]),
+                        "write_bytes_per_launch": round(a["write"] / a["launches"]),
+                        "bytes_per_launch": round((a["read"] + a["write"]) / a["launches"])} for c_, a in agg.items()}}
+json.dump(out, open(D + "pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
