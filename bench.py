@@ -145,6 +145,7 @@ def main():
     from mimo_unet_amd.ddp import FlatGradientAllReducer
     reducer = FlatGradientAllReducer() if dist is not None else None
     if reducer is not None:
+        reducer.always = force_dist  # one-rank functional check: still issue the RCCL all-reduces
         reducer.attach(model.model)  # all-reduce of the core/decoder gradients overlaps the encoder backward
 
     def step(i):
