@@ -258,11 +258,11 @@ constexpr int kWsTR = 2;
 constexpr int kWsAPix = (kWsTR + 2) * kWgTCP;  // 136
 constexpr int kWsDPix = kWsTR * kWgTC;         // 64
 
-template <int NP>
+template <int NP, int NI>
 __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
-  // consumer wave = 16 ci x 64 co (MI = 1, NI = 4): an A fragment (re-read for every tap) then feeds 12
-  // MFMAs instead of 6 as in a 32x32 arrangement -> 52 instead of 80 transposed LDS reads per 108 MFMAs
-  constexpr int CI = 64, CO = 64, MI = 1, NI = 4;
+  // consumer wave = 16 ci x CO co (MI = 1, NI = CO/16 = 2, 3 or 4): an A fragment (re-read for every tap)
+  // feeds 3*NI MFMAs; at NI = 4, 52 instead of 80 transposed LDS reads per 108 MFMAs of a 32x32 arrangement
+  constexpr int CI = 64, CO = 16 * NI, MI = 1;
   constexpr int PA = wg_pitch(CI), PD = wg_pitch(CO);
   constexpr int QA = CI / 4, QD = CO / 4;
   constexpr int XA = (kWsAPix * QA + 255) / 256, XD = (kWsDPix * QD + 255) / 256;  // per producer thread
@@ -475,15 +475,19 @@ static int pick_ctile(int c_p) {
   const int p64 = round_up(c_p, 64), p48 = round_up(c_p, 48);
   return (double)p48 <= 0.70 * p64 ? 48 : 64;
 }
+static bool wgrad_ws_enabled() {
+  static const bool on = !(getenv("MIMO_WGRAD_WS") && atoi(getenv("MIMO_WGRAD_WS")) == 0);
+  return on;
+}
 void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO) {
   *CI = pick_ctile(cin_p);
   *CO = pick_ctile(cout_p);
+  // the wave-specialised kernel (64 input channels per workgroup) also comes 32 and 48 output channels wide
+  // and keeps its efficiency there: take the 48-wide tile whenever it saves >= 15 % of padded work
+  if (*CI == 64 && wgrad_ws_enabled() && cout_p > 32 && round_up(cout_p, 48) <= 0.85 * round_up(cout_p, 64)) *CO = 48;
 }
 
-static bool wgrad_use_ws(int CI, int CO) {
-  static const bool on = !(getenv("MIMO_WGRAD_WS") && atoi(getenv("MIMO_WGRAD_WS")) == 0);
-  return on && CI == 64 && CO == 64;
-}
+static bool wgrad_use_ws(int CI, int CO) { return wgrad_ws_enabled() && CI == 64 && (CO == 32 || CO == 48 || CO == 64); }
 
 int wgrad_split_num_tiles(int N, int H, int W, int tr) { return N * ceil_div(H, tr) * ceil_div(W, kWgTC); }
 
@@ -524,10 +528,17 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
   const int numTiles = a.N * tilesY * tilesX;
   dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
   if (ws) {
-    if (a.np == 1)
-      hipLaunchKernelGGL(wgrad_split_ws_kernel<1>, grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles);
-    else
-      hipLaunchKernelGGL(wgrad_split_ws_kernel<3>, grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles);
+#define WS_LAUNCH(NI_)                                                                                          \
+  if (a.np == 1)                                                                                                \
+    hipLaunchKernelGGL((wgrad_split_ws_kernel<1, NI_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \
+  else                                                                                                          \
+    hipLaunchKernelGGL((wgrad_split_ws_kernel<3, NI_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles)
+    switch (CO) {
+      case 32: WS_LAUNCH(2); break;
+      case 48: WS_LAUNCH(3); break;
+      default: WS_LAUNCH(4); break;
+    }
+#undef WS_LAUNCH
     MIMO_KERNEL_CHECK();
     return MIMO_OK;
   }
