@@ -196,6 +196,18 @@ struct mimo_plan {
   std::vector<float*> g_masks;
   std::vector<const float*> g_mask_ptrs;
 
+  // MIMO_SUBNET_STREAMS=1 (opt-in, forward only): the S private encoder / decoder chains are independent until
+  // the concat / after the core, so they are issued on S streams — one chain's bandwidth-bound BatchNorm /
+  // gather kernels then run beside another chain's matrix-pipe-bound convolution (+1.5 % images/s at cfg3).
+  // Per-stream copies of the scratch the chains would otherwise share.  Off by default because the
+  // per-kernel HIP-event durations the roofline is computed from become overlapped durations.
+  bool subnet_streams = false, capturing = false;
+  std::vector<hipStream_t> sub_streams;       // [S]; [0] unused (the caller's stream)
+  std::vector<hipEvent_t> sub_join;           // [S]
+  hipEvent_t sub_fork = nullptr;
+  std::vector<float*> set_partial;            // [S] forward partial-statistics rows
+  std::vector<double*> set_sums;              // [S]
+
   // weight repack job tables (device): [0, n_fwd_jobs) forward packs (+ bias copies), then the data-gradient packs
   PackJob* pack_jobs = nullptr;
   int n_fwd_jobs = 0, n_all_jobs = 0, pack_max_total = 0;
@@ -225,6 +237,11 @@ struct mimo_plan {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     if (wg_stream) (void)hipStreamDestroy(wg_stream);
+    for (hipStream_t t : sub_streams)
+      if (t) (void)hipStreamDestroy(t);
+    for (hipEvent_t e : sub_join)
+      if (e) (void)hipEventDestroy(e);
+    if (sub_fork) (void)hipEventDestroy(sub_fork);
     for (hipEvent_t e : {ev_dz[0], ev_dz[1], ev_wg[0], ev_wg[1], ev_join})
       if (e) (void)hipEventDestroy(e);
   }
@@ -526,6 +543,23 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&s_wslab, cap_slab));
     MIMO_TRY(dalloc(&s_partial, cap_partial));
     MIMO_TRY(dalloc(&s_sums, cap_sums));
+    {
+      const char* se = getenv("MIMO_SUBNET_STREAMS");
+      subnet_streams = se && atoi(se) != 0 && S > 1;
+      set_partial.assign(S, s_partial);
+      set_sums.assign(S, s_sums);
+      sub_streams.assign(S, nullptr);
+      sub_join.assign(S, nullptr);
+      if (subnet_streams) {
+        MIMO_HIP_CHECK(hipEventCreateWithFlags(&sub_fork, hipEventDisableTiming));
+        for (int i = 1; i < S; ++i) {
+          MIMO_TRY(dalloc(&set_partial[i], cap_partial));
+          MIMO_TRY(dalloc(&set_sums[i], cap_sums));
+          MIMO_HIP_CHECK(hipStreamCreateWithFlags(&sub_streams[i], hipStreamNonBlocking));
+          MIMO_HIP_CHECK(hipEventCreateWithFlags(&sub_join[i], hipEventDisableTiming));
+        }
+      }
+    }
     MIMO_TRY(dalloc(&s_losspart, (size_t)S * 512));
     // ---- weight repack job tables ----
     {
@@ -699,7 +733,9 @@ struct mimo_plan {
       ga.drop_masks = args->drop_masks ? g_mask_ptrs.data() : nullptr;
       ga.out = g_out;
       MIMO_HIP_CHECK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+      capturing = true;
       const int rc = forward_impl(&ga, cap_stream);
+      capturing = false;
       hipGraph_t graph = nullptr;
       const hipError_t ce = hipStreamEndCapture(cap_stream, &graph);
       if (rc != MIMO_OK) {
@@ -724,6 +760,28 @@ struct mimo_plan {
     return MIMO_OK;
   }
 
+  // ---- S independent chains on S streams (subnet_streams) ----
+  int fork_streams(hipStream_t st) {
+    MIMO_HIP_CHECK(hipEventRecord(sub_fork, st));
+    for (int i = 1; i < S; ++i) MIMO_HIP_CHECK(hipStreamWaitEvent(sub_streams[i], sub_fork, 0));
+    return MIMO_OK;
+  }
+  // the stream chain s is issued on; also switches the scratch that chain uses
+  hipStream_t chain_stream(bool fork, int s, hipStream_t st) {
+    s_partial = set_partial[fork ? s : 0];
+    s_sums = set_sums[fork ? s : 0];
+    return fork && s > 0 ? sub_streams[s] : st;
+  }
+  int join_streams(hipStream_t st) {
+    for (int i = 1; i < S; ++i) {
+      MIMO_HIP_CHECK(hipEventRecord(sub_join[i], sub_streams[i]));
+      MIMO_HIP_CHECK(hipStreamWaitEvent(st, sub_join[i], 0));
+    }
+    s_partial = set_partial[0];
+    s_sums = set_sums[0];
+    return MIMO_OK;
+  }
+
   int forward_impl(const mimo_forward_args* args, hipStream_t st) {
     if (!params || !bnbuf) {
       set_error("mimo_forward: parameters not bound (mimo_plan_bind)");
@@ -742,8 +800,14 @@ struct mimo_plan {
     for (int s = 0; s < S; ++s)
       MIMO_TRY(pack_input_launch(args->x, args->stride_n, args->stride_s, args->perm, s, N, Ci, H, W, enc_in[s]->in_buf,
                                  Ci_p, st));
-    for (int s = 0; s < S; ++s) MIMO_TRY(dc_forward(enc_in[s], training, st));
-    for (int s = 0; s < S; ++s) MIMO_TRY(dc_forward(down1[s], training, st));
+    const bool fork = subnet_streams && !capturing;
+    if (fork) MIMO_TRY(fork_streams(st));
+    for (int s = 0; s < S; ++s) {  // chain by chain, so that the chains' kernels interleave on the device
+      hipStream_t ss = chain_stream(fork, s, st);
+      MIMO_TRY(dc_forward(enc_in[s], training, ss));
+      MIMO_TRY(dc_forward(down1[s], training, ss));
+    }
+    if (fork) MIMO_TRY(join_streams(st));
     MIMO_TRY(dc_forward(down2, training, st));
     MIMO_TRY(dc_forward(down3, training, st));
     MIMO_TRY(dc_forward(down4, training, st));
@@ -754,7 +818,10 @@ struct mimo_plan {
     MIMO_TRY(dc_forward(up1, training, st));
     MIMO_TRY(dc_forward(up2, training, st));
     MIMO_TRY(dc_forward(up3, training, st));
+    if (fork) MIMO_TRY(fork_streams(st));
     for (int s = 0; s < S; ++s) {
+      hipStream_t st_main = st;
+      hipStream_t st = chain_stream(fork, s, st_main);  // this chain's stream for the rest of the body
       MIMO_TRY(dc_forward(up4[s], training, st));
       const Act& o = up4[s]->out;
       // final_dropouts[s]: in place, the head (forward and weight gradient) is the only reader
@@ -762,6 +829,7 @@ struct mimo_plan {
       MIMO_TRY(head_fwd_launch(o.a, o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co, N, S, s, H * W,
                                args->out, st));
     }
+    if (fork) MIMO_TRY(join_streams(st));
     out = args->out;
     fwd_done = true;
     fwd_training = training;
