@@ -17,3 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def built_library():
+    """libmimo_hip.so next to the package; built with `make` (hipcc cross-compiles gfx950 without a GPU) when a
+    fresh checkout has not been through __graft_entry__.build() yet."""
+    so = os.path.join(ROOT, "mimo_unet_amd", "libmimo_hip.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.run(["make", "-j4"], cwd=ROOT, check=True, capture_output=True)
+    return so

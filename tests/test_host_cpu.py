@@ -14,7 +14,7 @@ from tests.helpers import free_port, load_npz
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_exports_every_declared_symbol():
+def test_library_exports_every_declared_symbol(built_library):
     from mimo_unet_amd import _lib
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "mimo_hip.h")).read()
