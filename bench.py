@@ -192,6 +192,11 @@ def main():
                          "ms_per_step": round(r["ms"] / args.steps, 3), "tflops": round(r["flops"] / sec / 1e12, 2),
                          "algorithmic_gbs": round(r["bytes"] / sec / 1e9, 1),
                          "algorithmic_bytes_per_launch": int(r["bytes"] / r["launches"])}
+    # bandwidth-class kernels (HBM roofline) are reported next to the convolution classes (MFMA roofline)
+    bw_kernels = {k: kernels.pop(k) for k in list(kernels) if not k.startswith("conv3x3")}
+    for v in bw_kernels.values():
+        v["hbm_frac"] = round(v["algorithmic_gbs"] / HBM_PEAK_GBS, 4)
+        del v["tflops"]
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     precision = os.environ.get("MIMO_PRECISION", "split16")
     peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "split16": SPLIT16_PEAK_TFLOPS, "bf16": 2500.0}[precision]
@@ -205,7 +210,10 @@ def main():
                                "bf16": "bf16 MFMA operands (one MFMA per product), fp32 accumulate and storage — reduced "
                                        "precision, NOT the fp32 metric"}[precision],
                 "hbm_frac_algorithmic": round(kernels[dom]["algorithmic_gbs"] / HBM_PEAK_GBS, 4),
-                "conv_ms_per_step": round(sum(k["ms_per_step"] for k in kernels.values()), 2), "kernels": kernels}
+                "conv_ms_per_step": round(sum(k["ms_per_step"] for k in kernels.values()), 2), "kernels": kernels,
+                # the bandwidth class, priced against HBM (8000 GB/s): algorithmic bytes (8 or 12 B per element of the
+                # BatchNorm passes) / HIP-event time of the same timed region
+                "bandwidth_kernels": {"peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": bw_kernels}}
     line = {
         "metric": "train images/sec at 256x256, S=2, fbc=30" if args.config == "cfg3" else f"train images/sec ({args.config})",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -148,7 +148,15 @@ int64_t mimo_plan_encoder_param_floats(const mimo_plan* plan);
  * recorded on the launch stream around every 3x3 convolution launch, with the ALGORITHMIC
  * flops (2*9*Cin*Cout*N*H*W, logical channels) and bytes ((Cin+Cout)*N*H*W*4) of those
  * launches.  mimo_plan_profile(plan, 1) resets and arms; reads synchronise on the events. */
-enum mimo_prof_kind { MIMO_PROF_CONV_FWD = 0, MIMO_PROF_CONV_DGRAD = 1, MIMO_PROF_CONV_WGRAD = 2, MIMO_PROF_KINDS = 3 };
+enum mimo_prof_kind {
+  MIMO_PROF_CONV_FWD = 0,
+  MIMO_PROF_CONV_DGRAD = 1,
+  MIMO_PROF_CONV_WGRAD = 2,
+  MIMO_PROF_BN_RELU_FWD = 3,   /* bandwidth class: BatchNorm + ReLU forward pass (8 B per element) */
+  MIMO_PROF_BN_BWD_REDUCE = 4, /* BatchNorm backward pass 1 (8 B per element) */
+  MIMO_PROF_BN_BWD_APPLY = 5,  /* BatchNorm backward pass 2 (12 B per element) */
+  MIMO_PROF_KINDS = 6
+};
 int mimo_plan_profile(mimo_plan* plan, int enable);
 int mimo_plan_profile_read(mimo_plan* plan, int kind, double* total_ms, int64_t* launches, double* flops,
                            double* bytes);

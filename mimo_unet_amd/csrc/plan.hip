@@ -147,8 +147,8 @@ struct mimo_plan {
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
-  double prof_ms[MIMO_PROF_KINDS] = {0, 0, 0}, prof_flops[MIMO_PROF_KINDS] = {0, 0, 0}, prof_bytes[MIMO_PROF_KINDS] = {0, 0, 0};
-  int64_t prof_launches[MIMO_PROF_KINDS] = {0, 0, 0};
+  double prof_ms[MIMO_PROF_KINDS] = {}, prof_flops[MIMO_PROF_KINDS] = {}, prof_bytes[MIMO_PROF_KINDS] = {};
+  int64_t prof_launches[MIMO_PROF_KINDS] = {};
 
   void prof_begin(int kind, hipStream_t st) {
     if (!prof_on) return;
@@ -666,8 +666,11 @@ struct mimo_plan {
                                       params + L.off_beta, bnbuf + L.off_rm, bnbuf + L.off_rv, cfg.bn_momentum,
                                       cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
     }
-    if (!fused)
+    if (!fused) {
+      prof_begin(MIMO_PROF_BN_RELU_FWD, st);
       MIMO_TRY(bn_relu_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, P, L.H * L.W, st));
+      prof_end(MIMO_PROF_BN_RELU_FWD, 0.0, 8.0 * (double)P * L.cout_p, st);
+    }
     return MIMO_OK;
   }
 
@@ -866,8 +869,10 @@ struct mimo_plan {
                       float* dxpad_out, hipStream_t st) {
     int rows = 0, chunks = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
+    prof_begin(MIMO_PROF_BN_BWD_REDUCE, st);
     MIMO_TRY(bnrelu_bwd_reduce_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd,
                                       mask, L.Cout, L.cout_p, L.N, L.H, L.W, s_partial, &rows, st));
+    prof_end(MIMO_PROF_BN_BWD_REDUCE, 0.0, 8.0 * (double)P * L.cout_p, st);
     MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_p, s_sums, &chunks, st));
     MIMO_TRY(bn_bwd_finalize_launch(s_sums, chunks, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
                                     grads + L.off_gamma, grads + L.off_beta, st));
@@ -877,8 +882,10 @@ struct mimo_plan {
       dz_idx ^= 1;
       if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
     }
+    prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
     MIMO_TRY(bn_bwd_apply_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
                                  L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, L.dg_split ? 1 : 0, s_partial, &rows, st));
+    prof_end(MIMO_PROF_BN_BWD_APPLY, 0.0, 12.0 * (double)P * L.cout_p, st);
     // dz storage: bf16 hi|lo pairs when the data-gradient kernel is the bf16-pair one (then the weight
     // gradient is too); fp32 otherwise, with a split copy for a bf16-pair weight gradient
     const float* dz_wg = dz;

@@ -148,7 +148,7 @@ class Plan:
                                                  L.ptr(dx) or None, L.current_stream()), "mimo_backward_stage")
 
 
-    PROF_KINDS = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad")
+    PROF_KINDS = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "bn_relu_fwd", "bn_bwd_reduce", "bn_bwd_apply")
 
     def profile(self, enable: bool) -> None:
         L.check(self.lib.mimo_plan_profile(self.handle, int(enable)), "mimo_plan_profile")
