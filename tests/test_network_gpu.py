@@ -240,7 +240,7 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, prec
     Gradients: ReLU / max-pool derivatives are discontinuous, so a single mask flip caused by
     1e-7 forward rounding moves a weight gradient by ~1/sqrt(#pixels) of its scale; the
     oracle's own fp32 run differs from its fp64 run by 3e-3..3e-2 on these shapes (measured,
-    scripts/diag_grad_noise.py).  The gradient check is therefore anchored on the fp64 oracle:
+    tests/tools/diag_grad_noise.py).  The gradient check is therefore anchored on the fp64 oracle:
     the HIP error must stay within the fp32 noise floor measured in the same test
     (rms error <= 1e-3 + 5x the fp32 oracle's rms error, per tensor), and the whole gradient
     must agree in direction and size (cosine > 0.9999, global rel-L2 < 2e-2).  small_net: networks with a

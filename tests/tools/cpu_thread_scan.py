@@ -1,6 +1,6 @@
 """How does the CPU oracle's training step scale with threads on this box? (diagnostic)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import mimo_oracle as O
 cfg = O.NetConfig(2, 2, 2, 30)

@@ -1,6 +1,6 @@
 """Diagnostic: HIP (fp32) and oracle (fp32) gradients, each against an fp64 oracle run."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import mimo_oracle as O
 from tests.test_network_gpu import build_model
