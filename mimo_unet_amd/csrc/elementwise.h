@@ -36,7 +36,8 @@ int bn_relu_fwd_launch(const float* z, int ldz, float* a, int lda, const float* 
 
 // ---- pooling / upsampling ---------------------------------------------------------------
 int maxpool_fwd_launch(const float* a, int lda, int N, int H, int W, int Cp, float* out, int ldo, hipStream_t st);
-// out[N,H,W,csp+clp] = cat(skip, zero_pad(bilinear_x2_align_corners(low)))
+// out[N,H,W,csp+clp] = cat(skip, zero_pad(bilinear_x2_align_corners(low))); skip == nullptr: channels [0, csp) of
+// out already hold the skip tensor (its producer writes it in place), only the up-sampled part is written
 int upcat_fwd_launch(const float* skip, int lds, int csp, const float* low, int ldl, int clp, int N, int H, int W,
                      int h, int w, float* out, hipStream_t st);
 

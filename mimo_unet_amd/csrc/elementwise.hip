@@ -385,8 +385,11 @@ __global__ void upcat_fwd_kernel(const float* __restrict__ skip, int lds, int cs
                                  int ldl, int clv, int N, int H, int W, int h, int w, int padT, int padL,
                                  float* __restrict__ out) {
   const int Cv = csv + clv;
-  const PQ t = pixquad(Cv);
+  // skip == nullptr: the skip tensor already lives in channels [0, 4*csv) of `out` (its producer writes it
+  // there); only the up-sampled part is written, and the threads are mapped over those channels alone
+  PQ t = pixquad(skip ? Cv : clv);
   if (!t.active) return;
+  if (!skip) t.q += csv;
   const int ldo = 4 * Cv;
   const int P = N * H * W;
   PixIter it = pix_iter(t.p, t.pstep, H, W);
@@ -421,8 +424,8 @@ int upcat_fwd_launch(const float* skip, int lds, int csp, const float* low, int 
     set_error("upcat: skip smaller than upsampled input");
     return MIMO_ERR_INVALID;
   }
-  hipLaunchKernelGGL(upcat_fwd_kernel, pq_grid(Cv, (int64_t)N * H * W, 4096), dim3(256), 0, st, skip, lds, csp / 4, low,
-                     ldl, clp / 4, N, H, W, h, w, padT, padL, out);
+  hipLaunchKernelGGL(upcat_fwd_kernel, pq_grid(skip ? Cv : clp / 4, (int64_t)N * H * W, 4096), dim3(256), 0, st, skip, lds,
+                     csp / 4, low, ldl, clp / 4, N, H, W, h, w, padT, padL, out);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

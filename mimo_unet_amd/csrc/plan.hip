@@ -85,6 +85,7 @@ struct DoubleConv {
   Act* src1 = nullptr;   // IN_UPCAT: low-resolution tensor
   float* in_buf = nullptr;  // materialised input (packed image / pooled / concat)
   int in_ld = 0;
+  bool skip_in_place = false;  // IN_UPCAT: the skip tensor already lives in channels [0, Cs) of in_buf
   float* mid = nullptr;  // a1
   Act out;               // a2 (+ gradient)
   float drop_p = 0.f;
@@ -397,6 +398,23 @@ struct mimo_plan {
     return MIMO_OK;
   }
 
+  // Skip connections cost no copy: the skip tensor is re-homed into channels [0, Cs) of the concat buffer of
+  // the Up block that consumes it (its producers write it there with the concat's pixel pitch), so the
+  // up-sample + concat kernel only writes the up-sampled channels.  `producers`: the ConvBN layers whose `a`
+  // is (a channel slice of) this tensor, with their channel offsets.
+  void rehome_skip(Act& sk, DoubleConv* up, std::vector<std::pair<DoubleConv*, int>> producers) {
+    sk.a = up->in_buf;
+    sk.ld = up->in_ld;
+    for (auto& pr : producers) {
+      DoubleConv* dc = pr.first;
+      dc->c2.a = up->in_buf + pr.second;
+      dc->c2.ld_a = up->in_ld;
+      dc->out.a = dc->c2.a;
+      dc->out.ld = up->in_ld;
+    }
+    up->skip_in_place = true;
+  }
+
   int set_input(DoubleConv* dc, InputKind kind, Act* s0, Act* s1, int in_cp, int h, int w) {
     dc->kind = kind;
     dc->src0 = s0;
@@ -435,6 +453,7 @@ struct mimo_plan {
               W5 = W4 / 2;
     std::vector<int> imgmap(Ci_p);
     for (int i = 0; i < Ci_p; ++i) imgmap[i] = i < Ci ? i : -1;
+    const bool skip_alias = !(getenv("MIMO_SKIP_IN_PLACE") && atoi(getenv("MIMO_SKIP_IN_PLACE")) == 0);
 
     // ---- encoder (model.py:150-175) ----
     for (int s = 0; s < S; ++s) {
@@ -482,18 +501,25 @@ struct mimo_plan {
       MIMO_TRY(make_dc(&up1, "core.up1.conv.double_conv", m, 16 * f * S, 8 * f * S, 4 * f * S, H4, W4, pc, nullptr, 0,
                        nullptr, 0));
       MIMO_TRY(set_input(up1, IN_UPCAT, &down3->out, &down4->out, (int)m.size(), H4, W4));
+      if (skip_alias) rehome_skip(down3->out, up1, {{down3, 0}});
     }
     {
       std::vector<int> m = cat_map(down2->out, up1->out);
       MIMO_TRY(make_dc(&up2, "core.up2.conv.double_conv", m, 8 * f * S, 4 * f * S, 2 * f * S, H3, W3, pc, nullptr, 0,
                        nullptr, 0));
       MIMO_TRY(set_input(up2, IN_UPCAT, &down2->out, &up1->out, (int)m.size(), H3, W3));
+      if (skip_alias) rehome_skip(down2->out, up2, {{down2, 0}});
     }
     {
       std::vector<int> m = cat_map(x2cat, up2->out);
       MIMO_TRY(make_dc(&up3, "core.up3.conv.double_conv", m, 4 * f * S, 2 * f * S, f * S, H2, W2, pc, nullptr, 0, nullptr,
                        0));
       MIMO_TRY(set_input(up3, IN_UPCAT, &x2cat, &up2->out, (int)m.size(), H2, W2));
+      if (skip_alias) {
+        std::vector<std::pair<DoubleConv*, int>> pr;
+        for (int s = 0; s < S; ++s) pr.push_back({down1[s], s * c2p});
+        rehome_skip(x2cat, up3, pr);
+      }
     }
     // ---- decoder (model.py:260-297) ----
     const int cin_dec = f * S + f;
@@ -503,6 +529,7 @@ struct mimo_plan {
       MIMO_TRY(make_dc(&dc, "decoder.up4s." + std::to_string(s) + ".conv.double_conv", m, cin_dec, cin_dec / 2, f, H1, W1,
                        cfg.decoder_dropout_rate, nullptr, 0, nullptr, 0));
       MIMO_TRY(set_input(dc, IN_UPCAT, &enc_in[s]->out, &up3->out, (int)m.size(), H1, W1));
+      if (skip_alias) rehome_skip(enc_in[s]->out, dc, {{enc_in[s], 0}});
       up4.push_back(dc);
     }
     for (int s = 0; s < S; ++s) {
@@ -681,7 +708,8 @@ struct mimo_plan {
       MIMO_TRY(maxpool_fwd_launch(s->a, s->ld, N, s->H, s->W, s->Cp, dc->in_buf, dc->in_ld, st));
     } else if (dc->kind == IN_UPCAT) {
       Act *sk = dc->src0, *lo = dc->src1;
-      MIMO_TRY(upcat_fwd_launch(sk->a, sk->ld, sk->Cp, lo->a, lo->ld, lo->Cp, N, h, w, lo->H, lo->W, dc->in_buf, st));
+      MIMO_TRY(upcat_fwd_launch(dc->skip_in_place ? nullptr : sk->a, sk->ld, sk->Cp, lo->a, lo->ld, lo->Cp, N, h, w, lo->H,
+                                lo->W, dc->in_buf, st));
     }
 
     MIMO_TRY(convbn_forward(dc->c1, training, nullptr, st));
