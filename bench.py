@@ -45,6 +45,16 @@ SPLIT16_PEAK_TFLOPS = 2500.0 / 3.0
 HBM_PEAK_GBS = 8000.0
 
 
+def learnable_label(image, noise=0.05, generator=None):
+    """Synthetic regression target that the image actually predicts: a 5x5-smoothed non-linear mix of the
+    input channels plus uniform noise of known width (so a Laplace/Gaussian NLL has a real optimum instead of
+    the all-noise labels torch.rand gives, where BatchNorm ends up normalising near-constant channels)."""
+    import torch.nn.functional as F
+    mix = 0.6 * image[:, :1] + 0.4 * image[:, -1:] ** 2
+    smooth = F.avg_pool2d(F.pad(mix, (2, 2, 2, 2), mode="reflect"), 5, stride=1)
+    return smooth + noise * (torch.rand(smooth.shape, device=image.device, generator=generator) - 0.5)
+
+
 def make_model(c):
     from mimo.models.mimo_unet import MimoUnetModel
     return MimoUnetModel(in_channels=c["Ci"], out_channels=c["Co"], num_subnetworks=c["S"], filter_base_count=c["f"],
@@ -82,7 +92,7 @@ def cpu_baseline(c, batch=4, steps=2, threads=None):
     ts = O.TrainState(cfg=cfg, st=O.init_state(cfg, 1), loss_buffer=O.LossBuffer(c["S"], 0.3, 10))
     g = torch.Generator().manual_seed(1)
     image = torch.rand(batch, c["Ci"], c["H"], c["W"], generator=g)
-    label = torch.rand(batch, c["Co"] // 2, c["H"], c["W"], generator=g)
+    label = learnable_label(image, generator=g)
     times = []
     for i in range(steps + 1):
         perms = O.draw_perms(batch, c["S"], generator=g)
@@ -139,7 +149,9 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(100 + rank)
     B = c["batch"]
     image = torch.rand(B, c["Ci"], c["H"], c["W"], device="cuda", generator=g)
-    label = torch.rand(B, c["Co"] // 2, c["H"], c["W"], device="cuda", generator=g)
+    # targets the image predicts (see learnable_label): with all-noise labels the NLL's scale head collapses on
+    # single pixels and the loss spikes (reproduced by the fp64 CPU oracle, tests/tools/diag_trained_state.py)
+    label = learnable_label(image, generator=g)
     batch = {"image": image, "label": label}
 
     from mimo_unet_amd.ddp import FlatGradientAllReducer
