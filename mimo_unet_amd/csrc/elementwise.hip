@@ -27,7 +27,10 @@ struct PQ {
   bool active;
 };
 
-__device__ __forceinline__ PQ pixquad(int Cv) {
+// xcd_bands: workgroups are dealt round-robin to the 8 XCDs (each with a private L2); give every XCD one
+// contiguous band of the pixels in flight, so that gathers which re-read neighbouring rows (bilinear
+// backward: every gradient row feeds two input rows) find them in their own L2.
+__device__ __forceinline__ PQ pixquad(int Cv, bool xcd_bands = false) {
   PQ r;
   r.QB = Cv < 256 ? Cv : 256;
   r.PPI = 256 / r.QB;
@@ -35,7 +38,9 @@ __device__ __forceinline__ PQ pixquad(int Cv) {
   r.pl = threadIdx.x / r.QB;
   r.q = blockIdx.y * r.QB + r.ql;
   r.active = r.pl < r.PPI && r.q < Cv;
-  r.p = blockIdx.x * r.PPI + r.pl;
+  int bx = blockIdx.x;
+  if (xcd_bands && (gridDim.x & 7) == 0) bx = (bx & 7) * (gridDim.x >> 3) + (bx >> 3);
+  r.p = bx * r.PPI + r.pl;
   r.pstep = gridDim.x * r.PPI;
   return r;
 }
@@ -145,16 +150,30 @@ int rowsum_launch(const float* partial, int rows, int cols, double* sums, int* c
   return MIMO_OK;
 }
 
-__global__ void vec_finalize_kernel(const double* __restrict__ sums, int chunks, int cols, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// The finalize kernels run 256 threads per 64 columns: four groups each add every fourth chunk row (the
+// serial walk over up to kMaxChunks rows was most of their ~8 us), the group totals are added in fixed order.
+// Every thread of the workgroup must call this; the total is returned to all of them.
+__device__ __forceinline__ double chunk_total(const double* __restrict__ col, size_t stride, int chunks, bool valid,
+                                              double* red) {
   double s = 0.0;
-  for (int k = 0; k < chunks; ++k) s += sums[(size_t)k * cols + c];
-  out[c] = (float)s;
+  if (valid)
+    for (int k = threadIdx.x >> 6; k < chunks; k += 4) s += col[(size_t)k * stride];
+  __syncthreads();
+  red[threadIdx.x] = s;
+  __syncthreads();
+  const int cl = threadIdx.x & 63;
+  return (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
+}
+
+__global__ void vec_finalize_kernel(const double* __restrict__ sums, int chunks, int cols, int C, float* __restrict__ out) {
+  __shared__ double red[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const double s = chunk_total(sums + c, cols, chunks, c < C, red);
+  if (c < C && threadIdx.x < 64) out[c] = (float)s;
 }
 
 int vec_finalize_launch(const double* sums, int chunks, int cols, int C, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(vec_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, sums, chunks, cols, C, out);
+  hipLaunchKernelGGL(vec_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, sums, chunks, cols, C, out);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -216,20 +235,18 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ sums, int chun
                                        float* __restrict__ running_mean, float* __restrict__ running_var,
                                        float momentum, float eps, float* __restrict__ mean, float* __restrict__ invstd,
                                        float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cp) return;
+  __shared__ double red[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int cols = 2 * cout_pad;
+  const double s1 = chunk_total(sums + c, cols, chunks, c < C, red);
+  const double s2 = chunk_total(sums + cout_pad + c, cols, chunks, c < C, red);
+  if (c >= Cp || threadIdx.x >= 64) return;
   if (c >= C) {
     mean[c] = 0.f;
     invstd[c] = 0.f;
     scale[c] = 0.f;
     shift[c] = 0.f;
     return;
-  }
-  double s1 = 0.0, s2 = 0.0;
-  const int cols = 2 * cout_pad;
-  for (int k = 0; k < chunks; ++k) {
-    s1 += sums[(size_t)k * cols + c];
-    s2 += sums[(size_t)k * cols + cout_pad + c];
   }
   const double m = s1 / count;
   double var = s2 / count - m * m;
@@ -249,7 +266,7 @@ int bn_fwd_finalize_launch(const double* sums, int chunks, int cout_pad, int C, 
                            const float* gamma, const float* beta, float* running_mean, float* running_var,
                            float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                            hipStream_t st) {
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, st, sums, chunks, cout_pad, C, Cp,
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(256), 0, st, sums, chunks, cout_pad, C, Cp,
                      (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
@@ -381,6 +398,12 @@ __device__ __forceinline__ Lerp lerp_src(int dst, int in, int out) {
   return r;
 }
 
+// weight with which output index o (of an x2 align_corners upsample of `in` samples) reads input i
+__device__ __forceinline__ float lerp_weight(int o, int i, int in) {
+  const Lerp l = lerp_src(o, in, 2 * in);
+  return (l.i0 == i ? l.l0 : 0.f) + (l.i1 == i ? l.l1 : 0.f);
+}
+
 __global__ void upcat_fwd_kernel(const float* __restrict__ skip, int lds, int csv, const float* __restrict__ low,
                                  int ldl, int clv, int N, int H, int W, int h, int w, int padT, int padL,
                                  float* __restrict__ out) {
@@ -443,38 +466,59 @@ __device__ __forceinline__ float route_max(float g, float v00, float v01, float 
   return arg == self ? g : 0.f;
 }
 
+// One thread owns a 2x2 window: one folded gradient read, the four activations once (not once per
+// window member), four stores.  Rows / columns outside every window (odd H or W) receive no gradient.
 __global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int choff, const float* __restrict__ a,
                                 int lda, float* __restrict__ da, int ldda, int N, int H, int W, int Cv, int accumulate) {
   const PQ t = pixquad(Cv);
   if (!t.active) return;
   const int Hp = H / 2, Wp = W / 2;
-  const int P = N * H * W;
-  PixIter it = pix_iter(t.p, t.pstep, H, W);
-  for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
-    const int n = it.n, y = it.y, x = it.x;
-    float4 v = f4zero();
-    if (y < 2 * Hp && x < 2 * Wp) {
-      const int py = y >> 1, px = x >> 1;
-      const float4 g = fold_read(dxpad, ldp, n, py, px, Hp, Wp, choff + 4 * t.q);
-      const float* src = a + (((size_t)n * H + 2 * py) * W + 2 * px) * lda + 4 * t.q;
-      const float4 v00 = ld4(src), v01 = ld4(src + lda), v10 = ld4(src + (size_t)W * lda), v11 = ld4(src + (size_t)(W + 1) * lda);
-      const int self = (y & 1) * 2 + (x & 1);
-      v.x = route_max(g.x, v00.x, v01.x, v10.x, v11.x, self);
-      v.y = route_max(g.y, v00.y, v01.y, v10.y, v11.y, self);
-      v.z = route_max(g.z, v00.z, v01.z, v10.z, v11.z, self);
-      v.w = route_max(g.w, v00.w, v01.w, v10.w, v11.w, self);
+  const int P = N * Hp * Wp;
+  PixIter it = pix_iter(t.p, t.pstep, Hp, Wp);
+  for (int p = t.p; p < P; p += t.pstep, pix_next(it, Hp, Wp)) {
+    const int n = it.n, py = it.y, px = it.x;
+    const float4 g = fold_read(dxpad, ldp, n, py, px, Hp, Wp, choff + 4 * t.q);
+    const size_t pix = ((size_t)n * H + 2 * py) * W + 2 * px;
+    const float* src = a + pix * lda + 4 * t.q;
+    const float4 v00 = ld4(src), v01 = ld4(src + lda), v10 = ld4(src + (size_t)W * lda), v11 = ld4(src + (size_t)(W + 1) * lda);
+    float* dst = da + pix * ldda + 4 * t.q;
+    float4 r[4];
+#pragma unroll
+    for (int self = 0; self < 4; ++self) {
+      r[self].x = route_max(g.x, v00.x, v01.x, v10.x, v11.x, self);
+      r[self].y = route_max(g.y, v00.y, v01.y, v10.y, v11.y, self);
+      r[self].z = route_max(g.z, v00.z, v01.z, v10.z, v11.z, self);
+      r[self].w = route_max(g.w, v00.w, v01.w, v10.w, v11.w, self);
     }
-    float* dst = da + (size_t)p * ldda + 4 * t.q;
-    if (accumulate) v = f4add(v, ld4(dst));
-    st4(dst, v);
+    float* d4[4] = {dst, dst + ldda, dst + (size_t)W * ldda, dst + (size_t)(W + 1) * ldda};
+    if (accumulate) {
+      float4 o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = ld4(d4[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = f4add(r[j], o[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(d4[j], r[j]);
+    if (!accumulate) {  // odd sizes: the last row / column belongs to no window
+      if ((W & 1) && px == Wp - 1) {
+        st4(dst + 2 * (size_t)ldda, f4zero());
+        st4(dst + (size_t)(W + 2) * ldda, f4zero());
+      }
+      if ((H & 1) && py == Hp - 1) {
+        st4(dst + 2 * (size_t)W * ldda, f4zero());
+        st4(dst + (2 * (size_t)W + 1) * ldda, f4zero());
+        if ((W & 1) && px == Wp - 1) st4(dst + (2 * (size_t)W + 2) * ldda, f4zero());
+      }
+    }
   }
 }
 
 int pool_bwd_launch(const float* dxpad, int ldp, int choff, const float* a, int lda, float* da, int ldda, int N, int H,
                     int W, int Cp, int accumulate, hipStream_t st) {
   const int Cv = Cp / 4;
-  hipLaunchKernelGGL(pool_bwd_kernel, pq_grid(Cv, (int64_t)N * H * W, 4096), dim3(256), 0, st, dxpad, ldp, choff, a, lda,
-                     da, ldda, N, H, W, Cv, accumulate);
+  hipLaunchKernelGGL(pool_bwd_kernel, pq_grid(Cv, (int64_t)N * (H / 2) * (W / 2), 4096), dim3(256), 0, st, dxpad, ldp, choff,
+                     a, lda, da, ldda, N, H, W, Cv, accumulate);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -533,33 +577,58 @@ int elem_mask_mul_launch(float* a, int ld, const float* mask, int N, int C, int 
   return MIMO_OK;
 }
 
-// weight with which output index o (of an x2 align_corners upsample of `in` samples) reads input i
-__device__ __forceinline__ float lerp_weight(int o, int i, int in) {
-  const Lerp l = lerp_src(o, in, 2 * in);
-  return (l.i0 == i ? l.l0 : 0.f) + (l.i1 == i ? l.l1 : 0.f);
-}
-
+// Input pixel i of an x2 align_corners upsample is read by outputs 2i-1 .. 2i+2 only (2i-2 lands on
+// i-2 / i-1 for every size; checked exhaustively for in <= 300 and 512..2048 on the CPU).
 __global__ void up_bwd_kernel(const float* __restrict__ dxpad, int ldp, int choff, float* __restrict__ da, int ldda,
                               int N, int H, int W, int h, int w, int padT, int padL, int Cv, int accumulate) {
-  const PQ t = pixquad(Cv);
+  const PQ t = pixquad(Cv, true);
   if (!t.active) return;
   const int P = N * h * w;
   PixIter it = pix_iter(t.p, t.pstep, h, w);
   for (int p = t.p; p < P; p += t.pstep, pix_next(it, h, w)) {
     const int n = it.n, iy = it.y, ix = it.x;
+    float wy[4], wx[4];
+    int cy[4], cx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int oy = 2 * iy - 1 + k, ox = 2 * ix - 1 + k;
+      wy[k] = (oy >= 0 && oy < 2 * h) ? lerp_weight(oy, iy, h) : 0.f;
+      wx[k] = (ox >= 0 && ox < 2 * w) ? lerp_weight(ox, ix, w) : 0.f;
+      cy[k] = min(max(oy, 0), 2 * h - 1) + padT;
+      cx[k] = min(max(ox, 0), 2 * w - 1) + padL;
+    }
     float4 v = f4zero();
-    for (int oy = max(0, 2 * iy - 2); oy <= min(2 * h - 1, 2 * iy + 2); ++oy) {
-      const float wy = lerp_weight(oy, iy, h);
-      if (wy == 0.f) continue;
-      for (int ox = max(0, 2 * ix - 2); ox <= min(2 * w - 1, 2 * ix + 2); ++ox) {
-        const float wx = lerp_weight(ox, ix, w);
-        if (wx == 0.f) continue;
-        const float4 g = fold_read(dxpad, ldp, n, oy + padT, ox + padL, H, W, choff + 4 * t.q);
-        const float ww = wy * wx;
-        v.x += ww * g.x;
-        v.y += ww * g.y;
-        v.z += ww * g.z;
-        v.w += ww * g.w;
+    if (cy[0] >= 2 && cy[3] <= H - 3 && cx[0] >= 2 && cx[3] <= W - 3) {
+      // none of the 16 candidates receives a reflected border: 16 independent loads, weights 0 where the
+      // candidate does not read this input (adds an exact zero, same sum as skipping it)
+      const float* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + choff + 4 * t.q;
+      float4 g[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[k][j] = ld4(base + ((size_t)(cy[k] + 1) * (W + 2) + (cx[j] + 1)) * ldp);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float ww = wy[k] * wx[j];
+          v.x += ww * g[k][j].x;
+          v.y += ww * g[k][j].y;
+          v.z += ww * g[k][j].z;
+          v.w += ww * g[k][j].w;
+        }
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        if (wy[k] == 0.f) continue;
+        for (int j = 0; j < 4; ++j) {
+          if (wx[j] == 0.f) continue;
+          const float4 g = fold_read(dxpad, ldp, n, cy[k], cx[j], H, W, choff + 4 * t.q);
+          const float ww = wy[k] * wx[j];
+          v.x += ww * g.x;
+          v.y += ww * g.y;
+          v.z += ww * g.z;
+          v.w += ww * g.w;
+        }
       }
     }
     float* dst = da + (size_t)p * ldda + 4 * t.q;
@@ -654,13 +723,11 @@ int bnrelu_bwd_reduce_launch(const float* da, int ldda, const float* dxpad, int 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int chunks, int C, int Cp, double count,
                                        int training, float* __restrict__ c1, float* __restrict__ c2,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cp) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    s1 += sums[(size_t)k * 2 * Cp + c];
-    s2 += sums[(size_t)k * 2 * Cp + Cp + c];
-  }
+  __shared__ double red[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const double s1 = chunk_total(sums + c, (size_t)2 * Cp, chunks, c < Cp, red);
+  const double s2 = chunk_total(sums + Cp + c, (size_t)2 * Cp, chunks, c < Cp, red);
+  if (c >= Cp || threadIdx.x >= 64) return;
   c1[c] = training ? (float)(s1 / count) : 0.f;
   c2[c] = training ? (float)(s2 / count) : 0.f;
   if (c < C) {
@@ -671,7 +738,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int chun
 
 int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_t count, int training, float* c1,
                            float* c2, float* dgamma, float* dbeta, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, st, sums, chunks, C, Cp, (double)count,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(256), 0, st, sums, chunks, C, Cp, (double)count,
                      training, c1, c2, dgamma, dbeta);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;

@@ -319,9 +319,8 @@ class MimoUNet(nn.Module):
         return self.encoder.in_convs[0].norm.training
 
     def _bump_batch_counters(self) -> None:
-        for dc in self.double_convs():
-            dc.double_conv[1].num_batches_tracked += 1
-            dc.double_conv[4].num_batches_tracked += 1
+        counters = [bn.num_batches_tracked for dc in self.double_convs() for bn in (dc.double_conv[1], dc.double_conv[4])]
+        torch._foreach_add_(counters, 1)  # one launch for the 2 x #DoubleConv counters instead of one each
 
     # ---- forward ----------------------------------------------------------------------------
     def _call(self, x, label, lmask, perm):
