@@ -420,12 +420,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     const int ptid = tid - 256;
     f32x4 xreg[XU];
     u32x4 wreg[3][WU];
-    int u_tr[XU], u_tc[XU];  // halo-tile coordinates of this thread's units (tile-shape constants)
+    // halo-tile coordinates of this thread's units (tile-shape constants): (row << 16) | column, and the byte
+    // offset of the unit from the tile's first halo pixel for tiles whose halo lies inside the image
+    int u_rc[XU], u_off[XU];
 #pragma unroll
     for (int k = 0; k < XU; ++k) {
       const int p = min((ptid + k * 256) >> 3, npix_lds - 1);
-      u_tr[k] = p / TCP;
-      u_tc[k] = p - u_tr[k] * TCP;
+      const int tr = p / TCP, tc = p - tr * TCP;
+      u_rc[k] = (tr << 16) | tc;
+      u_off[k] = ((tr * a.Wi + tc) * a.ldx + 4 * ((ptid + k * 256) & 7)) * 4;
     }
     const u32x4* wpk = reinterpret_cast<const u32x4*>(a.wpk);
     // stage j = (tile j / nchunks, chunk j % nchunks)
@@ -440,8 +443,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     const int n_ = t_ / tilesY;                                                                      \
     const int y0_ = ty_ * TR - a.off, x0_ = tx_ * TC - a.off;                                        \
     const float* ximg_ = a.x + (size_t)n_ * a.Hi * a.Wi * a.ldx;                                     \
+    /* halo inside the image and a full 32-channel chunk (a wave-uniform test): no reflection, no     \
+       masking, address = scalar tile base + per-thread constant -- the ~20 vector instructions per    \
+       unit of the general path compete with the MFMAs for the SIMD's issue port.  Data gradient     \
+       only: measured -8 % on its thin layers, nothing on the forward (whose producers are bound by   \
+       the fp32 -> fp16 split) */                                                                     \
+    if (!CVT && y0_ >= 0 && y0_ + TRP <= a.Hi && x0_ >= 0 && x0_ + TCP <= a.Wi && ck_ * 32 + 32 <= a.cin_p) { \
+      const char* tb_ = reinterpret_cast<const char*>(ximg_ + ((size_t)y0_ * a.Wi + x0_) * a.ldx) + ck_ * 128; \
+      _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_)                                         \
+        xreg[k_] = *reinterpret_cast<const f32x4*>(tb_ + u_off[k_]);                                 \
+    } else {                                                                                         \
     _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                         \
-      int iy_ = y0_ + u_tr[k_], ix_ = x0_ + u_tc[k_];                                                \
+      int iy_ = y0_ + (u_rc[k_] >> 16), ix_ = x0_ + (u_rc[k_] & 0xffff);                             \
       bool in_ = true;                                                                               \
       if (a.off == 1) { /* reflect (forward) */                                                      \
         iy_ = max(iy_, -iy_);                                                                        \
@@ -464,6 +477,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
                                    (ck_ * 64 + (q_ >> 2) * rc_ + 8 * (q_ & 3));                      \
         xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
       }                                                                                              \
+    }                                                                                                \
     }                                                                                                \
   }
 #define WS_STORE_X(K0, K1, BUF)                                                                      \
@@ -577,7 +591,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
   f32x4 bv[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
-    bv[nf] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co0 + nf * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bv[nf] = (CVT && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + co0 + nf * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   // tile-relative (row, column) of this lane's pixel in each of its MF fragments; row 0x4000 = not in the tile
   int prc[MF];
 #pragma unroll
@@ -677,9 +691,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
       if (oy < a.Ho && ox < a.Wo) {                                                                  \
         float* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy;                                         \
         _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                          \
-          f32x4 v = acc[m][nf] * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];                       \
+          /* bias, inference epilogue and BatchNorm sums exist on the forward only (CVT); the data   \
+             gradient stores its accumulators as they are */                                         \
+          f32x4 v = acc[m][nf];                                                                      \
+          if (CVT) v = v * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];                             \
           const int c_ = co0 + nf * 16 + g * 4;                                                      \
-          if (a.ep_scale) {                                                                          \
+          if (CVT && a.ep_scale) {                                                                   \
             const f32x4 esc_ = *reinterpret_cast<const f32x4*>(a.ep_scale + c_);                     \
             const f32x4 esh_ = *reinterpret_cast<const f32x4*>(a.ep_shift + c_);                     \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
@@ -689,8 +706,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
             }                                                                                        \
           }                                                                                          \
           if (c_ < a.cout_store) *reinterpret_cast<f32x4*>(yp + nf * 16) = v;                        \
-          s1[nf] += v;                                                                               \
-          s2[nf] += v * v;                                                                           \
+          if (CVT) {                                                                                 \
+            s1[nf] += v;                                                                             \
+            s2[nf] += v * v;                                                                         \
+          }                                                                                          \
         }                                                                                            \
       }                                                                                              \
     }                                                                                                \
@@ -736,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     C_MFMA(1, 0, 3)
   }
   C_EPILOGUE(ti)
-  if (a.stats) {
+  if (CVT && a.stats) {
     const size_t row = ((size_t)blockIdx.x * 4 + wave) * 2;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
