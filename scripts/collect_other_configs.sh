@@ -1,0 +1,20 @@
+#!/bin/bash
+# The non-headline workloads (run through gpurun from the repo root): writes gpurun_out/other_configs.raw
+# with one line per command; scripts/other_configs.py turns it into profiles/<round>/final/other_configs.jsonl
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$R"
+O=gpurun_out/other_configs.raw
+: > $O
+run() { echo "CMD $*" >> $O; "$@" 2>/dev/null | tail -n 1 >> $O; }
+run python scripts/measure_inference_speed.py
+run python scripts/measure_inference_speed.py --batch 8
+run python scripts/measure_inference_speed.py --monte_carlo_steps 0 --dropout 0 --height 128 --width 160
+run python bench.py --config cfg2 --steps 10 --warmup 3 --no-cpu-baseline
+run python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline
+echo "CMD MIMO_PRECISION=bf16 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline" >> $O
+MIMO_PRECISION=bf16 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -n 1 >> $O
+echo "CMD MIMO_PRECISION=bf16 python bench.py --steps 20 --warmup 5 --no-cpu-baseline" >> $O
+MIMO_PRECISION=bf16 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -n 1 >> $O
+echo "CMD MIMO_PRECISION=fp32 python bench.py --steps 10 --warmup 3 --no-cpu-baseline" >> $O
+MIMO_PRECISION=fp32 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -n 1 >> $O
+cat $O | cut -c1-200
