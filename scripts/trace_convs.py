@@ -11,9 +11,8 @@ import sys
 d = sys.argv[1]
 S, f, N, H, W, Ci = (int(v) for v in sys.argv[2:8]) if len(sys.argv) >= 8 else (2, 30, 32, 256, 256, 2)
 layers = []  # (name, Cin, Cout, H, W)
-for s in range(S):
+for s in range(S):  # the plan runs each private encoder chain to its end before the next one
     layers += [(f"enc_in{s}.c1", Ci, f, H, W), (f"enc_in{s}.c2", f, f, H, W)]
-for s in range(S):
     layers += [(f"down1_{s}.c1", f, 2 * f, H // 2, W // 2), (f"down1_{s}.c2", 2 * f, 2 * f, H // 2, W // 2)]
 fs = f * S
 layers += [("down2.c1", 2 * fs, 4 * fs, H // 4, W // 4), ("down2.c2", 4 * fs, 4 * fs, H // 4, W // 4),
