@@ -258,11 +258,16 @@ constexpr int kWsTR = 2;
 constexpr int kWsAPix = (kWsTR + 2) * kWgTCP;  // 136
 constexpr int kWsDPix = kWsTR * kWgTC;         // 64
 
-template <int NP, int NI>
+template <int NP, int NI, int CI_>
 __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
   // consumer wave = 16 ci x CO co (MI = 1, NI = CO/16 = 2, 3 or 4): an A fragment (re-read for every tap)
-  // feeds 3*NI MFMAs; at NI = 4, 52 instead of 80 transposed LDS reads per 108 MFMAs of a 32x32 arrangement
-  constexpr int CI = 64, CO = 16 * NI, MI = 1;
+  // feeds 3*NI MFMAs; at NI = 4, 52 instead of 80 transposed LDS reads per 108 MFMAs of a 32x32 arrangement.
+  // CI_ = 64: the four consumer waves are stacked along ci, each accumulates all nine taps.  CI_ = 32 (layers
+  // with <= 32 input channels): two waves along ci x two tap sets (taps 0-4 / 5-8), so all four SIMDs still
+  // multiply and a wave holds 5 instead of 9 tap accumulators.
+  constexpr int CI = CI_, CO = 16 * NI, MI = 1;
+  constexpr bool TSPLIT = CI == 32;
+  static_assert(CI == 64 || CI == 32, "64 or 32 input channels per workgroup");
   constexpr int PA = wg_pitch(CI), PD = wg_pitch(CO);
   constexpr int QA = CI / 4, QD = CO / 4;
   constexpr int XA = (kWsAPix * QA + 255) / 256, XD = (kWsDPix * QD + 255) / 256;  // per producer thread
@@ -386,11 +391,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   // =========================== consumers ===========================
   const int lr = lane & 15, g = lane >> 4;
   const int q = lr >> 2, p4 = lr & 3;
-  const int wn = 0, wm = wave;
-  static_assert(4 * MI * 16 == CI && NI * 16 == CO, "4 consumer waves stacked along ci");
-  f32x4 acc[9][MI][NI];
+  const int wn = 0, wm = TSPLIT ? (wave & 1) : wave;
+  const int tset = TSPLIT ? (wave >> 1) : 0;  // wave-uniform
+  static_assert(NI * 16 == CO, "one co tile per workgroup");
+  constexpr int NTMAX = TSPLIT ? 5 : 9;
+  f32x4 acc[NTMAX][MI][NI];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NTMAX; ++t)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -426,32 +433,42 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       if (NP == 3) al[SLOT][mi] = tr_read8(a0_ + mi * 32 + 2 * CI, a1_ + mi * 32 + 2 * CI);  \
     }                                                                                         \
   }
-      WS_READ_A(0, 0)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        if (t + 1 < 9) WS_READ_A((t + 1) & 1, t + 1)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            f32x4 c = acc[t][mi][ni];
-            if (NP == 3) {
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t & 1][mi], bh[ni], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1][mi], bl[ni], c, 0, 0, 0);
-            }
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t & 1][mi], bh[ni], c, 0, 0, 0);
-            acc[t][mi][ni] = c;
-          }
-        if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, (NP == 3 ? 4 : 2) * MI, 0);  // DS reads of tap t+1
-        __builtin_amdgcn_sched_group_barrier(0x008, NP * MI * NI, 0);                            // MFMAs of tap t
+      // taps T0 .. T0+NT-1 of this wave, accumulators indexed from 0
+#define WS_TAPS(T0, NT)                                                                       \
+  {                                                                                           \
+    WS_READ_A(0, (T0))                                                                        \
+    _Pragma("unroll") for (int tt = 0; tt < (NT); ++tt) {                                     \
+      if (tt + 1 < (NT)) WS_READ_A((tt + 1) & 1, (T0) + tt + 1)                               \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                       \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                   \
+          f32x4 c = acc[tt][mi][ni];                                                          \
+          if (NP == 3) {                                                                      \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tt & 1][mi], bh[ni], c, 0, 0, 0);  \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tt & 1][mi], bl[ni], c, 0, 0, 0);  \
+          }                                                                                   \
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tt & 1][mi], bh[ni], c, 0, 0, 0);    \
+          acc[tt][mi][ni] = c;                                                                \
+        }                                                                                     \
+      if (tt + 1 < (NT)) __builtin_amdgcn_sched_group_barrier(0x100, (NP == 3 ? 4 : 2) * MI, 0); /* DS reads of the next tap */ \
+      __builtin_amdgcn_sched_group_barrier(0x008, NP * MI * NI, 0);                              /* MFMAs of this tap */ \
+    }                                                                                         \
+  }
+      if (!TSPLIT) {
+        WS_TAPS(0, 9)
+      } else if (tset == 0) {
+        WS_TAPS(0, 5)
+      } else {
+        WS_TAPS(5, 4)
       }
+#undef WS_TAPS
 #undef WS_READ_A
     }
     __syncthreads();
   }
   float* out = a.partial + (size_t)blockIdx.y * 9 * a.cin_pad * a.cout_pad;
+  const int t0 = tset ? 5 : 0, nt = TSPLIT ? (tset ? 4 : 5) : 9;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int tt = 0; tt < NTMAX; ++tt)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -460,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const int ci = ci0 + (wm * MI + mi) * 16 + g * 4 + r4;
-          out[((size_t)t * a.cin_pad + ci) * a.cout_pad + co] = acc[t][mi][ni][r4];
+          if (tt < nt) out[((size_t)(t0 + tt) * a.cin_pad + ci) * a.cout_pad + co] = acc[tt][mi][ni][r4];
         }
       }
 }
@@ -487,7 +504,9 @@ void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO) {
   if (*CI == 64 && wgrad_ws_enabled() && cout_p > 32 && round_up(cout_p, 48) <= 0.85 * round_up(cout_p, 64)) *CO = 48;
 }
 
-static bool wgrad_use_ws(int CI, int CO) { return wgrad_ws_enabled() && CI == 64 && (CO == 32 || CO == 48 || CO == 64); }
+static bool wgrad_use_ws(int CI, int CO) {
+  return wgrad_ws_enabled() && (CI == 64 || CI == 32) && (CO == 32 || CO == 48 || CO == 64);
+}
 
 int wgrad_split_num_tiles(int N, int H, int W, int tr) { return N * ceil_div(H, tr) * ceil_div(W, kWgTC); }
 
@@ -528,16 +547,23 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
   const int numTiles = a.N * tilesY * tilesX;
   dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
   if (ws) {
-#define WS_LAUNCH(NI_)                                                                                          \
-  if (a.np == 1)                                                                                                \
-    hipLaunchKernelGGL((wgrad_split_ws_kernel<1, NI_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \
-  else                                                                                                          \
-    hipLaunchKernelGGL((wgrad_split_ws_kernel<3, NI_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles)
+#define WS_LAUNCH2(NI_, CI_)                                                                                         \
+  if (a.np == 1)                                                                                                     \
+    hipLaunchKernelGGL((wgrad_split_ws_kernel<1, NI_, CI_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \
+  else                                                                                                               \
+    hipLaunchKernelGGL((wgrad_split_ws_kernel<3, NI_, CI_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles)
+#define WS_LAUNCH(NI_)     \
+  if (CI == 64) {          \
+    WS_LAUNCH2(NI_, 64);   \
+  } else {                 \
+    WS_LAUNCH2(NI_, 32);   \
+  }
     switch (CO) {
       case 32: WS_LAUNCH(2); break;
       case 48: WS_LAUNCH(3); break;
       default: WS_LAUNCH(4); break;
     }
+#undef WS_LAUNCH2
 #undef WS_LAUNCH
     MIMO_KERNEL_CHECK();
     return MIMO_OK;
