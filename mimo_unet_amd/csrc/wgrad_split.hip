@@ -254,11 +254,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
 // pipes of every SIMD run concurrently.  Tile = 2 rows x 32 columns (K = 64 pixels), one barrier
 // per tile; producers run one tile ahead in LDS and two tiles ahead in registers.
 // ---------------------------------------------------------------------------------------
-constexpr int kWsTR = 2;
-constexpr int kWsAPix = (kWsTR + 2) * kWgTCP;  // 136
-constexpr int kWsDPix = kWsTR * kWgTC;         // 64
+// pixel tile of the wave-specialised kernel: TR rows x 32 columns.  2 rows with 64 input channels per
+// workgroup (128 KB of LDS); 4 rows with 32 (the thin 256x256 layers: twice the MFMAs per barrier, 127-157 KB)
+static int wgrad_ws_tr(int CI) { return CI == 32 ? 4 : 2; }
 
-template <int NP, int NI, int CI_>
+template <int NP, int NI, int CI_, int TR_>
 __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
   // consumer wave = 16 ci x CO co (MI = 1, NI = CO/16 = 2, 3 or 4): an A fragment (re-read for every tap)
   // feeds 3*NI MFMAs; at NI = 4, 52 instead of 80 transposed LDS reads per 108 MFMAs of a 32x32 arrangement.
@@ -268,6 +268,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   constexpr int CI = CI_, CO = 16 * NI, MI = 1;
   constexpr bool TSPLIT = CI == 32;
   static_assert(CI == 64 || CI == 32, "64 or 32 input channels per workgroup");
+  constexpr int kWsTR = TR_, kWsAPix = (kWsTR + 2) * kWgTCP, kWsDPix = kWsTR * kWgTC;
   constexpr int PA = wg_pitch(CI), PD = wg_pitch(CO);
   constexpr int QA = CI / 4, QD = CO / 4;
   constexpr int XA = (kWsAPix * QA + 255) / 256, XD = (kWsDPix * QD + 255) / 256;  // per producer thread
@@ -512,7 +513,7 @@ int wgrad_split_num_tiles(int N, int H, int W, int tr) { return N * ceil_div(H, 
 
 int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO) {
   const int wtiles = (cin_pad / CI) * (cout_pad / CO);
-  const int tiles = wgrad_split_num_tiles(N, H, W, wgrad_use_ws(CI, CO) ? kWsTR : kWgTR);
+  const int tiles = wgrad_split_num_tiles(N, H, W, wgrad_use_ws(CI, CO) ? wgrad_ws_tr(CI) : kWgTR);
   static const int mode = [] { const char* e = getenv("MIMO_WGRAD_SPLIT_MODE"); return e ? atoi(e) : 1; }();
   if (!wgrad_use_ws(CI, CO) || mode == 0) {
     int splits = ceil_div(512, wtiles);  // one 4-wave workgroup per CU: ~2 rounds of workgroups
@@ -524,7 +525,8 @@ int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int 
   // wave-specialised kernel: one workgroup per CU (128 KB of LDS), all workgroups of a launch do the same
   // work, so time ~ rounds x (pixel tiles per workgroup + fixed cost); the fixed cost (147 KB slab written
   // per workgroup and re-read by the reduction, pipeline fill) is worth about `kFixed` pixel tiles.
-  constexpr int kCUs = 256, kFixed = 8;
+  constexpr int kCUs = 256;
+  const int kFixed = 16 / wgrad_ws_tr(CI);  // in pixel tiles of this kernel
   int best = 1;
   long bestCost = -1;
   for (int s = 1; s <= tiles && s <= 1024; ++s) {
@@ -543,20 +545,20 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
     return MIMO_ERR_INVALID;
   }
   const bool ws = wgrad_use_ws(CI, CO);
-  const int tilesY = ceil_div(a.H, ws ? kWsTR : kWgTR), tilesX = ceil_div(a.W, kWgTC);
+  const int tilesY = ceil_div(a.H, ws ? wgrad_ws_tr(CI) : kWgTR), tilesX = ceil_div(a.W, kWgTC);
   const int numTiles = a.N * tilesY * tilesX;
   dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
   if (ws) {
-#define WS_LAUNCH2(NI_, CI_)                                                                                         \
+#define WS_LAUNCH2(NI_, CI_, TR_)                                                                                       \
   if (a.np == 1)                                                                                                     \
-    hipLaunchKernelGGL((wgrad_split_ws_kernel<1, NI_, CI_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \
+    hipLaunchKernelGGL((wgrad_split_ws_kernel<1, NI_, CI_, TR_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \
   else                                                                                                               \
-    hipLaunchKernelGGL((wgrad_split_ws_kernel<3, NI_, CI_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles)
+    hipLaunchKernelGGL((wgrad_split_ws_kernel<3, NI_, CI_, TR_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles)
 #define WS_LAUNCH(NI_)     \
   if (CI == 64) {          \
-    WS_LAUNCH2(NI_, 64);   \
+    WS_LAUNCH2(NI_, 64, 2); \
   } else {                 \
-    WS_LAUNCH2(NI_, 32);   \
+    WS_LAUNCH2(NI_, 32, 4); \
   }
     switch (CO) {
       case 32: WS_LAUNCH(2); break;
