@@ -376,18 +376,29 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
 // BatchNorm partial sums: accumulated in registers over the workgroup's tiles, one row per (workgroup,
 // consumer wave) — no cross-wave LDS reduction, 4 x gridDim.x rows for the column reduction that follows.
 // ---------------------------------------------------------------------------------------
-constexpr int kWsNPix = 256, kWsMaxPix = 360, kWsMF = 4;
+// MF = fragments of 16 pixels per consumer wave.  4: 256-pixel tiles, one workgroup per CU.  2: 128-pixel tiles
+// (180-pixel halo); with NF <= 2 the workgroup needs 79 KB of LDS and 128 registers per lane, so TWO workgroups
+// share a CU and one's MFMAs fill the other's barrier / staging / epilogue bubbles — for the thin layers (<= 32
+// output channels), whose tiles carry too little MFMA work to hide those.
+template <int MF>
+struct WsTile {
+  static constexpr int NPIX = 64 * MF;
+  static constexpr int MAXPIX = MF == 4 ? 360 : 180;
+};
+constexpr int kWsMaxMF = 4;
 
-template <int NF, int MODE, bool SWZ>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX,
-                                                            int numTiles, int xcd_order) {
+template <int NF, int MODE, bool SWZ, int MF_>
+__global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC,
+                                                                                          int tilesY, int tilesX,
+                                                                                          int numTiles, int xcd_order) {
   MIMO_CONV_MODE_CONSTANTS
   typedef typename Elem<F16>::T ET;
   typedef typename Elem<F16>::V8 bf16x8;
   typedef typename Elem<F16>::V4 bf16x4;
   constexpr int NB = NF * 16;
-  constexpr int MF = kWsMF;
-  constexpr int XU = (kWsMaxPix * 8 + 255) / 256;  // 16-byte units of an input tile per producer thread (12)
+  constexpr int MF = MF_;
+  constexpr int kWsMaxPix = WsTile<MF>::MAXPIX;
+  constexpr int XU = (kWsMaxPix * 8 + 255) / 256;  // 16-byte units of an input tile per producer thread (12 / 6)
   constexpr int XP = XU / 3;                        // units handled per phase
   static_assert(XU % 3 == 0, "input tile staged in three equal parts");
   constexpr int WUNITS = 3 * NB * 8;
@@ -571,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
   // latency several times per tap).  The pipeline runs across the phase barrier: the last tap of a
   // phase is multiplied after the barrier, under the first reads of the next phase.
   const int lr = lane & 15, g = lane >> 4;
-  int pbase[MF];
+  int pbase[kWsMaxMF];
 #pragma unroll
   for (int m = 0; m < MF; ++m) {
     int idx = (wave * MF + m) * 16 + lr;
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
   for (int nf = 0; nf < NF; ++nf)
     bv[nf] = (CVT && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + co0 + nf * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   // tile-relative (row, column) of this lane's pixel in each of its MF fragments; row 0x4000 = not in the tile
-  int prc[MF];
+  int prc[kWsMaxMF];
 #pragma unroll
   for (int m = 0; m < MF; ++m) {
     const int idx = (wave * MF + m) * 16 + lr;
@@ -610,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     s2[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  f32x4 acc[MF][NF];
+  f32x4 acc[kWsMaxMF][NF];
 #pragma unroll
   for (int m = 0; m < MF; ++m)
 #pragma unroll
@@ -664,15 +675,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     }                                                                                                \
     C_MFMA(0, BS, 0)                                                                                 \
     C_PIN((LAST) ? RA : RA + RB)                                                                     \
-    C_READ_A(0, KW, 2)                                                                               \
-    C_MFMA(1, BS, 1)                                                                                 \
-    C_PIN(RA)                                                                                        \
-    C_READ_A(1, KW, 3)                                                                               \
-    C_MFMA(0, BS, 2)                                                                                 \
-    C_PIN(RA)                                                                                        \
+    if (MF == 4) {                                                                                   \
+      C_READ_A(0, KW, 2)                                                                             \
+      C_MFMA(1, BS, 1)                                                                               \
+      C_PIN(RA)                                                                                      \
+      C_READ_A(1, KW, 3)                                                                             \
+      C_MFMA(0, BS, 2)                                                                               \
+      C_PIN(RA)                                                                                      \
+    }                                                                                                \
     if (!(LAST)) {                                                                                   \
       C_READ_A(0, (KW) + 1, 0)                                                                       \
-      C_MFMA(1, BS, 3)                                                                               \
+      C_MFMA(1, BS, MF - 1)                                                                          \
       C_PIN(RA)                                                                                      \
     }                                                                                                \
   }
@@ -727,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
     C_READ_B((P) ^ 1, 0)                                                                             \
     C_READ_A(0, 0, 0)                                                                                \
     if (!(FIRST)) {                                                                                  \
-      C_MFMA(1, P, 3)                                                                                \
+      C_MFMA(1, P, MF - 1)                                                                           \
       C_PIN(RA + RB)                                                                                 \
       if (tile_done) {                                                                               \
         C_EPILOGUE(ti)                                                                               \
@@ -750,9 +763,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(ConvLaunch a, int TR
   }
   if (ph < nphases) {  // odd number of remaining phases
     C_PHASE(0, false)
-    C_MFMA(1, 1, 3)
+    C_MFMA(1, 1, MF - 1)
   } else {
-    C_MFMA(1, 0, 3)
+    C_MFMA(1, 0, MF - 1)
   }
   C_EPILOGUE(ti)
   if (CVT && a.stats) {
@@ -788,17 +801,19 @@ static bool conv_ws_enabled() {
   return on;
 }
 
-int conv3x3_ws_stat_rows(int, int, int) { return 256 * 4; }  // <= 256 persistent workgroups x 4 consumer waves
+int conv3x3_ws_stat_rows(int, int, int) { return 512 * 4; }  // <= 512 persistent workgroups x 4 consumer waves
 
-template <int NF, int MODE>
+template <int NF, int MODE, int MF>
 static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   int TR, TC;
-  pick_tile_n(a.Ho, a.Wo, kWsNPix, kWsMaxPix, &TR, &TC);
+  pick_tile_n(a.Ho, a.Wo, WsTile<MF>::NPIX, WsTile<MF>::MAXPIX, &TR, &TC);
   const int tilesY = ceil_div(a.Ho, TR), tilesX = ceil_div(a.Wo, TC);
   const int numTiles = a.N * tilesY * tilesX;
   const int coTiles = a.cout_pad / (NF * 16);
-  // persistent: one workgroup per CU (LDS), every workgroup of a launch walks the same number of tiles
-  int gx = max(1, 256 / coTiles);
+  // persistent: one workgroup per CU (two for the 128-pixel / <= 32-channel instances), every workgroup of a
+  // launch walks the same number of tiles
+  constexpr int kWgPerCU = (MF == 2 && NF <= 2) ? 2 : 1;
+  int gx = max(1, 256 * kWgPerCU / coTiles);
   if (gx > numTiles) gx = numTiles;
   const int per = ceil_div(numTiles, gx);
   gx = ceil_div(numTiles, per);
@@ -809,9 +824,9 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   static const bool swz = getenv("MIMO_CONV_WS_SWIZZLE") && atoi(getenv("MIMO_CONV_WS_SWIZZLE")) != 0;
   static const int xcd = !(getenv("MIMO_CONV_XCD_ORDER") && atoi(getenv("MIMO_CONV_XCD_ORDER")) == 0);
   if (swz)
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, true, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd);
   else
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -840,11 +855,15 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
   // one's loads / stores overlap the other's MFMAs (MIMO_CONV_BIGTILE_NF2=1 restores 512-pixel tiles)
   static const bool big_nf2 = getenv("MIMO_CONV_BIGTILE_NF2") && atoi(getenv("MIMO_CONV_BIGTILE_NF2")) != 0;
   if (conv_ws_enabled() && a.Ho * a.Wo >= 256) {
+    // 128-pixel tiles / two workgroups per CU: forward only (measured per layer on one box: forward 30->30 at
+    // 256x256 169 -> 147 us, 45->30 282 -> 253 us; the data gradient of the same shapes 132 -> 145 us)
+    static const bool mf2_on = !(getenv("MIMO_CONV_WS_MF2") && atoi(getenv("MIMO_CONV_WS_MF2")) == 0);
+    const bool mf2 = mf2_on && (MODE == 1 || MODE == 2);
     switch (nf) {
-      case 4: return launch_ws<4, MODE>(a, rows, stream);
-      case 3: return launch_ws<3, MODE>(a, rows, stream);
-      case 2: return launch_ws<2, MODE>(a, rows, stream);
-      default: return launch_ws<1, MODE>(a, rows, stream);
+      case 4: return launch_ws<4, MODE, 4>(a, rows, stream);
+      case 3: return launch_ws<3, MODE, 4>(a, rows, stream);
+      case 2: return mf2 ? launch_ws<2, MODE, 2>(a, rows, stream) : launch_ws<2, MODE, 4>(a, rows, stream);
+      default: return mf2 ? launch_ws<1, MODE, 2>(a, rows, stream) : launch_ws<1, MODE, 4>(a, rows, stream);
     }
   }
   if (use_big_tile(a.Ho, a.Wo) && (nf >= 3 || big_nf2)) {
