@@ -16,8 +16,9 @@ VARIANTS = {
     "wgrad_split_mode0": {"MIMO_WGRAD_SPLIT_MODE": "0"},
     "side_stream": {"MIMO_WGRAD_STREAM": "1"},
     "no_graph": {"MIMO_HIP_GRAPH": "0"},
-    "subnet_streams": {"MIMO_SUBNET_STREAMS": "1"},
-    "skip_copy": {"MIMO_SKIP_IN_PLACE": "0"},           # skip tensors copied into the concat buffers     # encoder / decoder chains of the S subnetworks on S streams
+    "subnet_streams": {"MIMO_SUBNET_STREAMS": "1"},     # encoder / decoder chains of the S subnetworks on S streams
+    "skip_copy": {"MIMO_SKIP_IN_PLACE": "0"},           # skip tensors copied into the concat buffers
+    "conv_ws_mf2_off": {"MIMO_CONV_WS_MF2": "0"},       # thin forward layers on 256-pixel tiles, one workgroup per CU
 }
 
 
