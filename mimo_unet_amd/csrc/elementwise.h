@@ -34,6 +34,10 @@ int bn_eval_prepare_launch(int C, int Cp, const float* gamma, const float* beta,
 int bn_relu_fwd_launch(const float* z, int ldz, float* a, int lda, const float* scale, const float* shift,
                        const float* mask, int C, int Cp, int64_t P, int HW, hipStream_t st);
 
+// same, for a tensor that feeds MaxPool2d(2): also writes pool[N,H/2,W/2] = maxpool2x2(a) (one pass, 2x2 window per thread)
+int bn_relu_pool_fwd_launch(const float* z, int ldz, float* a, int lda, const float* scale, const float* shift,
+                            const float* mask, int C, int Cp, int N, int H, int W, float* pool, int ldpool, hipStream_t st);
+
 // ---- pooling / upsampling ---------------------------------------------------------------
 int maxpool_fwd_launch(const float* a, int lda, int N, int H, int W, int Cp, float* out, int ldo, hipStream_t st);
 // out[N,H,W,csp+clp] = cat(skip, zero_pad(bilinear_x2_align_corners(low))); skip == nullptr: channels [0, csp) of

@@ -58,6 +58,9 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4max(float4 a, float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
 
 // sum the accumulators of the threads that share a channel quad; result valid for pl == 0
 __device__ __forceinline__ float4 quad_block_sum(float4 v, const PQ& t, float4* red) {
@@ -346,12 +349,65 @@ int bn_relu_fwd_launch(const float* z, int ldz, float* a, int lda, const float* 
   return MIMO_OK;
 }
 
+// BatchNorm + ReLU (+ Dropout2d multipliers) of a tensor whose only spatial consumer is MaxPool2d(2): one thread
+// owns a 2x2 window, writes its four activations and their maximum into the pooled tensor — the separate
+// pooling pass (a second read of the activation) disappears.  Same arithmetic, bit-identical results.
+__global__ void bn_relu_pool_fwd_kernel(const float* __restrict__ z, int ldz, float* __restrict__ a, int lda,
+                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                        const float* __restrict__ mask, int C, int Cv, int N, int H, int W,
+                                        float* __restrict__ pool, int ldpool) {
+  const PQ t = pixquad(Cv);
+  if (!t.active) return;
+  const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q);
+  const int Hp = H / 2, Wp = W / 2;
+  const int P = N * Hp * Wp;
+  auto act = [&](float4 v, float4 m) {
+    float4 r;
+    r.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f) * m.x;
+    r.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f) * m.y;
+    r.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f) * m.z;
+    r.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f) * m.w;
+    return r;
+  };
+  PixIter it = pix_iter(t.p, t.pstep, Hp, Wp);
+  for (int p = t.p; p < P; p += t.pstep, pix_next(it, Hp, Wp)) {
+    const int n = it.n, py = it.y, px = it.x;
+    const float4 m = mask ? mask4(mask, n, C, 4 * t.q) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const size_t pix = ((size_t)n * H + 2 * py) * W + 2 * px;
+    const float* zs = z + pix * ldz + 4 * t.q;
+    float* as = a + pix * lda + 4 * t.q;
+    const float4 z00 = ld4(zs), z01 = ld4(zs + ldz), z10 = ld4(zs + (size_t)W * ldz), z11 = ld4(zs + (size_t)(W + 1) * ldz);
+    const float4 r00 = act(z00, m), r01 = act(z01, m), r10 = act(z10, m), r11 = act(z11, m);
+    st4(as, r00);
+    st4(as + lda, r01);
+    st4(as + (size_t)W * lda, r10);
+    st4(as + (size_t)(W + 1) * lda, r11);
+    st4(pool + (size_t)p * ldpool + 4 * t.q, f4max(f4max(r00, r01), f4max(r10, r11)));
+    // odd sizes: the last column / row belongs to no window but is still an activation
+    if ((W & 1) && px == Wp - 1) {
+      st4(as + 2 * (size_t)lda, act(ld4(zs + 2 * (size_t)ldz), m));
+      st4(as + (size_t)(W + 2) * lda, act(ld4(zs + (size_t)(W + 2) * ldz), m));
+    }
+    if ((H & 1) && py == Hp - 1) {
+      st4(as + 2 * (size_t)W * lda, act(ld4(zs + 2 * (size_t)W * ldz), m));
+      st4(as + (2 * (size_t)W + 1) * lda, act(ld4(zs + (2 * (size_t)W + 1) * ldz), m));
+      if ((W & 1) && px == Wp - 1) st4(as + (2 * (size_t)W + 2) * lda, act(ld4(zs + (2 * (size_t)W + 2) * ldz), m));
+    }
+  }
+}
+
+int bn_relu_pool_fwd_launch(const float* z, int ldz, float* a, int lda, const float* scale, const float* shift,
+                            const float* mask, int C, int Cp, int N, int H, int W, float* pool, int ldpool, hipStream_t st) {
+  const int Cv = Cp / 4;
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, pq_grid(Cv, (int64_t)N * (H / 2) * (W / 2), 4096), dim3(256), 0, st, z, ldz, a, lda,
+                     scale, shift, mask, C, Cv, N, H, W, pool, ldpool);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // max pooling 2x2 (floor) and bilinear x2 upsample + zero pad + concat
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 f4max(float4 a, float4 b) {
-  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
-}
 
 __global__ void maxpool_fwd_kernel(const float* __restrict__ a, int lda, int N, int H, int W, int Cv,
                                    float* __restrict__ out, int ldo) {

@@ -72,6 +72,8 @@ struct ConvBN {
   int ld_in = 0;
   float* a = nullptr;  // output activation
   int ld_a = 0;
+  float* pool_out = nullptr;  // the MaxPool2d(2) of `a` is written by the BatchNorm + ReLU pass (training forward)
+  int pool_ld = 0;
 };
 
 enum InputKind { IN_IMAGE = 0, IN_POOL = 1, IN_UPCAT = 2 };
@@ -86,6 +88,7 @@ struct DoubleConv {
   float* in_buf = nullptr;  // materialised input (packed image / pooled / concat)
   int in_ld = 0;
   bool skip_in_place = false;  // IN_UPCAT: the skip tensor already lives in channels [0, Cs) of in_buf
+  bool pool_fused = false;     // IN_POOL: in_buf is written by the producers' BatchNorm + ReLU pass
   float* mid = nullptr;  // a1
   Act out;               // a2 (+ gradient)
   float drop_p = 0.f;
@@ -521,6 +524,18 @@ struct mimo_plan {
         rehome_skip(x2cat, up3, pr);
       }
     }
+    // MaxPool2d inputs are produced by the BatchNorm + ReLU pass of the tensor they pool (one pass less per Down block)
+    if (!(getenv("MIMO_POOL_FUSED") && atoi(getenv("MIMO_POOL_FUSED")) == 0)) {
+      auto fuse = [](DoubleConv* producer, DoubleConv* consumer, int choff) {
+        producer->c2.pool_out = consumer->in_buf + choff;
+        producer->c2.pool_ld = consumer->in_ld;
+        consumer->pool_fused = true;
+      };
+      for (int s = 0; s < S; ++s) fuse(enc_in[s], down1[s], 0);
+      for (int s = 0; s < S; ++s) fuse(down1[s], down2, s * c2p);
+      fuse(down2, down3, 0);
+      fuse(down3, down4, 0);
+    }
     // ---- decoder (model.py:260-297) ----
     const int cin_dec = f * S + f;
     for (int s = 0; s < S; ++s) {
@@ -695,8 +710,12 @@ struct mimo_plan {
     }
     if (!fused) {
       prof_begin(MIMO_PROF_BN_RELU_FWD, st);
-      MIMO_TRY(bn_relu_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, P, L.H * L.W, st));
-      prof_end(MIMO_PROF_BN_RELU_FWD, 0.0, 8.0 * (double)P * L.cout_p, st);
+      if (L.pool_out)
+        MIMO_TRY(bn_relu_pool_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, L.N, L.H, L.W,
+                                         L.pool_out, L.pool_ld, st));
+      else
+        MIMO_TRY(bn_relu_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, P, L.H * L.W, st));
+      prof_end(MIMO_PROF_BN_RELU_FWD, 0.0, (L.pool_out ? 9.0 : 8.0) * (double)P * L.cout_p, st);
     }
     return MIMO_OK;
   }
@@ -705,7 +724,8 @@ struct mimo_plan {
     const int h = dc->c1.H, w = dc->c1.W;
     if (dc->kind == IN_POOL) {
       Act* s = dc->src0;
-      MIMO_TRY(maxpool_fwd_launch(s->a, s->ld, N, s->H, s->W, s->Cp, dc->in_buf, dc->in_ld, st));
+      if (!(dc->pool_fused && !fwd_no_grad))  // else: already written by the producers' BatchNorm + ReLU pass
+        MIMO_TRY(maxpool_fwd_launch(s->a, s->ld, N, s->H, s->W, s->Cp, dc->in_buf, dc->in_ld, st));
     } else if (dc->kind == IN_UPCAT) {
       Act *sk = dc->src0, *lo = dc->src1;
       MIMO_TRY(upcat_fwd_launch(dc->skip_in_place ? nullptr : sk->a, sk->ld, sk->Cp, lo->a, lo->ld, lo->Cp, N, h, w, lo->H,
