@@ -48,8 +48,10 @@ int upcat_fwd_launch(const float* skip, int lds, int csp, const float* low, int 
 // ---- backward gathers.  "dxpad" = gradient on the reflect-padded domain [N,H+2,W+2,ldp]
 // produced by the dgrad convolution; fold = transpose of reflect padding. ------------------
 // da[N,H,W] (lda) (=|+=) maxpool2x2 backward of fold(dxpad at pooled size), argmax from a
+// skip != nullptr: + fold(skip [N,H+2,W+2] (ldsk))[..., 0 : Cp] — the skip-connection gradient of the same tensor,
+// read straight from the Up block's padded-domain data gradient
 int pool_bwd_launch(const float* dxpad, int ldp, int choff, const float* a, int lda, float* da, int ldda, int N,
-                    int H, int W, int Cp, int accumulate, hipStream_t st);
+                    int H, int W, int Cp, int accumulate, hipStream_t st, const float* skip = nullptr, int ldsk = 0);
 // da (=|+=) fold(dxpad)[..., choff : choff+Cp]
 int fold_slice_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, int N, int H, int W, int Cp,
                       int accumulate, hipStream_t st);

@@ -523,9 +523,14 @@ __device__ __forceinline__ float route_max(float g, float v00, float v01, float 
 }
 
 // One thread owns a 2x2 window: one folded gradient read, the four activations once (not once per
-// window member), four stores.  Rows / columns outside every window (odd H or W) receive no gradient.
+// window member), four stores.  Rows / columns outside every window (odd H or W) receive no pooled gradient.
+// skip != nullptr: the tensor is also the skip input of an Up block; that block's padded-domain data gradient
+// (channels [0, Cp) of its own buffer, pixel pitch ldsk) is folded and added here, so the skip slice is never
+// copied out (da = pool route + skip fold, the same two operands in the same order as the former
+// fold_slice + accumulating pool_bwd pair).
 __global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int choff, const float* __restrict__ a,
-                                int lda, float* __restrict__ da, int ldda, int N, int H, int W, int Cv, int accumulate) {
+                                int lda, float* __restrict__ da, int ldda, int N, int H, int W, int Cv, int accumulate,
+                                const float* __restrict__ skip, int ldsk) {
   const PQ t = pixquad(Cv);
   if (!t.active) return;
   const int Hp = H / 2, Wp = W / 2;
@@ -554,27 +559,51 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int ch
 #pragma unroll
       for (int j = 0; j < 4; ++j) r[j] = f4add(r[j], o[j]);
     }
+    if (skip) {
+      float4 o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fold_read(skip, ldsk, n, 2 * py + (j >> 1), 2 * px + (j & 1), H, W, 4 * t.q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = f4add(r[j], o[j]);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) st4(d4[j], r[j]);
-    if (!accumulate) {  // odd sizes: the last row / column belongs to no window
+    if (!accumulate) {  // odd sizes: the last row / column belongs to no window (skip gradient only)
+      auto rest = [&](int y, int x) {
+        st4(da + (((size_t)n * H + y) * W + x) * ldda + 4 * t.q, skip ? fold_read(skip, ldsk, n, y, x, H, W, 4 * t.q) : f4zero());
+      };
       if ((W & 1) && px == Wp - 1) {
-        st4(dst + 2 * (size_t)ldda, f4zero());
-        st4(dst + (size_t)(W + 2) * ldda, f4zero());
+        rest(2 * py, W - 1);
+        rest(2 * py + 1, W - 1);
       }
       if ((H & 1) && py == Hp - 1) {
-        st4(dst + 2 * (size_t)W * ldda, f4zero());
-        st4(dst + (2 * (size_t)W + 1) * ldda, f4zero());
-        if ((W & 1) && px == Wp - 1) st4(dst + (2 * (size_t)W + 2) * ldda, f4zero());
+        rest(H - 1, 2 * px);
+        rest(H - 1, 2 * px + 1);
+        if ((W & 1) && px == Wp - 1) rest(H - 1, W - 1);
+      }
+    } else if (skip) {
+      auto rest = [&](int y, int x) {
+        float* d = da + (((size_t)n * H + y) * W + x) * ldda + 4 * t.q;
+        st4(d, f4add(ld4(d), fold_read(skip, ldsk, n, y, x, H, W, 4 * t.q)));
+      };
+      if ((W & 1) && px == Wp - 1) {
+        rest(2 * py, W - 1);
+        rest(2 * py + 1, W - 1);
+      }
+      if ((H & 1) && py == Hp - 1) {
+        rest(H - 1, 2 * px);
+        rest(H - 1, 2 * px + 1);
+        if ((W & 1) && px == Wp - 1) rest(H - 1, W - 1);
       }
     }
   }
 }
 
 int pool_bwd_launch(const float* dxpad, int ldp, int choff, const float* a, int lda, float* da, int ldda, int N, int H,
-                    int W, int Cp, int accumulate, hipStream_t st) {
+                    int W, int Cp, int accumulate, hipStream_t st, const float* skip, int ldsk) {
   const int Cv = Cp / 4;
   hipLaunchKernelGGL(pool_bwd_kernel, pq_grid(Cv, (int64_t)N * (H / 2) * (W / 2), 4096), dim3(256), 0, st, dxpad, ldp, choff,
-                     a, lda, da, ldda, N, H, W, Cv, accumulate);
+                     a, lda, da, ldda, N, H, W, Cv, accumulate, skip, ldsk);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

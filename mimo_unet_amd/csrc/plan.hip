@@ -52,6 +52,11 @@ struct Act {
   int N = 0, H = 0, W = 0;
   std::vector<int> chmap;
   int grad_writes = 0;  // run-time counter: first writer assigns, later writers accumulate
+  // skip-connection gradient of this tensor, left in the consuming Up block's own padded-domain buffer (channels
+  // [0, Cp), pixel pitch skipgrad_ld) until the MaxPool backward of the same tensor folds it in
+  const float* skipgrad = nullptr;
+  int skipgrad_ld = 0;
+  bool pooled = false;  // some Down block pools this tensor (its pool_bwd then takes the skip gradient along)
 };
 
 struct ConvBN {
@@ -89,6 +94,8 @@ struct DoubleConv {
   int in_ld = 0;
   bool skip_in_place = false;  // IN_UPCAT: the skip tensor already lives in channels [0, Cs) of in_buf
   bool pool_fused = false;     // IN_POOL: in_buf is written by the producers' BatchNorm + ReLU pass
+  float* dxpad_own = nullptr;  // IN_UPCAT: private buffer of c1's padded-domain data gradient (holds the skip slice
+                               // until the skip tensor's pool backward has read it)
   float* mid = nullptr;  // a1
   Act out;               // a2 (+ gradient)
   float drop_p = 0.f;
@@ -423,6 +430,10 @@ struct mimo_plan {
     dc->src0 = s0;
     dc->src1 = s1;
     MIMO_TRY(dalloc(&dc->in_buf, (size_t)N * h * w * in_cp));
+    if (kind == IN_POOL) s0->pooled = true;
+    static const bool skip_keep = !(getenv("MIMO_SKIP_GRAD_IN_PLACE") && atoi(getenv("MIMO_SKIP_GRAD_IN_PLACE")) == 0);
+    if (kind == IN_UPCAT && skip_keep && s0->pooled)
+      MIMO_TRY(dalloc(&dc->dxpad_own, (size_t)N * (h + 2) * (w + 2) * in_cp));
     dc->in_ld = in_cp;
     dc->c1.in = dc->in_buf;
     dc->c1.ld_in = in_cp;
@@ -1018,16 +1029,24 @@ struct mimo_plan {
 
   int dc_backward(DoubleConv* dc, bool need_input_grad, hipStream_t st) {
     MIMO_TRY(convbn_backward(dc->c2, dc->out.da, dc->out.ldda, nullptr, dc->mask, true, s_dxpadA, st));
-    MIMO_TRY(convbn_backward(dc->c1, nullptr, 0, s_dxpadA, nullptr, need_input_grad, s_dxpadB, st));
+    float* dxB = dc->dxpad_own ? dc->dxpad_own : s_dxpadB;
+    MIMO_TRY(convbn_backward(dc->c1, nullptr, 0, s_dxpadA, nullptr, need_input_grad, dxB, st));
     if (!need_input_grad) return MIMO_OK;
     const int h = dc->c1.H, w = dc->c1.W, ldp = dc->c1.cin_p;
     if (dc->kind == IN_POOL) {
       Act* s = dc->src0;
-      MIMO_TRY(pool_bwd_launch(s_dxpadB, ldp, 0, s->a, s->ld, s->da, s->ldda, N, s->H, s->W, s->Cp, acc_flag(s), st));
+      MIMO_TRY(pool_bwd_launch(dxB, ldp, 0, s->a, s->ld, s->da, s->ldda, N, s->H, s->W, s->Cp, acc_flag(s), st, s->skipgrad,
+                               s->skipgrad_ld));
+      s->skipgrad = nullptr;
     } else if (dc->kind == IN_UPCAT) {
       Act *sk = dc->src0, *lo = dc->src1;
-      MIMO_TRY(fold_slice_launch(s_dxpadB, ldp, 0, sk->da, sk->ldda, N, h, w, sk->Cp, acc_flag(sk), st));
-      MIMO_TRY(up_bwd_launch(s_dxpadB, ldp, sk->Cp, lo->da, lo->ldda, N, h, w, lo->H, lo->W, lo->Cp, acc_flag(lo), st));
+      if (dc->dxpad_own) {  // the skip slice stays where the data gradient wrote it; the pool backward of sk folds it in
+        sk->skipgrad = dxB;
+        sk->skipgrad_ld = ldp;
+      } else {
+        MIMO_TRY(fold_slice_launch(dxB, ldp, 0, sk->da, sk->ldda, N, h, w, sk->Cp, acc_flag(sk), st));
+      }
+      MIMO_TRY(up_bwd_launch(dxB, ldp, sk->Cp, lo->da, lo->ldda, N, h, w, lo->H, lo->W, lo->Cp, acc_flag(lo), st));
     }
     return MIMO_OK;
   }
@@ -1072,8 +1091,12 @@ struct mimo_plan {
       return backward_encoders(dx, st);
     }
     bwd_stage0_done = false;
-    for (auto& dc : dcs) dc->out.grad_writes = 0;
+    for (auto& dc : dcs) {
+      dc->out.grad_writes = 0;
+      dc->out.skipgrad = nullptr;
+    }
     x2cat.grad_writes = 0;
+    x2cat.skipgrad = nullptr;
     if (!fwd_training) {  // eval-mode forward skipped the dgrad weight packing
       MIMO_TRY(pack_all(true, st));
     }

@@ -18,6 +18,7 @@ VARIANTS = {
     "no_graph": {"MIMO_HIP_GRAPH": "0"},
     "subnet_streams": {"MIMO_SUBNET_STREAMS": "1"},     # encoder / decoder chains of the S subnetworks on S streams
     "skip_copy": {"MIMO_SKIP_IN_PLACE": "0"},           # skip tensors copied into the concat buffers
+    "skip_grad_copy": {"MIMO_SKIP_GRAD_IN_PLACE": "0"},  # skip-connection gradients copied out by fold_slice
     "pool_fused_off": {"MIMO_POOL_FUSED": "0"},         # separate MaxPool2d pass after BatchNorm + ReLU
     "conv_ws_mf2_off": {"MIMO_CONV_WS_MF2": "0"},       # thin forward layers on 256-pixel tiles, one workgroup per CU
 }
