@@ -8,6 +8,7 @@ namespace mimo {
 
 constexpr int kMaxChunks = 64;   // second-level partial rows kept for finalize kernels
 constexpr int kEwMaxBlocks = 1024;
+constexpr int kBnReduceMaxBlocks = 2048;  // upper bound of the BatchNorm-backward grids (partial-row capacity; 1792 used)
 constexpr int kMaxHeadOut = 8;   // out_channels supported by the fused head kernels
 
 // ---- generic two-level column reduction of per-workgroup partial rows -------------------

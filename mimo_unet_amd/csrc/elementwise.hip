@@ -11,6 +11,7 @@
 //   LaplaceNLL / GaussianNLL .............. mimo/losses.py:47-79,132-164
 //   apply_input_transform gather .......... mimo/models/utils.py:38-48
 #include <algorithm>
+#include <cstdlib>
 
 #include "elementwise.h"
 
@@ -45,6 +46,12 @@ __device__ __forceinline__ PQ pixquad(int Cv, bool xcd_bands = false) {
   return r;
 }
 
+// Grid caps of the grid-stride kernels, scanned per kernel on the cfg3 step (rocprofv3 kernel trace; 256 CUs):
+// the two BatchNorm-backward passes run best with exactly the 7 workgroups per CU their registers allow resident
+// (1024 -> 1792 blocks: reduce 1.92 -> 1.63 ms, apply 2.38 -> 2.21 ms per step; 2048 already spills into a second,
+// partial round), BatchNorm + ReLU forward with 6 per CU, the 16-tap bilinear backward with many short
+// workgroups (4096 -> 16384: 0.67 -> 0.55 ms), the rest at 4096-8192.
+constexpr int kBlocksBnRelu = 1536, kBlocksBnBwd = 1792, kBlocksUpBwd = 16384, kBlocksPoolBwd = 8192;
 static dim3 pq_grid(int Cv, int64_t P, int max_blocks = kEwMaxBlocks) {
   const int QB = Cv < 256 ? Cv : 256;
   const int PPI = 256 / QB;
@@ -343,7 +350,7 @@ __global__ void bn_relu_fwd_kernel(const float* __restrict__ z, int ldz, float* 
 int bn_relu_fwd_launch(const float* z, int ldz, float* a, int lda, const float* scale, const float* shift,
                        const float* mask, int C, int Cp, int64_t P, int HW, hipStream_t st) {
   const int Cv = Cp / 4;
-  hipLaunchKernelGGL(bn_relu_fwd_kernel, pq_grid(Cv, P, 4096), dim3(256), 0, st, z, ldz, a, lda, scale, shift, mask, C,
+  hipLaunchKernelGGL(bn_relu_fwd_kernel, pq_grid(Cv, P, kBlocksBnRelu), dim3(256), 0, st, z, ldz, a, lda, scale, shift, mask, C,
                      Cv, (int)P, HW);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
@@ -602,7 +609,7 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int ch
 int pool_bwd_launch(const float* dxpad, int ldp, int choff, const float* a, int lda, float* da, int ldda, int N, int H,
                     int W, int Cp, int accumulate, hipStream_t st, const float* skip, int ldsk) {
   const int Cv = Cp / 4;
-  hipLaunchKernelGGL(pool_bwd_kernel, pq_grid(Cv, (int64_t)N * (H / 2) * (W / 2), 4096), dim3(256), 0, st, dxpad, ldp, choff,
+  hipLaunchKernelGGL(pool_bwd_kernel, pq_grid(Cv, (int64_t)N * (H / 2) * (W / 2), kBlocksPoolBwd), dim3(256), 0, st, dxpad, ldp, choff,
                      a, lda, da, ldda, N, H, W, Cv, accumulate, skip, ldsk);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
@@ -726,7 +733,7 @@ int up_bwd_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, i
                   int Cp, int accumulate, hipStream_t st) {
   const int Cv = Cp / 4;
   const int padT = (H - 2 * h) / 2, padL = (W - 2 * w) / 2;
-  hipLaunchKernelGGL(up_bwd_kernel, pq_grid(Cv, (int64_t)N * h * w, 4096), dim3(256), 0, st, dxpad, ldp, choff, da, ldda,
+  hipLaunchKernelGGL(up_bwd_kernel, pq_grid(Cv, (int64_t)N * h * w, kBlocksUpBwd), dim3(256), 0, st, dxpad, ldp, choff, da, ldda,
                      N, H, W, h, w, padT, padL, Cv, accumulate);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
@@ -797,7 +804,7 @@ int bnrelu_bwd_reduce_launch(const float* da, int ldda, const float* dxpad, int 
                              const float* mask, int C, int Cp, int N, int H, int W, float* partial, int* rows,
                              hipStream_t st) {
   const int Cv = Cp / 4;
-  const dim3 grid = pq_grid(Cv, (int64_t)N * H * W);
+  const dim3 grid = pq_grid(Cv, (int64_t)N * H * W, kBlocksBnBwd);
   *rows = grid.x;
   hipLaunchKernelGGL(bnrelu_bwd_reduce_kernel, grid, dim3(256), 0, st, da, ldda, dxpad, ldp, z, ldz, scale, shift, mean,
                      invstd, mask, C, Cv, N, H, W, partial);
@@ -902,7 +909,7 @@ int bn_bwd_apply_launch(const float* da, int ldda, const float* dxpad, int ldp, 
                         int C, const float* c1, const float* c2, int Cp, int N, int H, int W, float* dz, int split_out,
                         float* partial, int* rows, hipStream_t st) {
   const int Cv = Cp / 4;
-  const dim3 grid = pq_grid(Cv, (int64_t)N * H * W);
+  const dim3 grid = pq_grid(Cv, (int64_t)N * H * W, kBlocksBnBwd);
   *rows = grid.x;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, da, ldda, dxpad, ldp, z, ldz, scale, shift, mean, invstd,
                      mask, C, c1, c2, Cv, N, H, W, dz, split_out, partial);

@@ -363,7 +363,7 @@ struct mimo_plan {
     cap_slab = std::max(cap_slab, (size_t)(L.wg_splits + L.wg_splits / 8 + 2) * 9 * L.wg_cin_pad * L.wg_cout_pad);
     const size_t stat_rows = std::max(conv3x3_stat_rows(n, h, w), conv3x3_ws_stat_rows(n, h, w));
     cap_partial = std::max(cap_partial, stat_rows * 2 * L.cout_pad);
-    cap_partial = std::max(cap_partial, (size_t)kEwMaxBlocks * 2 * L.cout_p);
+    cap_partial = std::max(cap_partial, (size_t)kBnReduceMaxBlocks * 2 * L.cout_p);
     cap_sums = std::max(cap_sums, (size_t)kMaxChunks * 2 * std::max(L.cout_pad, L.cout_p));
     return MIMO_OK;
   }
