@@ -185,6 +185,17 @@ int mimo_validation_epilogue(const float* out, const float* label, const float* 
                              float* aleatoric_std, float* epistemic_std, float* err, float* scalars, double* scratch,
                              int32_t scratch_blocks, mimo_stream stream);
 
+/* ---- training-step epilogue: replaces, after the fused forward + loss, the no_grad tail of
+ * MimoUnetModel.training_step (mimo_unet.py:121-144): the per-subnetwork label gather of apply_input_transform
+ * (utils.py:38-48), loss_fn.mode / loss_fn.std (losses.py:166-192), the error map and compute_regression_metrics
+ * on the flattened predictions (metrics.py:22-34) — one pass instead of ~20 tensor operations.
+ * out [N,S,2*Ct,HW] logits; label [N0,Ct,HW]; perm [S][N] int64 rows of label per (s, n), or NULL (identity, N0 = N).
+ * label_t / preds / aleatoric_std / err: [N,S,Ct,HW] each.
+ * scalars: device [5] = mae, mse, rmse, r2, element count.  scratch: device doubles [scratch_blocks * 8]. */
+int mimo_training_epilogue(const float* out, const float* label, const int64_t* perm, int32_t n, int32_t s, int32_t ct,
+                           int64_t hw, int32_t loss_kind, float* label_t, float* preds, float* aleatoric_std, float* err,
+                           float* scalars, double* scratch, int32_t scratch_blocks, mimo_stream stream);
+
 /* ---- single-operator entry points (NHWC, channel-padded) used by the parity tests -------
  * They run the same kernels the plan runs.  x [N,H,W,cin_p], w OIHW [cout][cin][3][3]. */
 int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, float* z, double* stats,

@@ -147,12 +147,24 @@ __global__ void val_epilogue_kernel(const float* __restrict__ out, const float* 
 // scalars: [0] combined NLL (mean), [1] mae, [2] mse, [3] rmse, [4] r2, [5] mean clip(aleatoric_std, 0, 5),
 //          [6] mean clip(epistemic_std, 0, 5), [7] element count
 __global__ void val_finalize_kernel(const double* __restrict__ partial, int blocks, double count, float* __restrict__ scalars) {
+  __shared__ double red[kValSums][256];
   __shared__ double tot[kValSums];
-  if (threadIdx.x < kValSums) {
-    double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += partial[(size_t)b * kValSums + threadIdx.x];
-    tot[threadIdx.x] = s;
+  double a[kValSums];
+#pragma unroll
+  for (int k = 0; k < kValSums; ++k) a[k] = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 256)
+#pragma unroll
+    for (int k = 0; k < kValSums; ++k) a[k] += partial[(size_t)b * kValSums + k];
+#pragma unroll
+  for (int k = 0; k < kValSums; ++k) red[k][threadIdx.x] = a[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+#pragma unroll
+      for (int k = 0; k < kValSums; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+    __syncthreads();
   }
+  if (threadIdx.x < kValSums) tot[threadIdx.x] = red[threadIdx.x][0];
   __syncthreads();
   if (threadIdx.x == 0) {
     const double mse = tot[1] / count;
@@ -168,7 +180,95 @@ __global__ void val_finalize_kernel(const double* __restrict__ partial, int bloc
   }
 }
 
+// Training-step epilogue (mimo_unet.py:121-144): gathered labels, predictions, aleatoric std, error map and the
+// sums behind mae / mse / rmse / r2 over all N*S*Ct*HW elements.
+__global__ void train_epilogue_kernel(const float* __restrict__ out, const float* __restrict__ label,
+                                      const int64_t* __restrict__ perm, int N, int S, int Ct, int64_t hw, int kind,
+                                      float* __restrict__ label_t, float* __restrict__ preds, float* __restrict__ alea_std,
+                                      float* __restrict__ err, double* __restrict__ partial) {
+  __shared__ double red[4][256];
+  const int64_t chw = (int64_t)Ct * hw, total = (int64_t)N * S * chw;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ns = i / chw, r = i - ns * chw;  // r = c * hw + pixel
+    const int64_t n = ns / S, s = ns - n * S;
+    const float mu = out[ns * 2 * chw + r], lp = out[ns * 2 * chw + chw + r];
+    const int64_t src = perm ? perm[s * N + n] : n;
+    const float y = label[src * chw + r];
+    const float e = expf(lp);
+    const float d = mu - y;
+    label_t[i] = y;
+    preds[i] = mu;
+    alea_std[i] = kind == MIMO_LOSS_LAPLACE_NLL ? e * 1.41421356237309515f : sqrtf(e);
+    err[i] = d;
+    acc[0] += fabsf(d);
+    acc[1] += (double)d * d;
+    acc[2] += y;
+    acc[3] += (double)y * y;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// scalars: [0] mae, [1] mse, [2] rmse, [3] r2, [4] element count
+__global__ void train_finalize_kernel(const double* __restrict__ partial, int blocks, double count, float* __restrict__ scalars) {
+  __shared__ double red[4][256];
+  __shared__ double tot[4];
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < blocks; b += 256)  // 256 threads walk the partial rows, then a fixed-order tree
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += partial[(size_t)b * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = a[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) tot[threadIdx.x] = red[threadIdx.x][0];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double mse = tot[1] / count;
+    const double ss_tot = tot[3] - tot[2] * tot[2] / count;
+    scalars[0] = (float)(tot[0] / count);
+    scalars[1] = (float)mse;
+    scalars[2] = (float)sqrt(mse);
+    scalars[3] = (float)(1.0 - tot[1] / ss_tot);
+    scalars[4] = (float)count;
+  }
+}
+
 }  // namespace mimo
+
+extern "C" int mimo_training_epilogue(const float* out, const float* label, const int64_t* perm, int32_t n, int32_t s,
+                                      int32_t ct, int64_t hw, int32_t loss_kind, float* label_t, float* preds,
+                                      float* aleatoric_std, float* err, float* scalars, double* scratch,
+                                      int32_t scratch_blocks, mimo_stream stream) {
+  using namespace mimo;
+  if (!out || !label || !label_t || !preds || !aleatoric_std || !err || !scalars || !scratch || n < 1 || s < 1 || ct < 1 ||
+      hw < 1 || scratch_blocks < 1) {
+    set_error("mimo_training_epilogue: invalid argument");
+    return MIMO_ERR_INVALID;
+  }
+  const int64_t total = (int64_t)n * s * ct * hw;
+  const int blocks = (int)std::min<int64_t>(std::min<int64_t>(ceil_div64(total, 256), 2048), scratch_blocks);
+  hipLaunchKernelGGL(train_epilogue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, label, perm, n, s, ct, hw,
+                     loss_kind, label_t, preds, aleatoric_std, err, scratch);
+  MIMO_KERNEL_CHECK();
+  hipLaunchKernelGGL(train_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, blocks, (double)total, scalars);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
 
 extern "C" int mimo_validation_epilogue(const float* out, const float* label, const float* mask, int32_t n, int32_t s,
                                         int32_t ct, int64_t hw, int32_t loss_kind, float eps_min, float eps_max, float* mean,
@@ -185,7 +285,7 @@ extern "C" int mimo_validation_epilogue(const float* out, const float* label, co
   hipLaunchKernelGGL(val_epilogue_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, label, mask, n, s, ct, hw,
                      loss_kind, eps_min, eps_max, mean, aleatoric_std, epistemic_std, err, scratch);
   MIMO_KERNEL_CHECK();
-  hipLaunchKernelGGL(val_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, blocks, (double)total, scalars);
+  hipLaunchKernelGGL(val_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, blocks, (double)total, scalars);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

@@ -185,6 +185,34 @@ def uncertainties(p1: torch.Tensor, p2: torch.Tensor, loss: str = "laplace_nll")
 VAL_SCALARS = ("nll_combined", "mae", "mse", "rmse", "r2", "aleatoric_std_mean", "epistemic_std_mean", "count")
 
 
+TRAIN_SCALARS = ("mae", "mse", "rmse", "r2", "count")
+
+
+def training_epilogue(out: torch.Tensor, label: torch.Tensor, perms: Optional[torch.Tensor], loss: str = "laplace_nll"):
+    """Logits [N,S,2*Ct,H,W] + label [N0,Ct,H,W] + perms [S,N] -> (label_t, preds, aleatoric_std, err) as
+    [N,S,Ct,H,W] and a device tensor of the TRAIN_SCALARS — the no_grad tail of MimoUnetModel.training_step
+    (mimo_unet.py:121-144: label gather, mode / std, error map, regression metrics) in one pass."""
+    lib = L.load()
+    out, label = out.detach().contiguous(), label.contiguous().float()
+    n, s, co, h, w = out.shape
+    ct = co // 2
+    if perms is not None:
+        perms = perms.to(device=out.device, dtype=torch.int64).contiguous()
+        assert perms.shape == (s, n), (perms.shape, out.shape)
+    else:
+        assert label.shape[0] == n
+    assert label.shape[1:] == (ct, h, w), (label.shape, out.shape)
+    maps = [torch.empty(n, s, ct, h, w, device=out.device, dtype=torch.float32) for _ in range(4)]
+    scalars = torch.empty(5, device=out.device, dtype=torch.float32)
+    blocks = 2048
+    scratch = torch.empty(blocks * 8, device=out.device, dtype=torch.float64)
+    L.check(lib.mimo_training_epilogue(out.data_ptr(), label.data_ptr(), L.ptr(perms) or None, n, s, ct, h * w,
+                                       L.LOSS_KINDS[loss], maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(),
+                                       maps[3].data_ptr(), scalars.data_ptr(), scratch.data_ptr(), blocks,
+                                       L.current_stream()), "mimo_training_epilogue")
+    return maps[0], maps[1], maps[2], maps[3], scalars
+
+
 def validation_epilogue(out: torch.Tensor, label: torch.Tensor, mask: Optional[torch.Tensor], loss: str = "laplace_nll",
                         eps_min: float = 1e-5, eps_max: float = 1e3):
     """Logits [N,S,2*Ct,H,W] + label [N,Ct,H,W] (+ mask [N,1,H,W]) -> (mean, aleatoric_std, epistemic_std,

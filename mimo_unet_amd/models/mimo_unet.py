@@ -18,7 +18,7 @@ from typing import Any, Dict, Literal, Optional, Tuple
 
 import torch
 
-from ..engine import validation_epilogue
+from ..engine import training_epilogue, validation_epilogue
 from ..lightning_compat import LightningModule
 from ..losses import UncertaintyLoss
 from ..metrics import compute_regression_metrics
@@ -122,15 +122,30 @@ class MimoUnetModel(LightningModule):
         weights = self.loss_buffer.get_weights().to(loss.device)  # read BEFORE the add (mimo_unet.py:243-245)
         self.loss_buffer.add(loss.detach())
         loss_weighted = loss * weights
+        loss_mean = loss_weighted.mean()  # the differentiable scalar, outside the no_grad section below
         with torch.no_grad():
-            label_t = gather_subnetworks(label, perms)
             mask_t = gather_subnetworks(mask, perms)
+            self._log_train_loss_and_weights(loss.detach(), weights)
+            if out.is_cuda and self.loss_name in ("laplace_nll", "gaussian_nll"):
+                # label gather, mode / std, error map and the regression metrics in one pass
+                # (engine.training_epilogue; the reference runs ~20 full-tensor torch ops here)
+                label_t, y_pred, aleatoric_std, err_map, sc = training_epilogue(out, label, perms, self.loss_name)
+                for i, name in ((3, "r2"), (0, "mae"), (1, "mse"), (2, "rmse")):
+                    self._log(f"metric_train/{name}", sc[i], on_step=True, on_epoch=True)
+                return {
+                    "loss": loss_mean,
+                    "label": flatten_subnetwork_dimension(label_t),
+                    "preds": flatten_subnetwork_dimension(y_pred),
+                    "aleatoric_std_map": flatten_subnetwork_dimension(aleatoric_std),
+                    "err_map": flatten_subnetwork_dimension(err_map),
+                    "mask": flatten_subnetwork_dimension(mask_t) if mask_t is not None else None,
+                }
+            label_t = gather_subnetworks(label, perms)
             y_pred = self.loss_fn.mode(p1, p2).detach()
             aleatoric_std = self.loss_fn.std(p1, p2).detach()
-            self._log_train_loss_and_weights(loss.detach(), weights)
             self._log_metrics(y_pred=y_pred, y_true=label_t, stage="train")
         return {
-            "loss": loss_weighted.mean(),
+            "loss": loss_mean,
             "label": flatten_subnetwork_dimension(label_t),
             "preds": flatten_subnetwork_dimension(y_pred),
             "aleatoric_std_map": flatten_subnetwork_dimension(aleatoric_std),

@@ -199,6 +199,33 @@ def test_validation_epilogue(S, kind, use_mask):
         assert abs(sc[i].item() - float(ref[name])) <= 1e-4 * max(abs(float(ref[name])), 1e-3), name
 
 
+@pytest.mark.parametrize("S", [1, 3])
+@pytest.mark.parametrize("kind", ["laplace_nll", "gaussian_nll"])
+@pytest.mark.parametrize("reps", [1, 2])
+def test_training_epilogue(S, kind, reps):
+    """mimo_training_epilogue against the tensor operations of the training_step tail (mimo_unet.py:121-144:
+    label gather per subnetwork, loss_fn.mode / std, error map) and the regression metrics (metrics.py:22-34)."""
+    from mimo_unet_amd.engine import TRAIN_SCALARS, training_epilogue
+    g = torch.Generator().manual_seed(7 * S + reps)
+    N0, Ct, H, W = 3, 2, 9, 7
+    N = N0 * reps
+    out = torch.randn(N, S, 2 * Ct, H, W, generator=g)
+    label = torch.randn(N0, Ct, H, W, generator=g)
+    perms = O.draw_perms(N0, S, 0.0, reps, generator=g)  # [S, N]
+    p1, p2 = out[:, :, :Ct], out[:, :, Ct:]
+    label_t = torch.stack([label[perms[s]] for s in range(S)], dim=1)
+    std = torch.exp(p2) * 2 ** 0.5 if kind == "laplace_nll" else torch.exp(p2) ** 0.5
+    yh, y = p1.flatten().double(), label_t.flatten().double()
+    ref = {"mae": (yh - y).abs().mean(), "mse": ((yh - y) ** 2).mean(), "rmse": ((yh - y) ** 2).mean().sqrt(),
+           "r2": 1 - ((y - yh) ** 2).sum() / ((y - y.mean()) ** 2).sum(), "count": float(N * S * Ct * H * W)}
+    lt, pr, sd, err, sc = training_epilogue(out.cuda(), label.cuda(), perms.cuda(), kind)
+    torch.cuda.synchronize()
+    assert torch.equal(lt.cpu(), label_t) and torch.equal(pr.cpu(), p1)
+    assert rel_err(sd.cpu(), std) < 1e-6 and rel_err(err.cpu(), p1 - label_t) < 1e-6
+    for i, name in enumerate(TRAIN_SCALARS):
+        assert abs(sc[i].item() - float(ref[name])) <= 1e-5 * max(abs(float(ref[name])), 1e-3), name
+
+
 @pytest.mark.parametrize("case", [(1, 64, 64, 30, 30), (2, 16, 16, 45, 30), (1, 16, 16, 120, 240), (2, 32, 32, 21, 42),
                                   (1, 6, 7, 16, 33)], ids=lambda c: "x".join(map(str, c)))
 def test_bf16_conv_kernels_against_rounded_operand_reference(case):
