@@ -440,13 +440,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   constexpr int PITCH = 289;  // 32*9 + 1
   constexpr int COB = 8;
   __shared__ float tile[COB * PITCH];
-  const int coTiles = (cout_pad + 31) / 32;  // cin_pad / cout_pad are multiples of 32 or 48
+  // one (32 ci x 8 co) sub-tile per workgroup: the four sequential passes of a 32 x 32 tile were four exposed
+  // load -> LDS -> store round trips (13 us even for a 36 KB slab)
+  const int coTiles = (cout_pad + COB - 1) / COB;  // cin_pad / cout_pad are multiples of 16
   const int ciT = blockIdx.x / coTiles, coT = blockIdx.x - ciT * coTiles;
   const int ci0 = ciT * 32;
   const size_t slab4 = (size_t)9 * cin_pad * cout_pad / 4;
-  for (int pass = 0; pass < 32 / COB; ++pass) {
-    const int co0 = coT * 32 + pass * COB;
-    if (co0 >= cout_pad) break;
+  {
+    const int co0 = coT * COB;
     // the [9][32 ci][8 co] sub-tile = 576 float4 units, up to 3 per thread: independent accumulators,
     // so the loads of all units and slabs are in flight together (the kernel is pure latency otherwise)
     float4 acc[3];
@@ -496,7 +497,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       if (ci < 0) continue;
       dw[((size_t)(co0 + co) * cin + ci) * 9 + tap] = tile[co * PITCH + j];
     }
-    __syncthreads();
   }
 }
 
@@ -515,10 +515,10 @@ int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_
   const size_t slab = (size_t)9 * cin_pad * cout_pad;
   const float* src = partial;
   int n = splits;
-  const int blocks = ceil_div(cin_pad, 32) * ceil_div(cout_pad, 32);
+  const int blocks = ceil_div(cin_pad, 32) * ceil_div(cout_pad, 8);
   // few output tiles (small layers, hundreds of splits): the transposing kernel has too few workgroups to
   // stream many slabs, so stage A sums all the way down to one slab
-  const int final_fan = blocks >= 128 ? kReduceFan : 1;
+  const int final_fan = blocks >= 512 ? kReduceFan : 1;
   while (n > final_fan) {  // stage A (repeated for large split counts); output behind the inputs
     const int groups = ceil_div(n, kReduceFan);
     float* out = const_cast<float*>(src) + (size_t)n * slab;
