@@ -175,6 +175,24 @@ __device__ __forceinline__ double chunk_total(const double* __restrict__ col, si
   return (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
 }
 
+// two columns in one walk (the BatchNorm finalize kernels need sum and sum of squares): one barrier pair
+__device__ __forceinline__ void chunk_total2(const double* __restrict__ col_a, const double* __restrict__ col_b, size_t stride,
+                                             int chunks, bool valid, double* red /*[512]*/, double* ta, double* tb) {
+  double sa = 0.0, sb = 0.0;
+  if (valid)
+    for (int k = threadIdx.x >> 6; k < chunks; k += 4) {
+      sa += col_a[(size_t)k * stride];
+      sb += col_b[(size_t)k * stride];
+    }
+  __syncthreads();
+  red[threadIdx.x] = sa;
+  red[256 + threadIdx.x] = sb;
+  __syncthreads();
+  const int cl = threadIdx.x & 63;
+  *ta = (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
+  *tb = (red[256 + cl] + red[320 + cl]) + (red[384 + cl] + red[448 + cl]);
+}
+
 __global__ void vec_finalize_kernel(const double* __restrict__ sums, int chunks, int cols, int C, float* __restrict__ out) {
   __shared__ double red[256];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -245,11 +263,11 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ sums, int chun
                                        float* __restrict__ running_mean, float* __restrict__ running_var,
                                        float momentum, float eps, float* __restrict__ mean, float* __restrict__ invstd,
                                        float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double red[256];
+  __shared__ double red[512];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int cols = 2 * cout_pad;
-  const double s1 = chunk_total(sums + c, cols, chunks, c < C, red);
-  const double s2 = chunk_total(sums + cout_pad + c, cols, chunks, c < C, red);
+  double s1, s2;
+  chunk_total2(sums + c, sums + cout_pad + c, cols, chunks, c < C, red, &s1, &s2);
   if (c >= Cp || threadIdx.x >= 64) return;
   if (c >= C) {
     mean[c] = 0.f;
@@ -815,10 +833,10 @@ int bnrelu_bwd_reduce_launch(const float* da, int ldda, const float* dxpad, int 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int chunks, int C, int Cp, double count,
                                        int training, float* __restrict__ c1, float* __restrict__ c2,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double red[256];
+  __shared__ double red[512];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const double s1 = chunk_total(sums + c, (size_t)2 * Cp, chunks, c < Cp, red);
-  const double s2 = chunk_total(sums + Cp + c, (size_t)2 * Cp, chunks, c < Cp, red);
+  double s1, s2;
+  chunk_total2(sums + c, sums + Cp + c, (size_t)2 * Cp, chunks, c < Cp, red, &s1, &s2);
   if (c >= Cp || threadIdx.x >= 64) return;
   c1[c] = training ? (float)(s1 / count) : 0.f;
   c2[c] = training ? (float)(s2 / count) : 0.f;
