@@ -7,8 +7,12 @@
  * replaces (paths relative to the reference root).  All pointers are raw device
  * pointers unless marked "host"; no torch types cross this boundary.  Every function
  * returns 0 on success or a negative mimo_status; mimo_last_error() gives the message
- * (thread-local).  Calls are asynchronous on the given hipStream_t, never synchronise,
- * never allocate after mimo_plan_create(), and are not re-entrant on one plan.
+ * (thread-local).  The plan calls (mimo_forward / mimo_loss_forward / mimo_backward* / mimo_adam_step /
+ * mimo_uncertainties / the epilogues) are asynchronous on the given hipStream_t, never synchronise and
+ * never allocate device memory after mimo_plan_create(); they are not re-entrant on one plan.  The
+ * mimo_op_* single-operator entry points at the end exist for the kernel parity tests only: they allocate
+ * their own scratch and synchronise the stream before returning.  mimo_plan_profile_read() synchronises on
+ * the recorded events.
  */
 #ifndef MIMO_HIP_H
 #define MIMO_HIP_H
@@ -60,6 +64,9 @@ typedef struct mimo_config {
   float eps_min, eps_max;    /* clamp of the scale/variance, losses.py:42-45,127-130: 1e-5, 1e3 */
   int32_t device;            /* HIP device ordinal */
   int32_t precision;         /* mimo_precision: arithmetic of the 3x3 forward / data-gradient convolutions */
+  int32_t inference_only;    /* != 0: no buffers for a backward (pre-activations, activation gradients, dz /
+                              * weight-gradient scratch, data-gradient weights); mimo_forward then requires
+                              * training = 0 and no_grad = 1.  What torch.no_grad() + eval() means for memory. */
 } mimo_config;
 
 const char* mimo_last_error(void);

@@ -28,6 +28,7 @@ class MimoConfig(C.Structure):
         ("encoder_dropout_rate", C.c_float), ("core_dropout_rate", C.c_float), ("decoder_dropout_rate", C.c_float),
         ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("loss_kind", C.c_int32),
         ("eps_min", C.c_float), ("eps_max", C.c_float), ("device", C.c_int32), ("precision", C.c_int32),
+        ("inference_only", C.c_int32),
     ]
 
 

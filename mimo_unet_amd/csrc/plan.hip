@@ -323,8 +323,9 @@ struct mimo_plan {
     L.off_beta = add_tensor(L.bn_name + ".bias", {Cout}, 0);
     L.off_rm = add_tensor(L.bn_name + ".running_mean", {Cout}, 1);
     L.off_rv = add_tensor(L.bn_name + ".running_var", {Cout}, 1);
+    const bool train_bufs = !cfg.inference_only;  // everything only a backward reads or writes
     MIMO_TRY(dalloc(&L.wf, (size_t)9 * L.cout_pad * L.cin_p));
-    MIMO_TRY(dalloc(&L.wd, (size_t)9 * L.dg_rows * L.cout_p));
+    if (train_bufs) MIMO_TRY(dalloc(&L.wd, (size_t)9 * L.dg_rows * L.cout_p));
     MIMO_TRY(dalloc(&L.bias_p, L.cout_pad));
     // split-bf16 MFMA needs a K chunk of 32 channels; the 2..4-channel image conv stays on the fp32 kernel
     L.fwd_split = mfma16 && L.cin_p >= 16;
@@ -335,7 +336,7 @@ struct mimo_plan {
       MIMO_TRY(dalloc(&q, (size_t)ceil_div(L.cin_p, 32) * 9 * L.cout_pad * 64));
       L.wf16 = q;
     }
-    if (L.dg_split) {
+    if (L.dg_split && train_bufs) {
       uint16_t* q = nullptr;
       MIMO_TRY(dalloc(&q, (size_t)ceil_div(L.cout_p, 32) * 9 * L.dg_rows * 64));
       L.wd16 = q;
@@ -348,7 +349,7 @@ struct mimo_plan {
     MIMO_TRY(upload_ints(&L.fwd_row_map, frm));
     MIMO_TRY(upload_ints(&L.dg_row_map, drm));
     MIMO_TRY(upload_ints(&L.dg_col_map, dcm));
-    MIMO_TRY(dalloc(&L.z, (size_t)n * h * w * L.cout_p));
+    if (train_bufs) MIMO_TRY(dalloc(&L.z, (size_t)n * h * w * L.cout_p));
     MIMO_TRY(dalloc(&L.mean, L.cout_p));
     MIMO_TRY(dalloc(&L.invstd, L.cout_p));
     MIMO_TRY(dalloc(&L.scale, L.cout_p));
@@ -394,7 +395,7 @@ struct mimo_plan {
       o.ldda = out_ldda;
     } else {
       MIMO_TRY(dalloc(&o.a, (size_t)N * h * w * o.Cp));
-      MIMO_TRY(dalloc(&o.da, (size_t)N * h * w * o.Cp));
+      if (!cfg.inference_only) MIMO_TRY(dalloc(&o.da, (size_t)N * h * w * o.Cp));
       o.ld = o.ldda = o.Cp;
     }
     dc->c1.a = dc->mid;
@@ -432,7 +433,7 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&dc->in_buf, (size_t)N * h * w * in_cp));
     if (kind == IN_POOL) s0->pooled = true;
     static const bool skip_keep = !(getenv("MIMO_SKIP_GRAD_IN_PLACE") && atoi(getenv("MIMO_SKIP_GRAD_IN_PLACE")) == 0);
-    if (kind == IN_UPCAT && skip_keep && s0->pooled)
+    if (kind == IN_UPCAT && skip_keep && s0->pooled && !cfg.inference_only)
       MIMO_TRY(dalloc(&dc->dxpad_own, (size_t)N * (h + 2) * (w + 2) * in_cp));
     dc->in_ld = in_cp;
     dc->c1.in = dc->in_buf;
@@ -486,7 +487,7 @@ struct mimo_plan {
     x2cat.Cp = c2p * S;
     x2cat.ld = x2cat.ldda = x2cat.Cp;
     MIMO_TRY(dalloc(&x2cat.a, (size_t)N * H2 * W2 * x2cat.Cp));
-    MIMO_TRY(dalloc(&x2cat.da, (size_t)N * H2 * W2 * x2cat.Cp));
+    if (!cfg.inference_only) MIMO_TRY(dalloc(&x2cat.da, (size_t)N * H2 * W2 * x2cat.Cp));
     x2cat.chmap.assign(x2cat.Cp, -1);
     for (int s = 0; s < S; ++s)
       for (int c = 0; c < 2 * f; ++c) x2cat.chmap[s * c2p + c] = s * 2 * f + c;
@@ -573,6 +574,7 @@ struct mimo_plan {
     const int fp = pad_channels(f);
     cap_partial = std::max(cap_partial, (size_t)kEwMaxBlocks * (Co * fp + Co));
     cap_sums = std::max(cap_sums, (size_t)kMaxChunks * (Co * fp + Co));
+    if (cfg.inference_only) cap_act = cap_pad = cap_slab = 1;  // backward scratch: never touched
     MIMO_TRY(dalloc(&s_dz, cap_act));
     {
       const char* we = getenv("MIMO_WGRAD_STREAM");
@@ -651,7 +653,7 @@ struct mimo_plan {
           dg.push_back(d);
         }
       n_fwd_jobs = (int)jobs.size();
-      jobs.insert(jobs.end(), dg.begin(), dg.end());
+      if (!cfg.inference_only) jobs.insert(jobs.end(), dg.begin(), dg.end());
       n_all_jobs = (int)jobs.size();
       for (auto& j : jobs) pack_max_total = std::max(pack_max_total, j.total);
       MIMO_TRY(dalloc(&pack_jobs, jobs.size()));
@@ -756,6 +758,10 @@ struct mimo_plan {
     if (!args || !args->x || !args->out) {
       set_error("mimo_forward: null argument");
       return MIMO_ERR_INVALID;
+    }
+    if (cfg.inference_only && (args->training || !args->no_grad)) {
+      set_error("mimo_forward: inference-only plan (mimo_config.inference_only) needs training = 0 and no_grad = 1");
+      return MIMO_ERR_STATE;
     }
     // what has to be (re)derived from the parameters in this call, and whether anything is kept for a backward
     const bool training_call = args->training != 0;
@@ -1194,7 +1200,13 @@ int mimo_plan_bind(mimo_plan* plan, float* params, float* grads, float* bn_buffe
     set_error("mimo_plan_bind: null argument");
     return MIMO_ERR_INVALID;
   }
-  if (plan->params != params || plan->bnbuf != bn_buffers) plan->derived_version = -1;  // other tensors: re-derive
+  if (plan->params != params || plan->bnbuf != bn_buffers) {
+    plan->derived_version = -1;  // other tensors: re-derive
+    if (plan->graph_exec) {      // the captured head kernels hold the old parameter pointer
+      (void)hipGraphExecDestroy(plan->graph_exec);
+      plan->graph_exec = nullptr;
+    }
+  }
   plan->params = params;
   plan->grads = grads;
   plan->bnbuf = bn_buffers;

@@ -43,7 +43,8 @@ class NetGeometry:
 class Plan:
     """One plan per (network geometry, batch, height, width, device)."""
 
-    def __init__(self, geom: NetGeometry, batch: int, height: int, width: int, device: torch.device):
+    def __init__(self, geom: NetGeometry, batch: int, height: int, width: int, device: torch.device,
+                 inference_only: bool = False):
         if device.type != "cuda":
             raise L.MimoHipError("the MIMO U-Net engine runs on an AMD GPU only (no CPU fallback); got " + str(device))
         self.lib = L.load()
@@ -51,7 +52,9 @@ class Plan:
         cfg = L.MimoConfig(
             geom.in_channels, geom.out_channels, geom.num_subnetworks, geom.filter_base_count, batch, height, width,
             geom.encoder_dropout_rate, geom.core_dropout_rate, geom.decoder_dropout_rate,
-            1e-5, 0.1, L.LOSS_KINDS[geom.loss], 1e-5, 1e3, device.index or 0, L.PRECISIONS[geom.precision])
+            1e-5, 0.1, L.LOSS_KINDS[geom.loss], 1e-5, 1e3, device.index or 0, L.PRECISIONS[geom.precision],
+            int(bool(inference_only)))
+        self.inference_only = bool(inference_only)
         handle = C.c_void_p()
         with torch.cuda.device(device):
             L.check(self.lib.mimo_plan_create(C.byref(cfg), C.byref(handle)), "mimo_plan_create")

@@ -11,6 +11,7 @@ returned on the host like the reference does (it moves every pass with `.cpu()`,
 ensemble.py:101-102) unless `keep_on_device=True`."""
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -28,6 +29,7 @@ class EnsembleModule(LightningModule):
         self.monte_carlo_steps = monte_carlo_steps
         self.return_raw_predictions = return_raw_predictions
         self.keep_on_device = keep_on_device
+        self.max_samples_per_launch = max(1, int(os.environ.get("MIMO_MC_CHUNK_SAMPLES", "64")))
         self._run_device = None
         for model in self.models:
             model.eval()
@@ -71,13 +73,27 @@ class EnsembleModule(LightningModule):
         with torch.no_grad():
             for model in self.models:
                 dev = next(model.parameters()).device
-                xb = x.to(dev)
-                if passes > 1:
-                    xb = xb.repeat(passes, 1, 1, 1)  # pass-major: sample (m, i) at row m*B + i
-                n = xb.shape[0]
-                ident = torch.arange(n, device=dev, dtype=torch.int64)[None].repeat(model.num_subnetworks, 1)
-                out, _ = model.model._call(xb, None, None, ident)
+                xd = x.to(dev)
                 s, co = model.num_subnetworks, model.out_channels
+                # passes are stacked on the batch axis in chunks of at most `max_samples_per_launch` samples
+                # (the reference loops over passes in O(B) memory; one launch sequence over passes x B samples
+                # would need a passes-times larger plan)
+                chunk = max(1, min(passes, self.max_samples_per_launch // max(b, 1)))
+                net = model.model
+                recorded = net.mask_override  # tests: recorded Dropout2d masks for all passes x B samples
+                outs = []
+                try:
+                    for m0 in range(0, passes, chunk):
+                        m1 = min(passes, m0 + chunk)
+                        xb = xd if m1 - m0 == 1 else xd.repeat(m1 - m0, 1, 1, 1)  # pass-major: (m, i) at row (m-m0)*B + i
+                        n = xb.shape[0]
+                        ident = torch.arange(n, device=dev, dtype=torch.int64)[None].repeat(s, 1)
+                        if recorded is not None:
+                            net.mask_override = {j: t[m0 * b: m1 * b] for j, t in recorded.items()}
+                        outs.append(net._call(xb, None, None, ident)[0])
+                finally:
+                    net.mask_override = recorded
+                out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
                 # [passes*B, S, Co, H, W] -> [B, passes*S, Co, H, W] (pass-major on the subnetwork axis, like
                 # the reference's torch.cat of per-pass outputs)
                 out = out.view(passes, b, s, co, *out.shape[-2:]).permute(1, 0, 2, 3, 4, 5)

@@ -91,10 +91,7 @@ class EvidentialUnetModel(LightningModule):
         return dict(optimizer=optimizer, lr_scheduler=scheduler, monitor="val_loss")
 
     def _log(self, name, value, **kw):
-        try:
-            self.log(name, value, **kw)
-        except Exception:
-            pass  # no trainer attached
+        self.log(name, value, **kw)
 
     def _log_metrics(self, y_pred: torch.Tensor, y_true: torch.Tensor, stage: Literal["train", "val"] = "train") -> None:
         for name, value in compute_regression_metrics(y_pred.flatten(), y_true.flatten()).items():

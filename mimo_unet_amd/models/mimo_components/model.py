@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import logging
 import os
+from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -174,9 +175,14 @@ class MimoUNet(nn.Module):
         precision = os.environ.get("MIMO_PRECISION", "split16")
         self._geom = NetGeometry(in_channels, out_channels, S, f, encoder_dropout_rate, core_dropout_rate,
                                  decoder_dropout_rate, loss, precision)
-        self._plans: Dict[tuple, Plan] = {}
+        # one plan per (batch, H, W, device, inference-only); least recently used plans are dropped beyond
+        # MIMO_PLAN_CACHE entries (a plan owns its whole activation workspace: ragged last batches, separate
+        # train / val batch sizes and variable image sizes would otherwise pile up multi-GB plans)
+        self._plans: "OrderedDict[tuple, Plan]" = OrderedDict()
+        self._plan_cache_size = max(1, int(os.environ.get("MIMO_PLAN_CACHE", "4")))
         self._flat_params = self._flat_grads = self._flat_buffers = None
         self._param_list: List[nn.Parameter] = []
+        self._versioned: List[torch.Tensor] = []
         self._flat_device = None
         self.mask_override: Optional[Dict[int, torch.Tensor]] = None  # tests: {double-conv index: [N,C] multipliers}
         # tests: {"center" | "final{s}": full-shape nn.Dropout multipliers (reference NCHW layout)}
@@ -210,7 +216,7 @@ class MimoUNet(nn.Module):
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._flat_params = None  # .to()/.cuda() re-created the tensors: re-flatten lazily
-        self._plans = {}
+        self._plans = OrderedDict()
         return r
 
     def _ensure_flat(self, plan: Plan, device) -> None:
@@ -243,18 +249,26 @@ class MimoUNet(nn.Module):
         self._param_views = [(p, self._flat_grads[sp.offset: sp.offset + sp.numel].view(sp.shape))
                              for p, sp in zip(plist, [s for s in plan.specs if s.kind == 0])]
         self._flat_device = device
+        self._versioned = plist + [named_b[sp.name] for sp in plan.specs if sp.kind == 1]
 
-    def _plan_for(self, x: torch.Tensor, perm: Optional[torch.Tensor]) -> Plan:
+    def _plan_for(self, x: torch.Tensor, perm: Optional[torch.Tensor], inference: bool = False) -> Plan:
+        """inference: a plan without the buffers only a backward needs (pre-activation tensors, activation
+        gradients, dz / padded-gradient / weight-gradient scratch, data-gradient weight copies) — what eval
+        mode under torch.no_grad() uses, e.g. the passes x B samples of an MC-dropout ensemble."""
         if not x.is_cuda:
             raise L.MimoHipError("MimoUNet runs on an AMD GPU through libmimo_hip.so; move the module and its inputs "
                                  "to cuda (there is no CPU execution path)")
         n = perm.shape[1] if perm is not None else x.shape[0]
-        key = (n, x.shape[-2], x.shape[-1], x.device.index)
+        key = (n, x.shape[-2], x.shape[-1], x.device.index, bool(inference))
         plan = self._plans.get(key)
         if plan is None:
-            plan = Plan(self._geom, n, x.shape[-2], x.shape[-1], x.device)
+            while len(self._plans) >= self._plan_cache_size:
+                self._plans.popitem(last=False)  # a pending autograd node keeps its own reference to its plan
+            plan = Plan(self._geom, n, x.shape[-2], x.shape[-1], x.device, inference_only=inference)
             plan.generation = 0
             self._plans[key] = plan
+        else:
+            self._plans.move_to_end(key)
         self._ensure_flat(plan, x.device)
         return plan
 
@@ -330,8 +344,9 @@ class MimoUNet(nn.Module):
         masks = self._dropout_masks(n, x.device)
         elem_masks = self._elem_dropout_masks(n, x.shape[-2], x.shape[-1], x.device)
         # make sure the flat storage exists before the parameters are handed to autograd
-        plan = self._plan_for(x, perm)
-        if not bn_training and not torch.is_grad_enabled():
+        inference = not bn_training and not torch.is_grad_enabled()
+        plan = self._plan_for(x, perm, inference=inference)
+        if inference:
             # inference (eval mode under torch.no_grad()): no autograd node, BatchNorm + ReLU folded into the
             # convolution epilogue, packed weights reused while the parameters have not changed
             out = torch.empty(n, self.num_subnetworks, self.out_channels, plan.height, plan.width, device=x.device,
@@ -378,6 +393,11 @@ class MimoUNet(nn.Module):
         hook = self.grad_ready_hook
         if hook is None:
             plan.backward(dout, dloss, dx)
+        elif aliased:
+            # gradient accumulation (a live .grad aliases the flat buffer): the fix-up below adds the saved
+            # gradients into the same memory an in-flight all-reduce would be reducing, so the ranges are only
+            # announced once they are final — no overlap on accumulating micro-batches
+            plan.backward(dout, dloss, dx)
         else:
             # data-parallel overlap: the core/decoder/head gradients (the tail of the flat buffer, 99 % of
             # its bytes) are final after stage 0; their all-reduce runs while the encoders back-propagate
@@ -393,15 +413,31 @@ class MimoUNet(nn.Module):
                 v.add_(saved[off: off + v.numel()].view(v.shape))
             else:
                 p.grad.add_(v)
+        if hook is not None and aliased:
+            hook(g, plan.encoder_param_floats, g.numel())
+            hook(g, 0, plan.encoder_param_floats)
 
     def mark_parameters_changed(self) -> None:
         """Call after writing the flat parameter / buffer storage through a raw pointer."""
         self._param_epoch += 1
 
     def _param_version(self) -> int:
+        """Changes whenever the parameters / BatchNorm buffers may have changed.  The nn.Parameters are views
+        of the flat storage but carry their OWN torch version counters (`load_state_dict`, `p.copy_()`, EMA
+        swaps bump those, not the flat tensor's), so all of them are folded in; writers that go through
+        `.data` or a raw pointer are invisible to torch and must call `mark_parameters_changed()`."""
         if self._flat_params is None:
             return 0
-        return (self._param_epoch << 40) + (self._flat_params._version << 20) + self._flat_buffers._version + 1
+        v = self._flat_params._version + self._flat_buffers._version
+        for t in self._versioned:
+            v += t._version
+        return (self._param_epoch << 40) + v + 1
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        # any (partial) load may rewrite parameters in place: never serve packed weights derived before it
+        r = super()._load_from_state_dict(*args, **kwargs)
+        self._param_epoch += 1
+        return r
 
     # flat views for the fused optimiser / gradient all-reduce
     def flat_parameters(self) -> torch.Tensor:

@@ -196,17 +196,20 @@ class MimoUnetModel(LightningModule):
         return dict(optimizer=optimizer, lr_scheduler=scheduler, monitor="val_loss")
 
     # ------------------------------------------------------------------ logging ----------------
-    def _batch_size(self) -> Optional[int]:
+    def _attached_trainer(self):
+        """The trainer, or None in hand-written loops / benchmarks (Lightning's `trainer` property raises
+        RuntimeError while the module is not attached; the stand-in base class holds None)."""
         try:
-            return self.trainer.datamodule.batch_size
-        except Exception:
+            return self.trainer
+        except RuntimeError:
             return None
 
+    def _batch_size(self) -> Optional[int]:
+        # the reference reads self.trainer.datamodule.batch_size (mimo_unet.py:250)
+        return getattr(getattr(self._attached_trainer(), "datamodule", None), "batch_size", None)
+
     def _log(self, name, value, **kw):
-        try:
-            self.log(name, value, batch_size=self._batch_size(), **kw)
-        except Exception:
-            pass  # no trainer attached (hand-written loops, benchmarks)
+        self.log(name, value, batch_size=self._batch_size(), **kw)
 
     def _log_train_loss_and_weights(self, loss: torch.Tensor, weights: torch.Tensor) -> None:
         self._log("train_loss", loss.mean())

@@ -188,3 +188,127 @@ def test_evidential_loss_class_matches_golden():
                                rtol=1e-5)
     assert torch.equal(crit.mode(ev), ev[:, 0]) and crit.num_distribution_params == 4
     assert float(crit(ev, y, reduce_mean=True)) == float(crit(ev, y).mean())
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/mimo"), reason="needs the reference checkout (build container only)")
+def test_alias_package_resolves_unmirrored_submodules_from_the_reference():
+    """scripts/train/train_ndvi.py:10-13 imports mimo.models.* (mirrored here) and mimo.tasks / mimo.datasets (not):
+    with the repo first and the reference second on PYTHONPATH both resolve, each from its own tree."""
+    import subprocess
+    import sys
+    code = ("import mimo.models.mimo_unet as a, mimo.models.ensemble as e, mimo.losses as l\n"
+            "import mimo.regularization as r, mimo.visualization as v\n"
+            "print(a.__file__); print(e.__file__); print(l.__file__); print(r.__file__); print(v.__file__)\n")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + "/root/reference", PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    files = out.stdout.split()
+    assert all(f.startswith(ROOT + os.sep) for f in files[:3]), files
+    assert all(f.startswith("/root/reference/") for f in files[3:]), files
+
+
+class _FakeFlatNet(torch.nn.Module):
+    """Two parameters that are views of one flat buffer, like MimoUNet after _ensure_flat."""
+
+    def __init__(self):
+        super().__init__()
+        self.flat = torch.arange(10, dtype=torch.float32) / 10
+        self.grads = torch.zeros(10)
+        self.a = torch.nn.Parameter(torch.zeros(2, 3))
+        self.b = torch.nn.Parameter(torch.zeros(4))
+        self.a.data = self.flat[0:6].view(2, 3)
+        self.b.data = self.flat[6:10]
+
+    def flat_parameters(self):
+        return self.flat
+
+    def flat_gradients(self):
+        return self.grads
+
+
+def _torch_adam_step(p, g, m, v, *, lr, betas, eps, weight_decay, step, grad_scale):
+    g = g * grad_scale + weight_decay * p
+    m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+    v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+    p.sub_(lr * (m / (1 - betas[0] ** step)) / ((v / (1 - betas[1] ** step)).sqrt() + eps))
+
+
+def test_flat_adam_state_roundtrip_and_reference_adam_state(monkeypatch):
+    """FlatAdam.load_state_dict: own checkpoints survive a CPU-mapped save/load (no silent re-zeroing of the
+    moments), a reference torch.optim.Adam state_dict is scattered into the flat layout, the caller's dict is
+    left alone, and a wrong-sized state is an error."""
+    import copy
+    import io
+
+    from mimo_unet_amd import optim as OP
+    monkeypatch.setattr(OP, "adam_step", _torch_adam_step)
+    g = torch.Generator().manual_seed(0)
+    grads = [torch.randn(10, generator=g) for _ in range(4)]
+
+    def run(net, opt, gs):
+        for gr in gs:
+            net.grads.copy_(gr)
+            opt.step()
+
+    net = _FakeFlatNet()
+    opt = OP.FlatAdam(net, lr=1e-2)
+    run(net, opt, grads[:2])
+    buf = io.BytesIO()
+    torch.save({"opt": opt.state_dict(), "flat": net.flat.clone()}, buf)
+    run(net, opt, grads[2:])
+    want = net.flat.clone()
+    # resume from the checkpoint
+    ck = torch.load(io.BytesIO(buf.getvalue()), map_location="cpu", weights_only=False)
+    net2 = _FakeFlatNet()
+    net2.flat.copy_(ck["flat"])
+    opt2 = OP.FlatAdam(net2, lr=1e-2)
+    before = copy.deepcopy({k: v for k, v in ck["opt"].items() if k != "flat"})
+    opt2.load_state_dict(ck["opt"])
+    assert "flat" in ck["opt"] and {k: v for k, v in ck["opt"].items() if k != "flat"} == before  # not mutated
+    run(net2, opt2, grads[2:])
+    assert torch.equal(net2.flat, want)
+    # a reference torch.optim.Adam checkpoint (per-parameter state)
+    net3 = _FakeFlatNet()
+    ref = torch.optim.Adam(net3.parameters(), lr=1e-2)
+    for gr in grads[:2]:
+        net3.a.grad, net3.b.grad = gr[:6].view(2, 3).clone(), gr[6:].clone()
+        ref.step()
+    net4 = _FakeFlatNet()
+    net4.flat.copy_(net3.flat)
+    opt4 = OP.FlatAdam(net4, lr=1e-2)
+    opt4.load_state_dict(ref.state_dict())
+    for gr in grads[2:]:
+        net3.a.grad, net3.b.grad = gr[:6].view(2, 3).clone(), gr[6:].clone()
+        ref.step()
+    run(net4, opt4, grads[2:])
+    assert opt4._step == 4
+    torch.testing.assert_close(net4.flat, net3.flat, rtol=1e-6, atol=1e-7)
+    # wrong architecture
+    bad = opt.state_dict()
+    bad["flat"] = {"step": 1, "exp_avg": torch.zeros(7), "exp_avg_sq": torch.zeros(7)}
+    with pytest.raises(ValueError):
+        opt2.load_state_dict(bad)
+
+
+def test_logging_without_a_trainer_and_parameter_version_tracks_loads():
+    from mimo.models.mimo_unet import MimoUnetModel
+    m = MimoUnetModel(in_channels=3, out_channels=2, num_subnetworks=2, filter_base_count=4, center_dropout_rate=0.0,
+                      final_dropout_rate=0.0, encoder_dropout_rate=0.0, core_dropout_rate=0.0, decoder_dropout_rate=0.0,
+                      loss="laplace_nll", weight_decay=0.0, learning_rate=1e-3, seed=0, loss_buffer_size=10,
+                      loss_buffer_temperature=0.3)
+    assert m._batch_size() is None
+    m._log("x", torch.tensor(1.0))
+    assert float(m.logged["x"]) == 1.0
+
+    class DM:
+        batch_size = 7
+
+    class TR:
+        datamodule = DM()
+
+    m.trainer = TR()
+    assert m._batch_size() == 7
+    # every load_state_dict through the net invalidates the inference cache key
+    e0 = m.model._param_epoch
+    m.load_state_dict(m.state_dict())
+    assert m.model._param_epoch > e0
