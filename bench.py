@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: MIMO U-Net training throughput (images/s) at 256x256, S=2, fbc=30.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--config cfg3|cfg2|cfg4]
+
+N > 1 without a torch.distributed environment: this process starts the N ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before anything here touches the GPU) and
+exits with the child's status; under torch.distributed.run (RANK / WORLD_SIZE set) it is one rank.
 
 One "step" = what Lightning runs per batch for the reference's `MimoUnetModel`
 (mimo/models/mimo_unet.py:115-144 + backward + Adam): draw the S batch permutations,
 forward (gather fused into the first kernel), Laplace NLL, loss-buffer weighting, backward,
-[gradient all-reduce over RCCL when N>1], fused Adam.  Synthetic U[0,1) inputs, PyTorch
-default random init, fp32 end to end.  Weak scaling: the per-GPU batch is fixed (32, the
-reference README's SEN12TP batch size; Lightning DDP semantics = per-device batch).
+[gradient all-reduce over RCCL when N>1], fused Adam.  Synthetic inputs resident in HBM: image ~ U[0,1),
+label = `learnable_label(image)` (a smoothed channel mix + uniform noise; SURVEY 8d's U[0,1) labels make the
+NLL's scale head collapse on single pixels after ~100 steps in every arithmetic), the same batch every
+step, PyTorch default random init, fp32 storage.
 
-Prints ONE JSON line on rank 0 with the throughput, the roofline of the dominant kernel class
-(device time from HIP events recorded around every launch inside the timed region) and — at
-N=1 — the CPU oracle timed on this box's host cores for the same workload shape.
+Scaling: "weak" (default) = the per-GPU batch is fixed at the config's batch (32: the reference README's
+SEN12TP batch size with Lightning-DDP semantics, batch_size = per device); "strong" = the config's batch is
+the GLOBAL batch, sharded over the ranks (32 global, 4 per GPU at 8).
+
+The timed region runs WITHOUT instrumentation.  A second, shorter pass with HIP events recorded on the launch
+stream around every kernel class and every resolution tier gives the roofline numbers; at N=1 the CPU oracle
+is timed on this box's host cores for the same workload shape.  ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,15 +38,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # BASELINE.json configs[2] geometry; per-GPU batch 32 (README: --batch_size 32)
-    "cfg3": dict(name="cfg3: SEN12TP-shape synthetic 2->1 ch, 256x256, S=2, fbc=30, laplace_nll, batch 32 per GPU",
+    # BASELINE.json configs[2] geometry; batch 32 (README: --batch_size 32)
+    "cfg3": dict(name="cfg3: SEN12TP-shape synthetic 2->1 ch, 256x256, S=2, fbc=30, laplace_nll",
                  Ci=2, Co=2, S=2, f=30, H=256, W=256, batch=32),
     # BASELINE.json configs[1]
-    "cfg2": dict(name="cfg2: NYUv2-shape synthetic 3->1 ch, 256x256, S=2, fbc=21, laplace_nll, batch 64 per GPU",
+    "cfg2": dict(name="cfg2: NYUv2-shape synthetic 3->1 ch, 256x256, S=2, fbc=21, laplace_nll",
                  Ci=3, Co=2, S=2, f=21, H=256, W=256, batch=64),
-    # BASELINE.json configs[3] geometry (S=4 head-width stress; 128 global / 8 GPUs); run with MIMO_PRECISION=bf16
-    # for its arithmetic
-    "cfg4": dict(name="cfg4: synthetic 2->1 ch, 256x256, S=4, fbc=30, laplace_nll, batch 16 per GPU",
+    # BASELINE.json configs[3] geometry (S=4 head-width stress; 128 global = 16 per GPU at 8); run with
+    # MIMO_PRECISION=bf16 for its arithmetic
+    "cfg4": dict(name="cfg4: synthetic 2->1 ch, 256x256, S=4, fbc=30, laplace_nll",
                  Ci=2, Co=2, S=4, f=30, H=256, W=256, batch=16),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the vector rate
@@ -55,6 +66,40 @@ def learnable_label(image, noise=0.05, generator=None):
     return smooth + noise * (torch.rand(smooth.shape, device=image.device, generator=generator) - 0.5)
 
 
+def conv_layers(c):
+    """(tier, Cin, Cout, H, W, kernel) of every convolution of the network, per SURVEY 8(d) "Formula for any
+    config" (reference layer widths: model.py:150-175,190-243,260-297)."""
+    S, f, Ci, Co, H, W = c["S"], c["f"], c["Ci"], c["Co"], c["H"], c["W"]
+    w = f * S
+    L = []
+
+    def dc(tier, cin, mid, cout, times=1):
+        h, ww = H >> tier, W >> tier
+        L.extend([(tier, cin, mid, h, ww, 3), (tier, mid, cout, h, ww, 3)] * times)
+
+    dc(0, Ci, f, f, S)
+    dc(1, f, 2 * f, 2 * f, S)
+    dc(2, 2 * w, 4 * w, 4 * w)
+    dc(3, 4 * w, 8 * w, 8 * w)
+    dc(4, 8 * w, 8 * w, 8 * w)
+    dc(3, 16 * w, 8 * w, 4 * w)
+    dc(2, 8 * w, 4 * w, 2 * w)
+    dc(1, 4 * w, 2 * w, w)
+    dc(0, w + f, (w + f) // 2, f, S)
+    L.extend([(0, f, Co, H, W, 1)] * S)
+    return L
+
+
+def algorithmic_bytes_per_image(c):
+    """train = 3 x forward, forward = sum over conv layers of (input + output) tensor bytes (fp32),
+    every other operator fused away.  Returns ([bytes per tier], total).  cfg3: 525.3 / 188.7 / 94.4 / 47.2 /
+    5.9 MB = 861.5 MB per image."""
+    tiers = [0.0] * 5
+    for t, cin, cout, h, w, _ in conv_layers(c):
+        tiers[t] += 3.0 * 4.0 * (cin + cout) * h * w
+    return tiers, sum(tiers)
+
+
 def make_model(c):
     from mimo.models.mimo_unet import MimoUnetModel
     return MimoUnetModel(in_channels=c["Ci"], out_channels=c["Co"], num_subnetworks=c["S"], filter_base_count=c["f"],
@@ -63,28 +108,27 @@ def make_model(c):
                          loss_buffer_size=10, loss_buffer_temperature=0.3)
 
 
-def pmc_traffic(kernel_class):
-    """HBM bytes per launch of a kernel class from the committed counter passes of this same command
-    (profiles/<round>/final/pmc_traffic.json, written from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs —
-    counters cannot be collected from inside the timed run).  None when no summary is committed."""
+def pmc_traffic():
+    """HBM bytes from the committed counter passes of this same command (profiles/<round>/final/pmc_traffic.json,
+    written from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs — counters cannot be collected from inside the
+    timed run).  None when no summary is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "final", "pmc_traffic.json")))
     if not files:
         return None, None
     try:
         with open(files[-1]) as fh:
-            t = json.load(fh)
-        return int(t["classes"][kernel_class]["bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
-    except (KeyError, ValueError, OSError):
+            return json.load(fh), os.path.relpath(files[-1], ROOT)
+    except (ValueError, OSError):
         return None, None
 
 
-def cpu_baseline(c, batch=4, steps=2, threads=None):
-    """The CPU oracle (restatement of the reference's step, pinned to reference goldens) on the
-    host cores of this box: same network shape, bounded sample.  Thread count: torch's CPU
-    convolutions stop scaling (and collapse when oversubscribed) well below this box's core
-    count (measured on the 256-core GPU box: 8 thr 2.6, 16 thr 3.4, 32 thr 3.0, 64 thr 1.7, 128 thr 0.8
-    images/s), so the run uses min(cores, MIMO_BENCH_CPU_THREADS or 16) threads and reports that."""
+def cpu_baseline(c, batch=8, warmup=2, steps=5, threads=None):
+    """The CPU oracle (restatement of the reference's step, pinned to reference goldens) on the host cores of
+    this box: same network shape, SURVEY 8(d)'s bounded sample (batch 8, 2 warm-up + 5 timed steps, ~20 s).
+    Thread count: torch's CPU convolutions stop scaling (and collapse when oversubscribed) well below this
+    box's core count (measured on the 256-core GPU box: 8 thr 2.6, 16 thr 3.4, 32 thr 3.0, 64 thr 1.7, 128 thr
+    0.8 images/s), so the run uses min(cores, MIMO_BENCH_CPU_THREADS or 16) threads and reports that."""
     from oracle import mimo_oracle as O
     threads = threads or min(os.cpu_count() or 1, int(os.environ.get("MIMO_BENCH_CPU_THREADS", "16")))
     torch.set_num_threads(threads)
@@ -94,15 +138,32 @@ def cpu_baseline(c, batch=4, steps=2, threads=None):
     image = torch.rand(batch, c["Ci"], c["H"], c["W"], generator=g)
     label = learnable_label(image, generator=g)
     times = []
-    for i in range(steps + 1):
+    for i in range(warmup + steps):
         perms = O.draw_perms(batch, c["S"], generator=g)
         t0 = time.perf_counter()
         O.train_step(ts, image, label, None, perms)
         times.append(time.perf_counter() - t0)
-    dt = sum(times[1:]) / steps
+    dt = sum(times[warmup:]) / steps
     return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} timed steps (1 warm-up) of the same network shape at batch {batch}, fp32, "
+            "sample": f"{steps} timed steps ({warmup} warm-up) of the same network shape at batch {batch}, fp32, "
                       f"torch {torch.__version__} CPU, {dt * 1e3:.0f} ms/step"}
+
+
+def spawn_ranks(args):
+    """Parent of an N-rank run: start the ranks as a CHILD process tree before this process touches the GPU
+    (never re-exec a process that has initialised HIP), forward its output, return its status."""
+    have = torch.cuda.device_count()  # does not initialise the GPU on this image
+    if have < args.gpus and os.environ.get("MIMO_BENCH_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"--gpus {args.gpus} but only {have} GPU(s) visible (MIMO_BENCH_BACKEND=gloo lets ranks share one)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -111,19 +172,25 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--batch", type=int, default=0, help="the config's batch (per GPU when weak, global when strong)")
+    ap.add_argument("--scaling", default=os.environ.get("MIMO_BENCH_SCALING", "weak"), choices=["weak", "strong"])
+    ap.add_argument("--profile-steps", type=int, default=5, help="steps of the instrumented second pass (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
     c = dict(CONFIGS[args.config])
     if args.batch:
-        c["name"] = c["name"].replace(f"batch {c['batch']} per GPU", f"batch {args.batch} per GPU (non-default)")
         c["batch"] = args.batch
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.scaling == "strong" and c["batch"] % world:
+        raise SystemExit(f"strong scaling: global batch {c['batch']} does not split over {world} ranks")
+    B = c["batch"] // world if args.scaling == "strong" else c["batch"]  # per-GPU batch
     # one process per GPU over RCCL ("nccl").  MIMO_BENCH_BACKEND=gloo lets several ranks share one GPU
     # (functional check of the data-parallel path on a single-GPU box; not a performance configuration)
     backend = os.environ.get("MIMO_BENCH_BACKEND", "nccl")
@@ -144,35 +211,52 @@ def main():
     torch.manual_seed(1)
     model = make_model(c).cuda()
     model.train()
+    if dist is not None:
+        # DDP semantics: every rank starts from rank 0's parameters and buffers (not from a shared seed)
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
     opt = model.configure_optimizers()["optimizer"]
     opt.grad_scale = 1.0 / world
-    g = torch.Generator(device="cuda").manual_seed(100 + rank)
-    B = c["batch"]
-    image = torch.rand(B, c["Ci"], c["H"], c["W"], device="cuda", generator=g)
-    # targets the image predicts (see learnable_label): with all-noise labels the NLL's scale head collapses on
-    # single pixels and the loss spikes (reproduced by the fp64 CPU oracle, tests/tools/diag_trained_state.py)
-    label = learnable_label(image, generator=g)
-    batch = {"image": image, "label": label}
+    if args.scaling == "strong":
+        # the global batch, identical on every rank, sharded by rank (ddp.shard_batch: rows [r*B, (r+1)*B))
+        from mimo_unet_amd.ddp import shard_batch
+        g = torch.Generator(device="cuda").manual_seed(100)
+        image = torch.rand(c["batch"], c["Ci"], c["H"], c["W"], device="cuda", generator=g)
+        batch = shard_batch({"image": image, "label": learnable_label(image, generator=g)}, rank, world)
+        batch = {k: v.contiguous() for k, v in batch.items()}
+    else:
+        g = torch.Generator(device="cuda").manual_seed(100 + rank)
+        image = torch.rand(B, c["Ci"], c["H"], c["W"], device="cuda", generator=g)
+        batch = {"image": image, "label": learnable_label(image, generator=g)}
 
     from mimo_unet_amd.ddp import FlatGradientAllReducer
     reducer = FlatGradientAllReducer() if dist is not None else None
     if reducer is not None:
         reducer.always = force_dist  # one-rank functional check: still issue the RCCL all-reduces
-        reducer.attach(model.model)  # all-reduce of the core/decoder gradients overlaps the encoder backward
+        reducer.attach(model.model)  # all-reduces start from inside the backward, as gradient ranges become final
 
-    def step(i):
+    adam_events = []
+
+    def step(i, time_adam=False):
         opt.zero_grad()
         out = model.training_step(batch, i)
         out["loss"].backward()
         if reducer is not None:
             reducer.finish()  # bucketed sums over RCCL were started from inside backward; FlatAdam scales by 1/world
-        opt.step()
+        if time_adam:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            opt.step()
+            e1.record()
+            adam_events.append((e0, e1))
+        else:
+            opt.step()
         return out["loss"]
 
     for i in range(args.warmup):
         step(i)
-    plan = next(iter(model.model._plans.values()))
-    plan.profile(True)
+    plan = next(p for p in model.model._plans.values() if not p.inference_only)
+    # ---- timed region: EXACTLY --steps steps, no instrumentation ----
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -183,61 +267,109 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof = plan.profile_read()
-    plan.profile(False)
+    final_loss = float(loss.detach())
+    # ---- second pass: HIP events on the launch stream around every kernel class / resolution tier ----
+    prof, tiers, psteps = {}, [], max(0, args.profile_steps)
+    if psteps:
+        plan.profile(True)
+        for i in range(psteps):
+            step(i, time_adam=True)
+        torch.cuda.synchronize()
+        prof, tiers = plan.profile_read(), plan.profile_read_tiers()
+        plan.profile(False)
+    identical = None
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # data-parallel invariant: the same initial parameters + the same summed gradients => bit-identical parameters
+        flat = model.model.flat_parameters()
+        ref = flat.clone()
+        dist.broadcast(ref, 0)
+        same = torch.tensor([1 if torch.equal(ref, flat) else 0], device="cuda", dtype=torch.int32)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        identical = bool(same.item())
     if rank != 0:
         dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
-    kernels = {}
-    for name, r in prof.items():
-        if r["launches"] == 0:
-            continue
-        sec = r["ms"] * 1e-3
-        kernels[name] = {"avg_us": round(r["ms"] * 1e3 / r["launches"], 2), "launches_per_step": r["launches"] // args.steps,
-                         "ms_per_step": round(r["ms"] / args.steps, 3), "tflops": round(r["flops"] / sec / 1e12, 2),
-                         "algorithmic_gbs": round(r["bytes"] / sec / 1e9, 1),
-                         "algorithmic_bytes_per_launch": int(r["bytes"] / r["launches"])}
-    # bandwidth-class kernels (HBM roofline) are reported next to the convolution classes (MFMA roofline)
-    bw_kernels = {k: kernels.pop(k) for k in list(kernels) if not k.startswith("conv3x3")}
-    for v in bw_kernels.values():
-        v["hbm_frac"] = round(v["algorithmic_gbs"] / HBM_PEAK_GBS, 4)
-        del v["tflops"]
-    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     precision = os.environ.get("MIMO_PRECISION", "split16")
-    peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "split16": SPLIT16_PEAK_TFLOPS, "bf16": 2500.0}[precision]
-    traffic, traffic_src = pmc_traffic(dom) if (args.config == "cfg3" and precision == "split16") else (None, None)
-    roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                "arithmetic": {"fp32": "f32-input MFMA",
-                               "split16": "3x 16-bit MFMA per product (fp16 hi/lo forward, bf16 hi/lo gradients), fp32 "
-                                          "accumulate; peak = 2500 TFLOP/s dense 16-bit MFMA / 3",
-                               "bf16": "bf16 MFMA operands (one MFMA per product), fp32 accumulate and storage — reduced "
-                                       "precision, NOT the fp32 metric"}[precision],
-                "hbm_frac_algorithmic": round(kernels[dom]["algorithmic_gbs"] / HBM_PEAK_GBS, 4),
-                "conv_ms_per_step": round(sum(k["ms_per_step"] for k in kernels.values()), 2), "kernels": kernels,
-                # the bandwidth class, priced against HBM (8000 GB/s): algorithmic bytes (8 or 12 B per element of the
-                # BatchNorm passes) / HIP-event time of the same timed region
-                "bandwidth_kernels": {"peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": bw_kernels}}
+    tier_bytes, bytes_per_image = algorithmic_bytes_per_image(c)
+    weight_bytes = 3.0 * 4.0 * sum(cin * cout * k * k for _, cin, cout, _, _, k in conv_layers(c))
+    step_bytes = bytes_per_image * B + weight_bytes
     line = {
         "metric": "train images/sec at 256x256, S=2, fbc=30" if args.config == "cfg3" else f"train images/sec ({args.config})",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": {"fp32": "f32", "split16": "f32 (split into 16-bit hi/lo pairs on the MFMA)",
-                  "bf16": "bf16 MFMA operands, f32 accumulate/storage (reduced precision)"}[precision],
+                  "bf16": "bf16 MFMA operands, f32 accumulate/storage (reduced precision)"}.get(precision, precision),
         "data": "synthetic",
-        "config": {"workload": c["name"], "global_batch": world * B, "per_gpu_batch": B, "image": [c["H"], c["W"]],
-                   "parallelism": f"dp{world}" + ("" if world == 1 else f" ({backend}, all-reduce overlapped with the encoder backward)"),
-                   "optimizer": "adam(lr=1e-3) fused", "final_loss": round(float(loss.detach()), 5)},
-        "roofline": roofline,
+        "config": {"workload": f"{c['name']}, batch {c['batch']} " + ("global" if args.scaling == "strong" else "per GPU"),
+                   "global_batch": world * B, "per_gpu_batch": B, "image": [c["H"], c["W"]], "scaling": args.scaling,
+                   "labels": "learnable_label(image): 5x5-smoothed channel mix + U(-0.025, 0.025) noise; same batch every step",
+                   "parallelism": f"dp{world}" + ("" if dist is None else f" ({backend}: bucketed all-reduce started inside the backward)"),
+                   "rccl_ranks": None if dist is None else dist.get_world_size(),
+                   "params_bit_identical_across_ranks": identical,
+                   "optimizer": "adam(lr=1e-3) fused", "final_loss": round(final_loss, 5)},
+        # whole step against HBM: SURVEY 8(d) algorithmic bytes (activations + 3 x weights) / wall time / 8 TB/s
+        "hbm_frac_step": round(step_bytes / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
     }
+    if psteps:
+        kernels = {}
+        for name, r in prof.items():
+            if r["launches"] == 0:
+                continue
+            sec = r["ms"] * 1e-3
+            kernels[name] = {"avg_us": round(r["ms"] * 1e3 / r["launches"], 2), "launches_per_step": r["launches"] // psteps,
+                             "ms_per_step": round(r["ms"] / psteps, 3), "tflops": round(r["flops"] / sec / 1e12, 2),
+                             "algorithmic_gbs": round(r["bytes"] / sec / 1e9, 1),
+                             "algorithmic_bytes_per_launch": int(r["bytes"] / r["launches"])}
+        # bandwidth-class kernels (HBM roofline) are reported next to the convolution classes (MFMA roofline)
+        bw_kernels = {k: kernels.pop(k) for k in list(kernels) if not k.startswith("conv3x3")}
+        for v in bw_kernels.values():
+            v["hbm_frac"] = round(v["algorithmic_gbs"] / HBM_PEAK_GBS, 4)
+            del v["tflops"]
+        if adam_events:
+            ms = sum(a.elapsed_time(b) for a, b in adam_events) / len(adam_events)
+            nparam = model.model.flat_parameters().numel()
+            bw_kernels["adam"] = {"avg_us": round(ms * 1e3, 2), "launches_per_step": 1, "ms_per_step": round(ms, 3),
+                                  "algorithmic_gbs": round(28.0 * nparam / (ms * 1e-3) / 1e9, 1),
+                                  "algorithmic_bytes_per_launch": 28 * nparam,
+                                  "hbm_frac": round(28.0 * nparam / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "split16": SPLIT16_PEAK_TFLOPS, "bf16": 2500.0}.get(precision, 2500.0)
+        traffic = traffic_src = step_traffic = None
+        if args.config == "cfg3" and precision == "split16" and args.scaling == "weak" and not args.batch:
+            pt, traffic_src = pmc_traffic()
+            if pt is not None:
+                traffic = int(pt["classes"][dom]["bytes_per_launch"]) if dom in pt.get("classes", {}) else None
+                step_traffic = pt.get("step_bytes")
+        tier_ms = [(f + b) / psteps for f, b in tiers]
+        line["roofline"] = {
+            "kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+            "step_traffic_bytes": step_traffic,
+            "arithmetic": {"fp32": "f32-input MFMA",
+                           "split16": "3x 16-bit MFMA per product (fp16 hi/lo forward, bf16 hi/lo gradients), fp32 "
+                                      "accumulate; peak = 2500 TFLOP/s dense 16-bit MFMA / 3",
+                           "bf16": "bf16 MFMA operands (one MFMA per product), fp32 accumulate and storage — reduced "
+                                   "precision, NOT the fp32 metric"}.get(precision, precision),
+            "source": f"second pass of {psteps} steps with HIP events on the launch stream (the timed region is not instrumented)",
+            "hbm_frac_algorithmic": round(kernels[dom]["algorithmic_gbs"] / HBM_PEAK_GBS, 4),
+            "conv_ms_per_step": round(sum(k["ms_per_step"] for k in kernels.values()), 2), "kernels": kernels,
+            # per resolution tier: algorithmic activation bytes of the tier's conv layers (train = 3 x
+            # forward) / summed device time of EVERY kernel launched for that tier's blocks / 8 TB/s
+            "tiers": {f"{c['H'] >> t}x{c['W'] >> t}": {
+                "ms_per_step": round(tier_ms[t], 3), "algorithmic_mb_per_image": round(tier_bytes[t] / 1e6, 1),
+                "hbm_frac": round(tier_bytes[t] * B / (tier_ms[t] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if tier_ms[t] > 0 else None}
+                for t in range(5)},
+            # the bandwidth class, priced against HBM (8000 GB/s): algorithmic bytes / HIP-event time
+            "bandwidth_kernels": {"peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "ms_per_step": round(sum(k["ms_per_step"] for k in bw_kernels.values()), 2),
+                                  "kernels": bw_kernels}}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(c)
     print(json.dumps(line), flush=True)

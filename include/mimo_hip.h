@@ -142,11 +142,15 @@ int mimo_loss_forward(mimo_plan* plan, const float* label, const float* mask, co
  * Parameter gradients are written (not accumulated) into the bound flat grads buffer. */
 int mimo_backward(mimo_plan* plan, const float* dout, const float* dloss, float* dx, mimo_stream stream);
 
-/* The same backward in two stages, for data-parallel training (no reference counterpart: the reference
- * is single-GPU).  stage 0 = heads + decoders + shared core, stage 1 = the S encoders (+ dx).  The flat
- * gradient buffer is laid out encoder | core | decoder | heads, so after stage 0 the range
- * [mimo_plan_encoder_param_floats(plan), mimo_plan_param_floats(plan)) — 99 % of the bytes — is final
- * and its all-reduce can overlap stage 1. */
+/* The same backward in stages, for data-parallel training (no reference counterpart: the reference is
+ * single-GPU, scripts/train/train_ndvi.py:70 `devices=1`).  Stages run in order 0 .. n-1:
+ *   0 heads + S decoders, 1 up3, 2 up2, 3 up1, 4 down4, 5 down3, 6 down2, 7 the S encoders (+ dx).
+ * The parameters of a stage are one contiguous range [begin, end) of the flat gradient buffer (laid out encoder |
+ * core | decoder | heads) that is final when the stage returns, so its all-reduce can run while the later stages
+ * back-propagate: one bucket per core block, as SURVEY 8(e) asks.  The exchange itself is torch.distributed /
+ * RCCL on the caller's side (mimo_unet_amd/ddp.py), not part of this ABI: there is no mimo_ddp_* entry point. */
+int mimo_plan_num_backward_stages(const mimo_plan* plan);
+int mimo_plan_backward_stage_range(const mimo_plan* plan, int stage, int64_t* begin, int64_t* end);
 int mimo_backward_stage(mimo_plan* plan, int stage, const float* dout, const float* dloss, float* dx,
                         mimo_stream stream);
 int64_t mimo_plan_encoder_param_floats(const mimo_plan* plan);
@@ -162,11 +166,20 @@ enum mimo_prof_kind {
   MIMO_PROF_BN_RELU_FWD = 3,   /* bandwidth class: BatchNorm + ReLU forward pass (8 B per element) */
   MIMO_PROF_BN_BWD_REDUCE = 4, /* BatchNorm backward pass 1 (8 B per element) */
   MIMO_PROF_BN_BWD_APPLY = 5,  /* BatchNorm backward pass 2 (12 B per element) */
-  MIMO_PROF_KINDS = 6
+  MIMO_PROF_UPCAT_FWD = 6,     /* bilinear x2 + pad + concat (writes the up-sampled channels) */
+  MIMO_PROF_UP_BWD = 7,        /* its gradient gather */
+  MIMO_PROF_POOL_BWD = 8,      /* MaxPool2d backward (+ skip-gradient fold) */
+  MIMO_PROF_HEAD_FWD = 9,      /* 1x1 head */
+  MIMO_PROF_HEAD_BWD = 10,     /* NLL gradient + 1x1 head backward */
+  MIMO_PROF_KINDS = 11
 };
 int mimo_plan_profile(mimo_plan* plan, int enable);
 int mimo_plan_profile_read(mimo_plan* plan, int kind, double* total_ms, int64_t* launches, double* flops,
                            double* bytes);
+/* Device time of everything launched for the DoubleConv blocks (+ heads) of one resolution tier
+ * (0 = full resolution H x W ... 4 = H/16 x W/16), forward and backward separately, since the profile was
+ * armed: the denominator of the per-tier HBM fraction of SURVEY 8(d). */
+int mimo_plan_profile_read_tier(mimo_plan* plan, int tier, double* forward_ms, double* backward_ms);
 
 /* ---- optimiser: replaces torch.optim.Adam.step (mimo_unet.py:186-190; L2-in-grad) ------ */
 int mimo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

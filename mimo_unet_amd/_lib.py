@@ -65,9 +65,12 @@ _SIGNATURES = {
     "mimo_backward": (C.c_int, [_P, _P, _P, _P, _P]),
     "mimo_backward_stage": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "mimo_plan_encoder_param_floats": (_L, [_P]),
+    "mimo_plan_num_backward_stages": (C.c_int, [_P]),
+    "mimo_plan_backward_stage_range": (C.c_int, [_P, C.c_int, C.POINTER(_L), C.POINTER(_L)]),
     "mimo_plan_profile": (C.c_int, [_P, C.c_int]),
     "mimo_plan_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double)]),
+    "mimo_plan_profile_read_tier": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mimo_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "mimo_uncertainties": (C.c_int, [_P, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P]),
     "mimo_validation_epilogue": (C.c_int, [_P, _P, _P, _I, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -100,6 +100,7 @@ struct DoubleConv {
   Act out;               // a2 (+ gradient)
   float drop_p = 0.f;
   const float* mask = nullptr;  // set per forward call
+  int64_t p_begin = 0, p_end = 0;  // this block's parameters in the flat parameter / gradient buffers (floats)
 };
 
 struct Head {
@@ -161,8 +162,21 @@ struct mimo_plan {
   double prof_ms[MIMO_PROF_KINDS] = {}, prof_flops[MIMO_PROF_KINDS] = {}, prof_bytes[MIMO_PROF_KINDS] = {};
   int64_t prof_launches[MIMO_PROF_KINDS] = {};
 
-  void prof_begin(int kind, hipStream_t st) {
-    if (!prof_on) return;
+  // tier records: kind = kProfTierBase + 2 * tier + (backward ? 1 : 0); tier = resolution level of a DoubleConv
+  // (0 = full resolution ... 4 = 1/16): the whole block (every launch between the two events), so that a tier's
+  // summed device time can be priced against its algorithmic HBM bytes
+  static constexpr int kProfTierBase = 100, kProfTiers = 5;
+  double prof_tier_ms[2 * kProfTiers] = {};
+  int tier_of(int h) const {
+    int t = 0, hh = H;
+    while (t < kProfTiers - 1 && hh > h) {
+      hh /= 2;
+      ++t;
+    }
+    return t;
+  }
+  int prof_begin(int kind, hipStream_t st) {
+    if (!prof_on) return -1;
     ProfRec r;
     if (!prof_pool.empty()) {
       r.a = prof_pool.back().first;
@@ -175,10 +189,13 @@ struct mimo_plan {
     r.kind = kind;
     (void)hipEventRecord(r.a, st);
     prof_recs.push_back(r);
+    return (int)prof_recs.size() - 1;
   }
-  void prof_end(int kind, double flops, double bytes, hipStream_t st) {
-    if (!prof_on) return;
-    (void)hipEventRecord(prof_recs.back().b, st);
+  void prof_end(int idx, double flops, double bytes, hipStream_t st) {
+    if (idx < 0 || !prof_on) return;
+    (void)hipEventRecord(prof_recs[idx].b, st);
+    const int kind = prof_recs[idx].kind;
+    if (kind >= kProfTierBase) return;
     prof_flops[kind] += flops;
     prof_bytes[kind] += bytes;
     prof_launches[kind] += 1;
@@ -188,7 +205,10 @@ struct mimo_plan {
       MIMO_HIP_CHECK(hipEventSynchronize(r.b));
       float ms = 0.f;
       MIMO_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
-      prof_ms[r.kind] += ms;
+      if (r.kind >= kProfTierBase)
+        prof_tier_ms[r.kind - kProfTierBase] += ms;
+      else
+        prof_ms[r.kind] += ms;
       prof_pool.emplace_back(r.a, r.b);
     }
     prof_recs.clear();
@@ -224,7 +244,8 @@ struct mimo_plan {
   int n_fwd_jobs = 0, n_all_jobs = 0, pack_max_total = 0;
 
   // per-call state
-  bool fwd_done = false, fwd_training = false, had_perm = false, loss_done = false, bwd_stage0_done = false;
+  bool fwd_done = false, fwd_training = false, had_perm = false, loss_done = false;
+  int bwd_next_stage = 0;  // staged backward: the stage that may run next (0 = a fresh backward)
   bool fwd_no_grad = false;       // last forward folded BN/ReLU into the conv epilogue: nothing saved for a backward
   int64_t derived_version = -1;   // param_version the packed weights / eval scale+shift were derived from (-1: none)
   bool derived_dgrad = false;     // ... including the data-gradient weight copies
@@ -375,10 +396,12 @@ struct mimo_plan {
     auto dc = std::make_unique<DoubleConv>();
     dc->prefix = prefix;
     dc->drop_p = drop_p;
+    dc->p_begin = param_floats;
     MIMO_TRY(init_convbn(dc->c1, prefix, 0, 1, Cin, Cmid, in_chmap, N, h, w));
     std::vector<int> midmap(pad_channels(Cmid));
     for (size_t i = 0; i < midmap.size(); ++i) midmap[i] = (int)i < Cmid ? (int)i : -1;
     MIMO_TRY(init_convbn(dc->c2, prefix, 3, 4, Cmid, Cout, midmap, N, h, w));
+    dc->p_end = param_floats;
     MIMO_TRY(dalloc(&dc->mid, (size_t)N * h * w * dc->c1.cout_p));
     Act& o = dc->out;
     o.N = N;
@@ -708,12 +731,12 @@ struct mimo_plan {
     int rows = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
     a.wpk = L.wf16;
-    prof_begin(MIMO_PROF_CONV_FWD, st);
+    int pr = prof_begin(MIMO_PROF_CONV_FWD, st);
     if (L.fwd_split)
       MIMO_TRY(conv3x3_bf16x3_launch(a, cfg.precision == MIMO_PREC_BF16 ? 2 : 1, &rows, st));
     else
       MIMO_TRY(conv3x3_launch(a, &rows, st));
-    prof_end(MIMO_PROF_CONV_FWD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
+    prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     if (training) {
       int chunks = 0;
       MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_pad, s_sums, &chunks, st));
@@ -722,31 +745,36 @@ struct mimo_plan {
                                       cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
     }
     if (!fused) {
-      prof_begin(MIMO_PROF_BN_RELU_FWD, st);
+      pr = prof_begin(MIMO_PROF_BN_RELU_FWD, st);
       if (L.pool_out)
         MIMO_TRY(bn_relu_pool_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, L.N, L.H, L.W,
                                          L.pool_out, L.pool_ld, st));
       else
         MIMO_TRY(bn_relu_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, P, L.H * L.W, st));
-      prof_end(MIMO_PROF_BN_RELU_FWD, 0.0, (L.pool_out ? 9.0 : 8.0) * (double)P * L.cout_p, st);
+      prof_end(pr, 0.0, (L.pool_out ? 9.0 : 8.0) * (double)P * L.cout_p, st);
     }
     return MIMO_OK;
   }
 
   int dc_forward(DoubleConv* dc, bool training, hipStream_t st) {
     const int h = dc->c1.H, w = dc->c1.W;
+    const int blk = prof_begin(kProfTierBase + 2 * tier_of(h), st);
     if (dc->kind == IN_POOL) {
       Act* s = dc->src0;
       if (!(dc->pool_fused && !fwd_no_grad))  // else: already written by the producers' BatchNorm + ReLU pass
         MIMO_TRY(maxpool_fwd_launch(s->a, s->ld, N, s->H, s->W, s->Cp, dc->in_buf, dc->in_ld, st));
     } else if (dc->kind == IN_UPCAT) {
       Act *sk = dc->src0, *lo = dc->src1;
+      const int pr = prof_begin(MIMO_PROF_UPCAT_FWD, st);
       MIMO_TRY(upcat_fwd_launch(dc->skip_in_place ? nullptr : sk->a, sk->ld, sk->Cp, lo->a, lo->ld, lo->Cp, N, h, w, lo->H,
                                 lo->W, dc->in_buf, st));
+      // writes the up-sampled channels at (h, w), reads the low-resolution tensor once
+      prof_end(pr, 0.0, 4.0 * lo->Cp * ((double)N * h * w + (double)N * lo->H * lo->W), st);
     }
 
     MIMO_TRY(convbn_forward(dc->c1, training, nullptr, st));
     MIMO_TRY(convbn_forward(dc->c2, training, dc->mask, st));
+    prof_end(blk, 0.0, 0.0, st);
     return MIMO_OK;
   }
 
@@ -894,8 +922,12 @@ struct mimo_plan {
       const Act& o = up4[s]->out;
       // final_dropouts[s]: in place, the head (forward and weight gradient) is the only reader
       if (elem_masks[1 + s]) MIMO_TRY(elem_mask_mul_launch(o.a, o.ld, elem_masks[1 + s], N, o.C, o.Cp, H * W, st));
+      const int blk = prof_begin(kProfTierBase, st);
+      const int pr = prof_begin(MIMO_PROF_HEAD_FWD, st);
       MIMO_TRY(head_fwd_launch(o.a, o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co, N, S, s, H * W,
                                args->out, st));
+      prof_end(pr, 0.0, 4.0 * (double)N * H * W * (pad_channels(f) + Co), st);
+      prof_end(blk, 0.0, 0.0, st);
     }
     if (fork) MIMO_TRY(join_streams(st));
     out = args->out;
@@ -934,10 +966,10 @@ struct mimo_plan {
                       float* dxpad_out, hipStream_t st) {
     int rows = 0, chunks = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
-    prof_begin(MIMO_PROF_BN_BWD_REDUCE, st);
+    int pr = prof_begin(MIMO_PROF_BN_BWD_REDUCE, st);
     MIMO_TRY(bnrelu_bwd_reduce_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd,
                                       mask, L.Cout, L.cout_p, L.N, L.H, L.W, s_partial, &rows, st));
-    prof_end(MIMO_PROF_BN_BWD_REDUCE, 0.0, 8.0 * (double)P * L.cout_p, st);
+    prof_end(pr, 0.0, 8.0 * (double)P * L.cout_p, st);
     MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_p, s_sums, &chunks, st));
     MIMO_TRY(bn_bwd_finalize_launch(s_sums, chunks, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
                                     grads + L.off_gamma, grads + L.off_beta, st));
@@ -947,10 +979,10 @@ struct mimo_plan {
       dz_idx ^= 1;
       if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
     }
-    prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
+    pr = prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
     MIMO_TRY(bn_bwd_apply_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
                                  L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, L.dg_split ? 1 : 0, s_partial, &rows, st));
-    prof_end(MIMO_PROF_BN_BWD_APPLY, 0.0, 12.0 * (double)P * L.cout_p, st);
+    prof_end(pr, 0.0, 12.0 * (double)P * L.cout_p, st);
     // dz storage: bf16 hi|lo pairs when the data-gradient kernel is the bf16-pair one (then the weight
     // gradient is too); fp32 otherwise, with a split copy for a bf16-pair weight gradient
     const float* dz_wg = dz;
@@ -982,12 +1014,12 @@ struct mimo_plan {
       a.cout_store = L.cin_p;
       a.off = 2;
       a.wpk = L.wd16;
-      prof_begin(MIMO_PROF_CONV_DGRAD, st);
+      pr = prof_begin(MIMO_PROF_CONV_DGRAD, st);
       if (L.dg_split)
         MIMO_TRY(conv3x3_bf16x3_launch(a, cfg.precision == MIMO_PREC_BF16 ? 3 : 0, nullptr, st));
       else
         MIMO_TRY(conv3x3_launch(a, nullptr, st));
-      prof_end(MIMO_PROF_CONV_DGRAD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
+      prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     }
     hipStream_t ws = st;
     if (wg_async) {
@@ -1009,12 +1041,12 @@ struct mimo_plan {
     wg.cout_pad = L.wg_cout_pad;
     wg.splits = L.wg_splits;
     wg.np = cfg.precision == MIMO_PREC_BF16 ? 1 : 3;
-    prof_begin(MIMO_PROF_CONV_WGRAD, ws);
+    pr = prof_begin(MIMO_PROF_CONV_WGRAD, ws);
     if (L.wg_split)
       MIMO_TRY(wgrad_split_launch(wg, ws));
     else
       MIMO_TRY(wgrad_launch(wg, ws));
-    prof_end(MIMO_PROF_CONV_WGRAD, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), ws);
+    prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), ws);
     if (wg_async) {
       MIMO_HIP_CHECK(hipEventRecord(ev_wg[b], wg_stream));
       wg_pending[b] = true;
@@ -1034,6 +1066,13 @@ struct mimo_plan {
   }
 
   int dc_backward(DoubleConv* dc, bool need_input_grad, hipStream_t st) {
+    const int blk = prof_begin(kProfTierBase + 2 * tier_of(dc->c1.H) + 1, st);
+    const int rc = dc_backward_impl(dc, need_input_grad, st);
+    prof_end(blk, 0.0, 0.0, st);
+    return rc;
+  }
+
+  int dc_backward_impl(DoubleConv* dc, bool need_input_grad, hipStream_t st) {
     MIMO_TRY(convbn_backward(dc->c2, dc->out.da, dc->out.ldda, nullptr, dc->mask, true, s_dxpadA, st));
     float* dxB = dc->dxpad_own ? dc->dxpad_own : s_dxpadB;
     MIMO_TRY(convbn_backward(dc->c1, nullptr, 0, s_dxpadA, nullptr, need_input_grad, dxB, st));
@@ -1041,8 +1080,12 @@ struct mimo_plan {
     const int h = dc->c1.H, w = dc->c1.W, ldp = dc->c1.cin_p;
     if (dc->kind == IN_POOL) {
       Act* s = dc->src0;
-      MIMO_TRY(pool_bwd_launch(dxB, ldp, 0, s->a, s->ld, s->da, s->ldda, N, s->H, s->W, s->Cp, acc_flag(s), st, s->skipgrad,
+      const int pr = prof_begin(MIMO_PROF_POOL_BWD, st);
+      const bool acc = acc_flag(s) != 0;
+      MIMO_TRY(pool_bwd_launch(dxB, ldp, 0, s->a, s->ld, s->da, s->ldda, N, s->H, s->W, s->Cp, acc ? 1 : 0, st, s->skipgrad,
                                s->skipgrad_ld));
+      // reads the pooled gradient (1/4), the activation, [the skip gradient], [the old gradient]; writes the gradient
+      prof_end(pr, 0.0, 4.0 * s->Cp * (double)N * s->H * s->W * (2.25 + (s->skipgrad ? 1.0 : 0.0) + (acc ? 1.0 : 0.0)), st);
       s->skipgrad = nullptr;
     } else if (dc->kind == IN_UPCAT) {
       Act *sk = dc->src0, *lo = dc->src1;
@@ -1052,14 +1095,33 @@ struct mimo_plan {
       } else {
         MIMO_TRY(fold_slice_launch(dxB, ldp, 0, sk->da, sk->ldda, N, h, w, sk->Cp, acc_flag(sk), st));
       }
+      const int pr = prof_begin(MIMO_PROF_UP_BWD, st);
       MIMO_TRY(up_bwd_launch(dxB, ldp, sk->Cp, lo->da, lo->ldda, N, h, w, lo->H, lo->W, lo->Cp, acc_flag(lo), st));
+      // reads the up-sampled slice of the padded-domain gradient once, writes the low-resolution gradient
+      prof_end(pr, 0.0, 4.0 * lo->Cp * ((double)N * (h + 2) * (w + 2) + (double)N * lo->H * lo->W), st);
     }
     return MIMO_OK;
   }
 
-  // stage 0: heads + decoder + core (98.6 % of the parameter bytes at cfg3); stage 1: encoders (+ dx).
-  // The flat gradient buffer is ordered encoder | core | decoder | heads, so after stage 0 the range
-  // [encoder_param_floats, param_floats) is final and can be all-reduced while stage 1 runs.
+  // The backward in kBwdStages stages, in execution order; each stage's parameters are one contiguous range of the
+  // flat gradient buffer (laid out encoder | core down2..up3 | decoder | heads), final when the stage returns, so a
+  // data-parallel caller can start that range's all-reduce while the later stages run:
+  //   0 heads + decoders (up4)   1 up3   2 up2   3 up1   4 down4   5 down3   6 down2   7 encoders (+ dx)
+  static constexpr int kBwdStages = 8;
+  void stage_range(int stage, int64_t* b, int64_t* e) const {
+    DoubleConv* core[6] = {up3, up2, up1, down4, down3, down2};
+    if (stage == 0) {
+      *b = up4[0]->p_begin;
+      *e = param_floats;
+    } else if (stage == kBwdStages - 1) {
+      *b = 0;
+      *e = encoder_param_floats;
+    } else {
+      *b = core[stage - 1]->p_begin;
+      *e = core[stage - 1]->p_end;
+    }
+  }
+
   int backward(const float* dout, const float* dloss, float* dx, int stage_first, int stage_last, hipStream_t st) {
     if (!fwd_done) {
       set_error("mimo_backward: call mimo_forward first");
@@ -1085,52 +1147,62 @@ struct mimo_plan {
       set_error("mimo_backward: dx requires a forward without perm");
       return MIMO_ERR_INVALID;
     }
-    if (stage_first < 0 || stage_last > 1 || stage_first > stage_last) {
+    if (stage_first < 0 || stage_last >= kBwdStages || stage_first > stage_last) {
       set_error("mimo_backward: bad stage range %d..%d", stage_first, stage_last);
       return MIMO_ERR_INVALID;
     }
-    if (stage_first == 1) {
-      if (!bwd_stage0_done) {
-        set_error("mimo_backward: stage 1 before stage 0");
-        return MIMO_ERR_STATE;
+    if (stage_first != 0 && stage_first != bwd_next_stage) {
+      set_error("mimo_backward: stage %d requested, stage %d is next", stage_first, bwd_next_stage);
+      return MIMO_ERR_STATE;
+    }
+    for (int stage = stage_first; stage <= stage_last; ++stage) MIMO_TRY(backward_stage(stage, dout, dloss, dx, st));
+    bwd_next_stage = stage_last + 1 < kBwdStages ? stage_last + 1 : 0;
+    return wg_join(st);  // the gradients of the stages run so far are final for the caller (all-reduce)
+  }
+
+  int backward_stage(int stage, const float* dout, const float* dloss, float* dx, hipStream_t st) {
+    switch (stage) {
+      case 0: {
+        for (auto& dc : dcs) {
+          dc->out.grad_writes = 0;
+          dc->out.skipgrad = nullptr;
+        }
+        x2cat.grad_writes = 0;
+        x2cat.skipgrad = nullptr;
+        if (!fwd_training) {  // eval-mode forward skipped the dgrad weight packing
+          MIMO_TRY(pack_all(true, st));
+        }
+        const int fp = pad_channels(f);
+        for (int s = S - 1; s >= 0; --s) {
+          DoubleConv* dc = up4[s];
+          int rows = 0, chunks = 0;
+          const int blk = prof_begin(kProfTierBase + 1, st);
+          const int pr = prof_begin(MIMO_PROF_HEAD_BWD, st);
+          MIMO_TRY(head_bwd_launch(dc->out.a, dc->out.ld, params + heads[s].off_w, f, fp, Co, N, S, s, H * W, out, dout, dloss,
+                                   label, lmask, lperm, cfg.loss_kind, cfg.eps_min, cfg.eps_max, dc->out.da, s_partial, &rows,
+                                   st));
+          prof_end(pr, 0.0, 4.0 * (double)N * H * W * (2.0 * fp + Co + Co / 2), st);
+          MIMO_TRY(rowsum_launch(s_partial, rows, Co * fp + Co, s_sums, &chunks, st));
+          MIMO_TRY(head_bwd_finalize_launch(s_sums, chunks, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, st));
+          if (!elem_masks.empty() && elem_masks[1 + s])
+            MIMO_TRY(elem_mask_mul_launch(dc->out.da, dc->out.ldda, elem_masks[1 + s], N, dc->out.C, dc->out.Cp, H * W, st));
+          prof_end(blk, 0.0, 0.0, st);
+          MIMO_TRY(dc_backward(dc, true, st));
+        }
+        return MIMO_OK;
       }
-      return backward_encoders(dx, st);
+      case 1: return dc_backward(up3, true, st);
+      case 2: return dc_backward(up2, true, st);
+      case 3: return dc_backward(up1, true, st);
+      case 4:
+        if (!elem_masks.empty() && elem_masks[0])
+          MIMO_TRY(elem_mask_mul_launch(down4->out.da, down4->out.ldda, elem_masks[0], N, down4->out.C, down4->out.Cp,
+                                        down4->out.H * down4->out.W, st));
+        return dc_backward(down4, true, st);
+      case 5: return dc_backward(down3, true, st);
+      case 6: return dc_backward(down2, true, st);
+      default: return backward_encoders(dx, st);
     }
-    bwd_stage0_done = false;
-    for (auto& dc : dcs) {
-      dc->out.grad_writes = 0;
-      dc->out.skipgrad = nullptr;
-    }
-    x2cat.grad_writes = 0;
-    x2cat.skipgrad = nullptr;
-    if (!fwd_training) {  // eval-mode forward skipped the dgrad weight packing
-      MIMO_TRY(pack_all(true, st));
-    }
-    const int fp = pad_channels(f);
-    for (int s = S - 1; s >= 0; --s) {
-      DoubleConv* dc = up4[s];
-      int rows = 0, chunks = 0;
-      MIMO_TRY(head_bwd_launch(dc->out.a, dc->out.ld, params + heads[s].off_w, f, fp, Co, N, S, s, H * W, out, dout, dloss,
-                               label, lmask, lperm, cfg.loss_kind, cfg.eps_min, cfg.eps_max, dc->out.da, s_partial, &rows,
-                               st));
-      MIMO_TRY(rowsum_launch(s_partial, rows, Co * fp + Co, s_sums, &chunks, st));
-      MIMO_TRY(head_bwd_finalize_launch(s_sums, chunks, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, st));
-      if (!elem_masks.empty() && elem_masks[1 + s])
-        MIMO_TRY(elem_mask_mul_launch(dc->out.da, dc->out.ldda, elem_masks[1 + s], N, dc->out.C, dc->out.Cp, H * W, st));
-      MIMO_TRY(dc_backward(dc, true, st));
-    }
-    MIMO_TRY(dc_backward(up3, true, st));
-    MIMO_TRY(dc_backward(up2, true, st));
-    MIMO_TRY(dc_backward(up1, true, st));
-    if (!elem_masks.empty() && elem_masks[0])
-      MIMO_TRY(elem_mask_mul_launch(down4->out.da, down4->out.ldda, elem_masks[0], N, down4->out.C, down4->out.Cp,
-                                    down4->out.H * down4->out.W, st));
-    MIMO_TRY(dc_backward(down4, true, st));
-    MIMO_TRY(dc_backward(down3, true, st));
-    MIMO_TRY(dc_backward(down2, true, st));
-    bwd_stage0_done = true;
-    if (stage_last >= 1) return backward_encoders(dx, st);
-    return wg_join(st);  // the core / decoder / head gradients are final for the caller (all-reduce)
   }
 
   int backward_encoders(float* dx, hipStream_t st) {
@@ -1139,8 +1211,7 @@ struct mimo_plan {
       MIMO_TRY(dc_backward(enc_in[s], dx != nullptr, st));
       if (dx) MIMO_TRY(unpack_dx_launch(s_dxpadB, Ci_p, N, S, s, Ci, H, W, dx, st));
     }
-    bwd_stage0_done = false;
-    return wg_join(st);
+    return MIMO_OK;
   }
 };
 
@@ -1225,6 +1296,7 @@ int mimo_plan_profile(mimo_plan* plan, int enable) {
       plan->prof_ms[k] = plan->prof_flops[k] = plan->prof_bytes[k] = 0.0;
       plan->prof_launches[k] = 0;
     }
+    for (double& v : plan->prof_tier_ms) v = 0.0;
   }
   return MIMO_OK;
 }
@@ -1239,6 +1311,17 @@ int mimo_plan_profile_read(mimo_plan* plan, int kind, double* total_ms, int64_t*
   if (launches) *launches = plan->prof_launches[kind];
   if (flops) *flops = plan->prof_flops[kind];
   if (bytes) *bytes = plan->prof_bytes[kind];
+  return MIMO_OK;
+}
+
+int mimo_plan_profile_read_tier(mimo_plan* plan, int tier, double* forward_ms, double* backward_ms) {
+  if (!plan || tier < 0 || tier >= mimo_plan::kProfTiers) {
+    set_error("mimo_plan_profile_read_tier: bad argument");
+    return MIMO_ERR_INVALID;
+  }
+  MIMO_TRY(plan->prof_collect());
+  if (forward_ms) *forward_ms = plan->prof_tier_ms[2 * tier];
+  if (backward_ms) *backward_ms = plan->prof_tier_ms[2 * tier + 1];
   return MIMO_OK;
 }
 
@@ -1264,7 +1347,7 @@ int mimo_backward(mimo_plan* plan, const float* dout, const float* dloss, float*
     set_error("mimo_backward: null plan");
     return MIMO_ERR_INVALID;
   }
-  return plan->backward(dout, dloss, dx, 0, 1, (hipStream_t)stream);
+  return plan->backward(dout, dloss, dx, 0, mimo_plan::kBwdStages - 1, (hipStream_t)stream);
 }
 
 int mimo_backward_stage(mimo_plan* plan, int stage, const float* dout, const float* dloss, float* dx, mimo_stream stream) {
@@ -1276,5 +1359,16 @@ int mimo_backward_stage(mimo_plan* plan, int stage, const float* dout, const flo
 }
 
 int64_t mimo_plan_encoder_param_floats(const mimo_plan* plan) { return plan ? plan->encoder_param_floats : 0; }
+
+int mimo_plan_num_backward_stages(const mimo_plan* plan) { return plan ? mimo_plan::kBwdStages : 0; }
+
+int mimo_plan_backward_stage_range(const mimo_plan* plan, int stage, int64_t* begin, int64_t* end) {
+  if (!plan || stage < 0 || stage >= mimo_plan::kBwdStages || !begin || !end) {
+    set_error("mimo_plan_backward_stage_range: bad argument");
+    return MIMO_ERR_INVALID;
+  }
+  plan->stage_range(stage, begin, end);
+  return MIMO_OK;
+}
 
 }  // extern "C"

@@ -4,9 +4,10 @@
 The reference is single-GPU (`devices=1`, scripts/train/train_ndvi.py:67-76); the semantics
 implemented are what Lightning DDP would do with its module: the batch is sharded, BatchNorm
 statistics and the loss buffer stay per rank, gradients are averaged.  The engine keeps all
-gradients in ONE flat buffer, so the exchange is a handful of large bucketed all-reduces of
-slices of that buffer (xGMI is per-link bound: few, large messages), issued asynchronously
-(RCCL runs them on its own stream) and waited for right before the optimiser."""
+gradients in ONE flat buffer, so the exchange is a handful of bucketed all-reduces of slices of
+that buffer (xGMI is per-link bound: few, large messages), issued asynchronously from inside the
+backward — one slice per core block as it becomes final (RCCL runs them on its own stream) — and
+waited for right before the optimiser."""
 from __future__ import annotations
 
 from typing import Dict, List, Optional
@@ -31,33 +32,65 @@ def shard_batch(batch: Dict[str, Optional[torch.Tensor]], rank: int, world_size:
 
 
 class FlatGradientAllReducer:
-    """Sum all-reduce of a flat gradient buffer in buckets; `scale` is what the optimiser must
-    multiply gradients by afterwards (1/world: FlatAdam.grad_scale)."""
+    """Sum all-reduce of a flat gradient buffer, started range by range while the backward is still running;
+    `scale` is what the optimiser must multiply gradients by afterwards (1/world: FlatAdam.grad_scale).
 
-    def __init__(self, bucket_bytes: int = 64 << 20, group=None):
+    The engine announces ranges in backward order — heads + decoders, up3, up2, up1, down4, down3, down2,
+    encoders — which walks the flat buffer (encoder | core | decoder | heads) from its tail to its head, so
+    consecutive announcements are adjacent in memory.  Ranges are merged until `min_bucket_bytes` are pending
+    (the 0.4 MB decoder and 1.3 MB up3 slices ride along with up2; xGMI collectives are latency-bound below a
+    few MB) and split above `bucket_bytes`; cfg3 (60 MB of gradients) goes out as six all-reduces of 3-21 MB,
+    the first of them after about a third of the backward."""
+
+    def __init__(self, bucket_bytes: int = 64 << 20, group=None, min_bucket_bytes: int = 4 << 20):
         self.group = group
         self.bucket_floats = max(1, bucket_bytes // 4)
+        self.min_floats = max(1, min(min_bucket_bytes, bucket_bytes) // 4)
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.always = False  # issue the collectives even with one rank (functional check of the RCCL path)
         self._pending: List = []
+        self._held = None  # (flat, begin, end): announced, not yet issued
+        self.issued: List = []  # [(begin, end)] of the collectives of the current step (diagnostics / tests)
 
     @property
     def scale(self) -> float:
         return 1.0 / self.world_size
 
+    def _issue(self, flat: torch.Tensor, begin: int, end: int) -> None:
+        for lo in range(begin, end, self.bucket_floats):
+            hi = min(end, lo + self.bucket_floats)
+            self.issued.append((lo, hi))
+            self._pending.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _flush(self) -> None:
+        if self._held is not None:
+            flat, b, e = self._held
+            self._held = None
+            self._issue(flat, b, e)
+
     def start(self, flat: torch.Tensor, begin: int = 0, end: Optional[int] = None) -> None:
-        """Issue async all-reduces for flat[begin:end] (bucketed)."""
+        """flat[begin:end] is final: issue its async all-reduce, or hold it to merge with an adjacent range."""
         if self.world_size == 1 and not self.always:
             return
         end = flat.numel() if end is None else end
-        for lo in range(begin, end, self.bucket_floats):
-            hi = min(end, lo + self.bucket_floats)
-            self._pending.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._held is not None:
+            hf, hb, he = self._held
+            if hf is flat and end == hb:
+                begin, end = begin, he
+            elif hf is flat and begin == he:
+                begin, end = hb, end
+            else:
+                self._flush()
+        self._held = (flat, begin, end)
+        if end - begin >= self.min_floats:
+            self._flush()
 
     def finish(self) -> None:
+        self._flush()
         for w in self._pending:
             w.wait()
         self._pending.clear()
+        self.issued = []
 
     def all_reduce(self, flat: torch.Tensor) -> None:
         self.start(flat)
@@ -65,6 +98,6 @@ class FlatGradientAllReducer:
 
     def attach(self, net) -> None:
         """Overlap with the backward: `net` (MimoUNet) calls `start` as soon as a range of its flat
-        gradient buffer is final (core + decoder after backward stage 0, encoders after stage 1);
-        call `finish()` before the optimiser step."""
+        gradient buffer is final (after each backward stage, include/mimo_hip.h); call `finish()` before
+        the optimiser step."""
         net.grad_ready_hook = self.start

@@ -63,6 +63,11 @@ class Plan:
         self.param_floats = int(self.lib.mimo_plan_param_floats(handle))
         self.buffer_floats = int(self.lib.mimo_plan_buffer_floats(handle))
         self.encoder_param_floats = int(self.lib.mimo_plan_encoder_param_floats(handle))
+        self.backward_stages = []  # [(begin, end)] flat-gradient range that is final after each backward stage
+        for st in range(int(self.lib.mimo_plan_num_backward_stages(handle))):
+            b, e = C.c_int64(), C.c_int64()
+            L.check(self.lib.mimo_plan_backward_stage_range(handle, st, C.byref(b), C.byref(e)), "mimo_plan_backward_stage_range")
+            self.backward_stages.append((int(b.value), int(e.value)))
         self.num_double_convs = int(self.lib.mimo_plan_num_double_convs(handle))
         self.double_conv_channels = [int(self.lib.mimo_plan_double_conv_channels(handle, i))
                                      for i in range(self.num_double_convs)]
@@ -142,7 +147,7 @@ class Plan:
 
     def backward(self, dout: Optional[torch.Tensor], dloss: Optional[torch.Tensor], dx: Optional[torch.Tensor],
                  stage: Optional[int] = None) -> None:
-        """stage None: whole backward; 0: heads + decoders + core; 1: encoders (+ dx)."""
+        """stage None: whole backward; else one of the `backward_stages`, in order (include/mimo_hip.h)."""
         if stage is None:
             L.check(self.lib.mimo_backward(self.handle, L.ptr(dout) or None, L.ptr(dloss) or None, L.ptr(dx) or None,
                                            L.current_stream()), "mimo_backward")
@@ -151,7 +156,9 @@ class Plan:
                                                  L.ptr(dx) or None, L.current_stream()), "mimo_backward_stage")
 
 
-    PROF_KINDS = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "bn_relu_fwd", "bn_bwd_reduce", "bn_bwd_apply")
+    PROF_KINDS = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "bn_relu_fwd", "bn_bwd_reduce", "bn_bwd_apply",
+                  "upcat_fwd", "up_bwd", "pool_bwd", "head_fwd", "head_bwd")
+    PROF_TIERS = 5  # resolution levels: 0 = H x W ... 4 = H/16 x W/16
 
     def profile(self, enable: bool) -> None:
         L.check(self.lib.mimo_plan_profile(self.handle, int(enable)), "mimo_plan_profile")
@@ -163,6 +170,15 @@ class Plan:
             L.check(self.lib.mimo_plan_profile_read(self.handle, k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)),
                     "mimo_plan_profile_read")
             res[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return res
+
+    def profile_read_tiers(self) -> List[Tuple[float, float]]:
+        """[(forward_ms, backward_ms)] per resolution tier: device time of every launch of the tier's blocks."""
+        res = []
+        for t in range(self.PROF_TIERS):
+            f, b = C.c_double(), C.c_double()
+            L.check(self.lib.mimo_plan_profile_read_tier(self.handle, t, C.byref(f), C.byref(b)), "mimo_plan_profile_read_tier")
+            res.append((f.value, b.value))
         return res
 
 

@@ -399,12 +399,12 @@ class MimoUNet(nn.Module):
             # announced once they are final — no overlap on accumulating micro-batches
             plan.backward(dout, dloss, dx)
         else:
-            # data-parallel overlap: the core/decoder/head gradients (the tail of the flat buffer, 99 % of
-            # its bytes) are final after stage 0; their all-reduce runs while the encoders back-propagate
-            plan.backward(dout, dloss, dx, stage=0)
-            hook(g, plan.encoder_param_floats, g.numel())
-            plan.backward(dout, dloss, dx, stage=1)
-            hook(g, 0, plan.encoder_param_floats)
+            # data-parallel overlap: one stage per core block (heads + decoders first, the encoders last); each
+            # stage's slice of the flat gradient buffer is final when it returns and its all-reduce runs while
+            # the later stages back-propagate
+            for st, (b, e) in enumerate(plan.backward_stages):
+                plan.backward(dout, dloss, dx, stage=st)
+                hook(g, b, e)
         for p, v in views:
             if p.grad is None:
                 p.grad = v
@@ -414,8 +414,8 @@ class MimoUNet(nn.Module):
             else:
                 p.grad.add_(v)
         if hook is not None and aliased:
-            hook(g, plan.encoder_param_floats, g.numel())
-            hook(g, 0, plan.encoder_param_floats)
+            for b, e in plan.backward_stages:
+                hook(g, b, e)
 
     def mark_parameters_changed(self) -> None:
         """Call after writing the flat parameter / buffer storage through a raw pointer."""

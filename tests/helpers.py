@@ -44,3 +44,15 @@ def free_port():
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         return so.getsockname()[1]
+
+
+def report(msg):
+    """Print an observed-error line and, when MIMO_PARITY_LOG names a file, append it there (the GPU run's
+    parity_errors.txt that is committed under profiles/)."""
+    print(msg)
+    path = os.environ.get("MIMO_PARITY_LOG")
+    if path:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+        with open(path, "a") as fh:
+            fh.write(f"{test}: {msg}\n")

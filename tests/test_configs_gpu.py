@@ -1,0 +1,214 @@
+"""Every BASELINE.json configuration at its REAL geometry (256x256, the config's S / filter_base_count), through the
+`MimoUnetModel` / `EnsembleModule` surface, against the CPU oracle run live on the same seeded inputs — at the
+largest batch the oracle finishes in well under a minute — plus the split16 path against the independent
+fp32-MFMA kernel family on random geometries.  Observed errors go to the parity log (tests/helpers.report).
+
+    cfg2  3->1 ch, S=2, fbc=21, batch 64     -> N=8  vs fp32 + fp64 oracle
+    cfg3  2->1 ch, S=2, fbc=30, batch 32     -> N=16 vs fp32 + fp64 oracle (pins the N-dependent weight-gradient
+                                                split schedule: at N=16 the layers use the same kernels and
+                                                split counts > 1 as at N=32)
+    cfg4  2->1 ch, S=4, fbc=30, bf16         -> N=2 in split16 AND bf16 mode vs the oracle; N=16 property run
+    cfg5  MC dropout, S=1, fbc=30, p=0.1, 16 passes -> EnsembleModule with recorded masks vs O.ensemble_forward
+"""
+import random
+
+import pytest
+import torch
+
+from oracle import mimo_oracle as O
+from tests.helpers import rel_err, report
+from tests.test_network_gpu import _oracle_vs_hip, build_model, is_prebn_bias
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def test_cfg3_full_resolution_batch16_vs_oracle():
+    e_out, worst = _oracle_vs_hip(O.NetConfig(2, 2, 2, 30), N=16, H=256, W=256, seed=21)
+    report(f"cfg3 256x256 N=16 [split16]: out err {e_out:.2e}; worst grad tensor {worst}")
+    assert e_out < TOL
+
+
+def test_cfg2_full_resolution_batch8_vs_oracle():
+    e_out, worst = _oracle_vs_hip(O.NetConfig(3, 2, 2, 21), N=8, H=256, W=256, seed=22, with_mask=True)
+    report(f"cfg2 256x256 N=8 [split16]: out err {e_out:.2e}; worst grad tensor {worst}")
+    assert e_out < TOL
+
+
+def test_cfg4_geometry_split16_vs_oracle():
+    """S=4, fbc=30: the 120..1920-channel core (960 -> 1920-channel concat in up1) at 256x256."""
+    e_out, worst = _oracle_vs_hip(O.NetConfig(2, 2, 4, 30), N=2, H=256, W=256, seed=23)
+    report(f"cfg4 256x256 N=2 [split16]: out err {e_out:.2e}; worst grad tensor {worst}")
+    assert e_out < TOL
+
+
+# bf16-operand arithmetic against the fp32 oracle at cfg4's geometry.  Stated tolerances (what bf16 operands with
+# fp32 accumulation give on this network; observed values are in profiles/r02/parity_errors.txt):
+BF16_EVAL_VS_EMULATION = 3e-4   # eval forward vs the oracle emulating the same rounding policy
+BF16_EVAL_VS_FP32 = 2e-2        # eval forward vs the fp32 oracle
+BF16_TRAIN_OUT = 5e-2           # training-mode outputs vs fp32 oracle (BatchNorm amplifies rounding-boundary noise)
+BF16_GRAD_COS = 0.99            # whole-gradient cosine vs the fp32 oracle's gradients
+
+
+def test_cfg4_geometry_bf16_vs_oracle():
+    cfg = O.NetConfig(2, 2, 4, 30)
+    N, H, W, S = 2, 256, 256, 4
+    g = torch.Generator().manual_seed(24)
+    st = O.init_state(cfg, 24)
+    image = torch.rand(N, 2, H, W, generator=g)
+    label = torch.rand(N, 1, H, W, generator=g)
+    perms = O.draw_perms(N, S, generator=g)
+    model = build_model(cfg, st, precision="bf16")
+    # (a) eval-mode forward
+    x = torch.stack([image[perms[s]] for s in range(S)], dim=1)
+    model.eval()
+    with torch.no_grad():
+        p1, p2 = model(x.cuda())
+        with O.conv_operands("bf16"):
+            o16 = O.mimo_unet_forward(cfg, st, x, training=False)
+        o32 = O.mimo_unet_forward(cfg, st, x, training=False)
+    hip = torch.cat([p1, p2], dim=2).cpu()
+    e16, e32 = rel_err(hip, o16), rel_err(hip, o32)
+    # (b) one training step
+    model.train()
+    lb_w = torch.tensor([0.7, 0.9, 1.1, 1.3])
+    model.loss_buffer.get_weights = lambda: lb_w
+    out = model.training_step_with_perms(image.cuda(), label.cuda(), None, perms.cuda())
+    out["loss"].backward()
+    ts = O.TrainState(cfg=cfg, st={k: v.clone() for k, v in st.items()}, loss_buffer=O.LossBuffer(S, 0.3, 10))
+    ts.loss_buffer.get_weights = lambda: lb_w
+    ref = O.train_step(ts, image, label, None, perms, apply_optimizer=False)
+    preds = out["preds"].view(N, S, 1, H, W).cpu()
+    t32 = rel_err(preds, ref["out"][:, :, :1])
+    e_loss = abs(out["loss"].item() - float(ref["total"])) / abs(float(ref["total"]))
+    dot = n1 = n2 = 0.0
+    for k, p in model.named_parameters():
+        k = k[len("model."):]
+        if is_prebn_bias(k):
+            continue
+        a, b = p.grad.detach().cpu().double(), ref["grads"][k].double()
+        dot, n1, n2 = dot + float((a * b).sum()), n1 + float((a * a).sum()), n2 + float((b * b).sum())
+    cos = dot / (n1 * n2) ** 0.5
+    report(f"cfg4 256x256 N=2 [bf16]: eval fwd vs bf16-emulating oracle {e16:.2e}, vs fp32 oracle {e32:.2e}; "
+           f"train out vs fp32 oracle {t32:.2e}, loss {e_loss:.2e}, gradient cosine {cos:.5f}, |g|/|g_ref| {(n1 / n2) ** 0.5:.4f}")
+    assert e16 < BF16_EVAL_VS_EMULATION and e16 < e32 < BF16_EVAL_VS_FP32
+    assert t32 < BF16_TRAIN_OUT and e_loss < 2e-2 and cos > BF16_GRAD_COS
+
+
+@pytest.mark.parametrize("precision", ["split16", "bf16"])
+def test_cfg4_batch16_properties(precision):
+    """cfg4's per-GPU batch (16) through size-independent properties: a training step is bit-reproducible and
+    finite, eval mode is equivariant under batch permutation, and the split16 / bf16 losses agree to bf16 tolerance."""
+    cfg = O.NetConfig(2, 2, 4, 30)
+    st = O.init_state(cfg, 3)
+    model = build_model(cfg, st, precision=precision)
+    g = torch.Generator().manual_seed(5)
+    N, S = 16, 4
+    image = torch.rand(N, 2, 256, 256, generator=g).cuda()
+    label = torch.rand(N, 1, 256, 256, generator=g).cuda()
+    perms = O.draw_perms(N, S, generator=g).cuda()
+    model.train()
+    outs = []
+    for _ in range(2):
+        model.load_state_dict({"model." + k: v for k, v in st.items()})
+        model.loss_buffer.buffer.zero_()
+        model.loss_buffer.index = 0
+        model.zero_grad()
+        o = model.training_step_with_perms(image, label, None, perms)
+        o["loss"].backward()
+        outs.append((o["loss"].item(), o["preds"].clone(), model.model.flat_gradients().clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.isfinite(outs[0][2]).all() and torch.isfinite(outs[0][1]).all()
+    model.eval()
+    with torch.no_grad():
+        x5 = torch.stack([image[perms[s]] for s in range(S)], 1)
+        a1, a2 = model(x5)
+        pi = torch.randperm(N, generator=torch.Generator().manual_seed(1)).cuda()
+        b1, b2 = model(x5[pi])
+    e = max(rel_err(b1.cpu(), a1[pi].cpu()), rel_err(b2.cpu(), a2[pi].cpu()))
+    report(f"cfg4 256x256 N=16 [{precision}]: loss {outs[0][0]:.6f}, bit-reproducible, eval batch-permutation equivariance {e:.1e}")
+    assert e < 1e-5
+
+
+def test_cfg5_mc_dropout_16_passes_full_resolution():
+    """BASELINE config 5: S=1, fbc=30, Dropout2d p=0.1 in encoder / core / decoder, eval-mode BatchNorm with the
+    dropout modules re-enabled (ensemble.py:54-66), 16 stochastic passes of a 256x256 image, reduced by
+    compute_uncertainties — EnsembleModule (passes batched on the GPU, recorded masks) against O.ensemble_forward."""
+    from mimo.models.ensemble import EnsembleModule
+    p, passes, B, Ci, f = 0.1, 16, 2, 3, 30
+    cfg = O.NetConfig(Ci, 2, 1, f, encoder_dropout_rate=p, core_dropout_rate=p, decoder_dropout_rate=p)
+    g = torch.Generator().manual_seed(31)
+    st = O.init_state(cfg, 31)
+    for k in st:  # running statistics a trained checkpoint would hold (not the 0 / 1 initial values)
+        if k.endswith("running_mean"):
+            st[k] = 0.1 * torch.randn(st[k].shape, generator=g)
+        if k.endswith("running_var"):
+            st[k] = 0.5 + torch.rand(st[k].shape, generator=g)
+    x = torch.rand(B, Ci, 256, 256, generator=g)
+    specs = O.double_conv_specs(cfg)
+    pass_masks = [{pref: torch.bernoulli(torch.full((B, cout), 1 - p), generator=g) / (1 - p) for pref, _, _, cout in specs}
+                  for _ in range(passes)]
+    model = build_model(cfg, st, dropout=(p, p, p))
+    # sample (pass m, image i) sits at batch row m*B + i
+    model.model.mask_override = {j: torch.cat([pm[pref] for pm in pass_masks], 0) for j, (pref, _, _, _) in enumerate(specs)}
+    ens = EnsembleModule([], monte_carlo_steps=passes, models=[model], return_raw_predictions=True)
+    p1, p2 = ens(x.cuda())
+    r1, r2 = O.ensemble_forward(cfg, st, x, monte_carlo_steps=passes, pass_masks=pass_masks, raw=True)
+    e_raw = max(rel_err(p1, r1), rel_err(p2, r2))
+    ens.return_raw_predictions = False
+    mean, al, ep = ens(x.cuda())
+    rm, ra, re_ = O.ensemble_forward(cfg, st, x, monte_carlo_steps=passes, pass_masks=pass_masks)
+    errs = (rel_err(mean, rm), rel_err(al, ra), rel_err(ep, re_))
+    report(f"cfg5 256x256 16 passes B={B}: raw {e_raw:.2e}; mean / aleatoric / epistemic {errs[0]:.2e} / {errs[1]:.2e} / {errs[2]:.2e}")
+    assert e_raw < TOL and max(errs) < TOL
+    # the production path draws its own masks: passes differ, and chunked launches give the same statistics layout
+    model.model.mask_override = None
+    ens.return_raw_predictions = True
+    ens.max_samples_per_launch = 8  # 4 chunks of 4 passes x 2 images
+    q1, _ = ens(x.cuda())
+    assert q1.shape == p1.shape and torch.isfinite(q1).all()
+    assert not torch.equal(q1[:, 0], q1[:, 1])  # independent masks per pass
+
+
+def test_split16_against_fp32_mfma_family_on_random_geometries():
+    """The split16 path (wave-specialised kernels, fused pooling, in-place skip gradients) against the fp32-MFMA path
+    (a different convolution kernel family, exact fp32 fma chains) on the same parameters, random geometries incl.
+    odd sizes, Dropout2d with shared masks.  Loss / predictions to 1e-3; whole gradient to 5e-2 rel-L2 (tiny
+    networks: a single flipped ReLU / max-pool mask moves the gradient by percents, see test_network_gpu.check_grads)."""
+    from mimo.models.mimo_unet import MimoUnetModel
+    rng = random.Random(0)
+    worst = [0.0, 0.0, 0.0]
+    for i in range(10):
+        S = rng.choice([1, 2, 3])
+        f = rng.choice([4, 6, 8, 12, 16, 21, 30])
+        N = rng.choice([1, 2, 3, 5])
+        H = rng.choice([32, 33, 48, 50, 64, 70, 96, 100, 130])
+        W = rng.choice([32, 35, 48, 56, 64, 72, 96, 110, 128])
+        Ci = rng.choice([1, 2, 3])
+        drop = rng.choice([0.0, 0.0, 0.1])
+        torch.manual_seed(100 + i)
+        m = MimoUnetModel(in_channels=Ci, out_channels=2, num_subnetworks=S, filter_base_count=f, center_dropout_rate=0.0,
+                          final_dropout_rate=0.0, encoder_dropout_rate=drop, core_dropout_rate=drop,
+                          decoder_dropout_rate=drop, loss="laplace_nll", weight_decay=0.0, learning_rate=1e-3, seed=1,
+                          loss_buffer_size=10, loss_buffer_temperature=0.3).cuda().train()
+        image = torch.rand(N, Ci, H, W, device="cuda")
+        label = torch.rand(N, 1, H, W, device="cuda")
+        perms = torch.stack([torch.randperm(N) for _ in range(S)]).cuda()
+        m.loss_buffer.get_weights = lambda: torch.ones(S)
+        res = []
+        rng_state = torch.cuda.get_rng_state()
+        for precision in ("split16", "fp32"):
+            torch.cuda.set_rng_state(rng_state)  # same Dropout2d masks in both runs
+            m.model.set_precision(precision)
+            m.zero_grad()
+            out = m.training_step_with_perms(image, label, None, perms)
+            out["loss"].backward()
+            gr = torch.cat([q.grad.flatten() for q in m.parameters() if q.grad is not None]).double().cpu()
+            res.append((float(out["loss"]), gr, out["preds"].double().cpu()))
+        (la, ga, pa), (lb, gb, pb) = res
+        el = abs(la - lb) / max(abs(lb), 1e-6)
+        eg = float((ga - gb).norm() / gb.norm())
+        ep = float((pa - pb).abs().max() / pb.abs().max())
+        worst = [max(worst[0], el), max(worst[1], ep), max(worst[2], eg)]
+        assert el < TOL and ep < TOL and eg < 5e-2, (S, f, N, H, W, Ci, drop, el, ep, eg)
+    report(f"split16 vs fp32-MFMA family, 10 random geometries: worst loss {worst[0]:.1e} preds {worst[1]:.1e} gradient rel-L2 {worst[2]:.1e}")

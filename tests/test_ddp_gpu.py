@@ -68,4 +68,42 @@ def test_two_rank_training_step_gloo_on_gpu():
     (_, l0, r0, p0, c0), (_, l1, r1, p1, c1) = res
     assert torch.allclose(r0, l0 + l1, rtol=1e-6, atol=1e-9) and torch.equal(r0, r1)  # sum on every rank
     assert torch.equal(p0, p1)                                                       # identical Adam step (scale 1/2)
-    assert len(c0) == 2 and c0[0][1] == r0.numel() and c0[1][0] == 0 and c0[0][0] == c0[1][1]
+    # one announcement per backward stage, walking the flat buffer from its tail to its head without gaps
+    assert len(c0) == 8 and c0[0][1] == r0.numel() and c0[-1][0] == 0
+    assert all(c0[i][0] == c0[i + 1][1] for i in range(7))
+
+
+def _run_bench(extra_env, *argv):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    env.pop("MIMO_PARITY_LOG", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks_gloo_sharing_the_gpu():
+    """`python bench.py --gpus 2` with no torch.distributed environment starts two rank processes itself (the form
+    the driver uses); here over gloo with both ranks on GPU 0 so that it runs on a single-GPU box.  Strong scaling:
+    the global batch of 4 is sharded 2 + 2; rank-0 parameters are broadcast at start and all ranks end bit-identical."""
+    line = _run_bench({"MIMO_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                      "--scaling", "strong", "--profile-steps", "0", "--no-cpu-baseline")
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
+    cfg = line["config"]
+    assert cfg["global_batch"] == 4 and cfg["per_gpu_batch"] == 2 and cfg["rccl_ranks"] == 2
+    assert cfg["params_bit_identical_across_ranks"] is True
+    assert line["value"] > 0 and "roofline" not in line
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_bench_two_ranks_rccl():
+    line = _run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4", "--profile-steps", "0",
+                      "--no-cpu-baseline")
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 8
+    assert line["config"]["rccl_ranks"] == 2 and line["config"]["params_bit_identical_across_ranks"] is True

@@ -146,9 +146,13 @@ def _ddp_worker(rank, world, port, q):
     # stand-in per-rank "gradient": a deterministic function of the shard, 1000 floats
     flat = torch.cat([shard["image"].flatten(), shard["label"].flatten()]).repeat(7)[:1000].clone()
     local = flat.clone()
-    red = FlatGradientAllReducer(bucket_bytes=256 * 4)  # 4 buckets
-    red.start(flat, 0, 500)
-    red.start(flat, 500)
+    red = FlatGradientAllReducer(bucket_bytes=256 * 4, min_bucket_bytes=200 * 4)  # buckets of <= 256 floats
+    # announced like the engine does: adjacent ranges from the tail to the head; small ones are merged
+    red.start(flat, 900, 1000)   # held (100 < 200)
+    red.start(flat, 850, 900)    # merged: 150, still held
+    red.start(flat, 500, 850)    # merged: [500, 1000) -> issued as 256 + 244
+    red.start(flat, 0, 500)      # issued as 256 + 244
+    assert red.issued == [(500, 756), (756, 1000), (0, 256), (256, 500)], red.issued
     red.finish()
     q.put((rank, local.numpy(), flat.clone().numpy(), red.scale, shard["image"].shape[0]))  # by value
     dist.barrier()
@@ -312,3 +316,27 @@ def test_logging_without_a_trainer_and_parameter_version_tracks_loads():
     e0 = m.model._param_epoch
     m.load_state_dict(m.state_dict())
     assert m.model._param_epoch > e0
+
+
+def test_bench_multi_gpu_request_without_gpus_fails_cleanly():
+    """`bench.py --gpus 2` is self-launching; on a box without two GPUs it must say so (before any GPU call) instead of
+    silently running one rank."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MIMO_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present: the multi-rank run itself is covered by the gpu tests")
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+def test_bench_algorithmic_byte_model_matches_survey_table():
+    """SURVEY 8(d) contract figures: cfg3 = 525.3 / 188.7 / 94.4 / 47.2 / 5.9 MB per image and tier (861.5 total),
+    194.8 GFLOP per image; cfg2 605.0 MB, 95.4 GFLOP."""
+    import bench
+    tiers, total = bench.algorithmic_bytes_per_image(bench.CONFIGS["cfg3"])
+    assert [round(t / 1e6, 1) for t in tiers] == [525.3, 188.7, 94.4, 47.2, 5.9] and round(total / 1e6, 1) == 861.5
+    flops = 3 * sum(2 * ci * co * k * k * h * w for _, ci, co, h, w, k in bench.conv_layers(bench.CONFIGS["cfg3"]))
+    assert round(flops / 1e9, 1) == 194.8
+    assert round(bench.algorithmic_bytes_per_image(bench.CONFIGS["cfg2"])[1] / 1e6, 1) == 605.0

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import mimo_oracle as O
-from tests.helpers import cfg_from_meta, load_npz, rel_err, state_from
+from tests.helpers import cfg_from_meta, load_npz, rel_err, report, state_from
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -33,28 +33,19 @@ def is_prebn_bias(k):
     return k.endswith((".0.bias", ".3.bias")) and "double_conv" in k
 
 
-def check_grads(named_grads, ref_grads, tol=TOL, flip_robust=False):
-    """Per-tensor max error relative to the tensor's scale.  flip_robust (split16 arithmetic): the
-    forward differs from fp32 by a few 1e-6, which on these tiny networks can flip a single
-    ReLU / max-pool mask and move one or two tensors by percents (the derivative is discontinuous;
-    reproduced on CPU by emulating the split arithmetic) — require 1e-3 on >= 85 % of the
-    tensors, 5e-2 on all, and the whole gradient to agree (cosine > 0.9995)."""
-    worst, errs, dot, n1, n2 = ("", 0.0), [], 0.0, 0.0, 0.0
+def check_grads(named_grads, ref_grads, tol=TOL):
+    """Per-tensor max error relative to the tensor's scale, 1e-3 in both arithmetic modes (observed on the golden
+    fixtures: fp32 <= 6e-5, split16 <= 1e-4 — no ReLU / max-pool mask of these fixtures flips under the split
+    arithmetic; profiles/r02/parity_errors.txt)."""
+    worst = ("", 0.0)
     for k, ref in ref_grads.items():
         g = named_grads[k].double()
         r = torch.as_tensor(ref).double()
         scale = ref_grads[k[:-4] + "weight"] if is_prebn_bias(k) else ref  # zero-gradient biases: noise, see oracle test
         e = float((g - r).abs().max()) / max(float(torch.as_tensor(scale).abs().max()), 1e-30)
-        errs.append(e)
         if e > worst[1]:
             worst = (k, e)
-        if not is_prebn_bias(k):
-            dot, n1, n2 = dot + float((g * r).sum()), n1 + float((g * g).sum()), n2 + float((r * r).sum())
-        assert e < (5e-2 if flip_robust else tol), (k, e)
-    if flip_robust:
-        frac = sum(e < tol for e in errs) / len(errs)
-        cos = dot / (n1 * n2) ** 0.5
-        assert frac >= 0.85 and cos > 0.9995, (frac, cos, worst)
+        assert e < tol, (k, e)
     return worst
 
 
@@ -88,9 +79,8 @@ def test_train_steps_match_reference_golden(name, precision):
             preds = out_dict["preds"].view(N, S, half, *image.shape[-2:]).cpu()
             e_out = rel_err(preds, ref_out[:, :, :half])
             grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
-            worst = check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")},
-                                flip_robust=(precision != "fp32"))
-            print(f"{name} [{precision}]: out err {e_out:.2e}, worst grad err {worst[1]:.2e} at {worst[0]}")
+            worst = check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")})
+            report(f"{name} [{precision}]: out err {e_out:.2e}, worst grad err {worst[1]:.2e} at {worst[0]}")
             assert e_out < TOL
             sd = model.state_dict()
             for k, v in fx.items():
@@ -134,11 +124,10 @@ def test_input_gradient_and_generic_backward_cfg1(precision):
     loss = model.loss_fn.forward(p1, p2, y, reduce_mean=False).mean(dim=(0, 2, 3, 4)).mean()
     loss.backward()
     e = rel_err(x.grad.cpu(), fx["s0/dx"])
-    print(f"[{precision}] dx err {e:.2e}")
-    assert e < (TOL if precision == "fp32" else 5e-2)
+    report(f"[{precision}] dx err {e:.2e}")
+    assert e < TOL
     grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
-    check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")},
-                flip_robust=(precision != "fp32"))
+    check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")})
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -161,10 +150,9 @@ def test_elementwise_center_final_dropout_golden(precision):
     loss.mean().backward()
     e_dx = rel_err(x.grad.cpu(), fx["dx"])
     grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
-    worst = check_grads(grads, {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")},
-                        flip_robust=(precision != "fp32"))
-    print(f"elem dropout [{precision}]: out {e_out:.2e} dx {e_dx:.2e} worst grad {worst[1]:.2e} at {worst[0]}")
-    assert e_out < TOL and e_dx < (TOL if precision == "fp32" else 5e-2)
+    worst = check_grads(grads, {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")})
+    report(f"elem dropout [{precision}]: out {e_out:.2e} dx {e_dx:.2e} worst grad {worst[1]:.2e} at {worst[0]}")
+    assert e_out < TOL and e_dx < TOL
     # without an override the module draws its own Bernoulli masks: a different, but finite, result
     model.model.elem_mask_override = None
     with torch.no_grad():
@@ -192,7 +180,7 @@ def test_odd_sizes_forward(tag):
         p1, p2 = model(x)
     out_eval = torch.cat([p1, p2], dim=2).cpu()
     e1, e2 = rel_err(out_train, fx[tag + "/out_train"]), rel_err(out_eval, fx[tag + "/out_eval"])
-    print(f"odd {tag}: train {e1:.2e} eval {e2:.2e}")
+    report(f"odd {tag}: train {e1:.2e} eval {e2:.2e}")
     assert e1 < TOL and e2 < TOL
     sd = model.state_dict()
     for k, v in fx.items():
@@ -218,7 +206,7 @@ def test_mc_dropout_ensemble_golden():
     ens.return_raw_predictions = False
     mean, al, ep = ens(x)
     e = (rel_err(mean, fx["mean"]), rel_err(al, fx["alea"]), rel_err(ep, fx["epi"]))
-    print("mc-dropout errs", e)
+    report("mc-dropout errs", e)
     assert max(e) < TOL
     assert ens.num_subnetworks == S
 
@@ -286,7 +274,7 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, prec
         nr += float((g64 ** 2).sum())
         nd += float(((grads[k] - g64) ** 2).sum())
     cos, rel_l2 = dot / (nh * nr) ** 0.5, (nd / nr) ** 0.5
-    print(f"[{precision}] out {e_out:.2e} loss {e_loss:.2e} bn-buffers {e_buf:.2e}; grads vs fp64: cos {cos:.7f} rel-L2 {rel_l2:.2e}; "
+    report(f"[{precision}] out {e_out:.2e} loss {e_loss:.2e} bn-buffers {e_buf:.2e}; grads vs fp64: cos {cos:.7f} rel-L2 {rel_l2:.2e}; "
           f"worst tensor {worst[0]} hip {worst[1]:.2e} (fp32 oracle {worst[2]:.2e})")
     assert e_out < TOL and e_loss < TOL and e_buf < TOL
     assert cos > (0.9995 if small_net else 0.9999) and rel_l2 < (3e-2 if small_net else 2e-2)
@@ -297,7 +285,7 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, prec
 def test_cfg3_shape_vs_oracle(precision):
     """BASELINE config[2] geometry (2->1 ch, 256x256, S=2, fbc=30) at a batch the CPU oracle finishes in seconds."""
     e_out, worst = _oracle_vs_hip(O.NetConfig(2, 2, 2, 30), N=2, H=256, W=256, seed=5, precision=precision)
-    print(f"cfg3-shape: out err {e_out:.2e}; worst grad {worst}")
+    report(f"cfg3-shape: out err {e_out:.2e}; worst grad {worst}")
     assert e_out < TOL
 
 
@@ -305,14 +293,14 @@ def test_cfg3_shape_vs_oracle(precision):
 def test_cfg2_shape_vs_oracle(precision):
     """BASELINE config[1] geometry (3->1 ch, S=2, fbc=21: channel counts 21/42/63/31 exercise every padding path)."""
     e_out, worst = _oracle_vs_hip(O.NetConfig(3, 2, 2, 21), N=2, H=128, W=128, seed=6, with_mask=True, precision=precision)
-    print(f"cfg2-shape: out err {e_out:.2e}; worst grad {worst}")
+    report(f"cfg2-shape: out err {e_out:.2e}; worst grad {worst}")
     assert e_out < TOL
 
 
 def test_s4_gaussian_vs_oracle():
     """S=4 head-width stress (BASELINE config[3] topology) with the Gaussian loss, small spatial size."""
     e_out, worst = _oracle_vs_hip(O.NetConfig(2, 2, 4, 6), N=3, H=48, W=64, seed=7, loss="gaussian_nll")
-    print(f"S4: out err {e_out:.2e}; worst grad {worst}")
+    report(f"S4: out err {e_out:.2e}; worst grad {worst}")
     assert e_out < TOL
 
 
@@ -329,7 +317,7 @@ def test_more_geometries_vs_oracle(case):
     Ci, Co, S, f, N, H, W, loss, with_mask = case
     e_out, worst = _oracle_vs_hip(O.NetConfig(Ci, Co, S, f), N=N, H=H, W=W, seed=sum(case[:7]), loss=loss,
                                   with_mask=with_mask, small_net=f < 16)
-    print(f"{case}: out err {e_out:.2e}; worst grad {worst}")
+    report(f"{case}: out err {e_out:.2e}; worst grad {worst}")
 
 
 def test_batch_repetitions_and_input_repetition_vs_oracle():
@@ -337,7 +325,7 @@ def test_batch_repetitions_and_input_repetition_vs_oracle():
     the transformed batch is 2N wide and half of its rows show every subnetwork the same image."""
     e_out, worst = _oracle_vs_hip(O.NetConfig(3, 2, 2, 16), N=3, H=48, W=64, seed=11, with_mask=True, repetitions=2, irp=0.5,
                                   small_net=True)
-    print(f"repetitions: out err {e_out:.2e}; worst grad {worst}")
+    report(f"repetitions: out err {e_out:.2e}; worst grad {worst}")
 
 
 def test_full_size_properties():
@@ -444,8 +432,9 @@ def test_deep_ensemble_of_two_checkpoints(tmp_path):
 
 
 def test_staged_backward_equals_monolithic_and_hook_ranges():
-    """mimo_backward_stage 0 + 1 (data-parallel overlap path) == mimo_backward, and the gradient-ready hook
-    is told disjoint ranges that cover the flat buffer, the first one being the core/decoder tail."""
+    """mimo_backward_stage 0..7 (data-parallel overlap path) == mimo_backward, and the gradient-ready hook is told
+    disjoint ranges that walk the flat buffer from its tail (heads + decoders) to its head (encoders), each one
+    final — bit-identical to the finished buffer — at the moment it is announced."""
     fx = load_npz("mini_s2_step.npz")
     cfg = cfg_from_meta(fx["meta"])
     image, label, perms = (torch.from_numpy(fx[f"s0/{k}"]).cuda() for k in ("image", "label", "perms"))
@@ -459,12 +448,25 @@ def test_staged_backward_equals_monolithic_and_hook_ranges():
         out["loss"].backward()
         grads.append(model.model.flat_gradients().clone())
     assert torch.equal(grads[0], grads[1])
-    (b0, e0, g0), (b1, e1, g1) = calls
-    assert b1 == 0 and e1 == b0 and e0 == grads[0].numel() and b0 > 0
-    assert torch.equal(g0, grads[0][b0:e0]) and torch.equal(g1, grads[0][:e1])  # final when announced
+    assert len(calls) == 8 and calls[0][1] == grads[0].numel() and calls[-1][0] == 0
+    for i, (b, e, g) in enumerate(calls):
+        assert b < e and torch.equal(g, grads[0][b:e])  # final when announced
+        if i:
+            assert e == calls[i - 1][0]  # adjacent, descending
     names = dict(model.model.named_parameters())
     enc_numel = sum(p.numel() for n, p in names.items() if n.startswith("encoder."))
-    assert enc_numel <= b0 <= enc_numel + 4 * len(names)  # encoder block (+16-byte alignment gaps)
+    assert enc_numel <= calls[-1][1] <= enc_numel + 4 * len(names)  # encoder block (+16-byte alignment gaps)
+    dec_numel = sum(p.numel() for n, p in names.items() if n.startswith("decoder."))
+    assert dec_numel <= calls[0][1] - calls[0][0] <= dec_numel + 4 * len(names)
+    # gradient accumulation under a hook: ranges are announced after the accumulation, with the accumulated values
+    calls.clear()
+    out = model.training_step_with_perms(image, label, None, perms)
+    out["loss"].backward()  # .grad still set: accumulates
+    assert len(calls) == 8
+    total = model.model.flat_gradients()
+    for b, e, g in calls:
+        assert torch.equal(g, total[b:e])
+    assert torch.allclose(total, 2 * grads[0], rtol=1e-5, atol=1e-8)
 
 
 @pytest.mark.parametrize("name", ["mini_s2_step.npz", "cfg1_step.npz"])
@@ -542,6 +544,78 @@ def test_inference_path_matches_eval_forward_and_tracks_parameter_changes():
     assert torch.isfinite(xg.grad).all()
 
 
+def test_inference_cache_is_invalidated_by_load_state_dict_alone():
+    """no_grad forward, load_state_dict, no_grad forward — with NO grad-enabled call in between (which would reset
+    the cache by itself): the second forward must use the new weights, also for in-place parameter writes torch
+    can see (p.copy_) and after mark_parameters_changed() for raw writes through .data."""
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    s_a, s_b = state_from(fx, "init/"), state_from(fx, "final/")
+    s_b.pop("loss_buffer", None)
+    x = repeat_sub(torch.from_numpy(fx["s0/image"]).cuda(), cfg.num_subnetworks)
+    want = []
+    for st in (s_a, s_b):
+        m = build_model(cfg, st)
+        m.eval()
+        with torch.no_grad():
+            want.append(m(x)[0].clone())
+    assert not torch.equal(want[0], want[1])
+    model = build_model(cfg, s_a)
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(model(x)[0], want[0])
+        assert torch.equal(model(x)[0], want[0])          # served from the cache / graph replay
+        model.load_state_dict({"model." + k: v for k, v in s_b.items()})
+        assert torch.equal(model(x)[0], want[1])
+        assert torch.equal(model(x)[0], want[1])
+        for k, p in model.model.named_parameters():      # in-place copies torch's version counters see
+            p.copy_(s_a[k].cuda())
+        for k, b in model.model.named_buffers():
+            b.copy_(s_a[k].cuda())
+        assert torch.equal(model(x)[0], want[0])
+        for k, p in model.model.named_parameters():      # raw writes: invisible to torch, announced by hand
+            p.data.copy_(s_b[k].cuda())
+        for k, b in model.model.named_buffers():
+            b.data.copy_(s_b[k].cuda())
+        model.model.mark_parameters_changed()
+        assert torch.equal(model(x)[0], want[1])
+
+
+def test_flat_adam_checkpoint_resume_on_device(tmp_path):
+    """Optimiser state saved, re-loaded with map_location="cpu" (what Lightning's checkpoint IO delivers) and
+    stepped: identical parameters to the uninterrupted run — the moments are moved, not silently re-zeroed."""
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    image, label, perms = (torch.from_numpy(fx[f"s0/{k}"]).cuda() for k in ("image", "label", "perms"))
+
+    def one_step(m, opt):
+        opt.zero_grad()
+        m.training_step_with_perms(image, label, None, perms)["loss"].backward()
+        opt.step()
+
+    model = build_model(cfg, state_from(fx, "init/"))
+    model.train()
+    opt = model.configure_optimizers()["optimizer"]
+    one_step(model, opt)
+    one_step(model, opt)
+    path = str(tmp_path / "ck.pt")
+    torch.save({"state_dict": model.state_dict(), "optimizer": opt.state_dict(),
+                "loss_buffer": (model.loss_buffer.buffer.clone(), model.loss_buffer.index)}, path)
+    one_step(model, opt)
+    want = model.model.flat_parameters().clone()
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert not ck["optimizer"]["flat"]["exp_avg"].is_cuda
+    resumed = build_model(cfg, state_from(fx, "init/"))
+    resumed.load_state_dict(ck["state_dict"])
+    resumed.train()
+    resumed.loss_buffer.buffer.copy_(ck["loss_buffer"][0])
+    resumed.loss_buffer.index = ck["loss_buffer"][1]
+    opt2 = resumed.configure_optimizers()["optimizer"]
+    opt2.load_state_dict(ck["optimizer"])
+    one_step(resumed, opt2)
+    assert opt2._step == 3 and torch.equal(resumed.model.flat_parameters(), want)
+
+
 def repeat_sub(x, S):
     return x[:, None].repeat(1, S, 1, 1, 1).contiguous()
 
@@ -570,10 +644,9 @@ def test_evidential_model_golden(precision):
     assert set(out) == {"loss", "label", "preds", "aleatoric_std_map", "err_map", "mask"}
     e_dx = rel_err(x.grad.cpu(), fx["dx"])
     grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in m.named_parameters()}
-    worst = check_grads(grads, {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")},
-                        flip_robust=(precision != "fp32"))
-    print(f"evidential [{precision}]: dx {e_dx:.2e} worst grad {worst[1]:.2e} at {worst[0]}")
-    assert e_dx < (TOL if precision == "fp32" else 5e-2)
+    worst = check_grads(grads, {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")})
+    report(f"evidential [{precision}]: dx {e_dx:.2e} worst grad {worst[1]:.2e} at {worst[0]}")
+    assert e_dx < TOL
     m.eval()
     v = m.validation_step({"image": x.detach(), "label": y, "mask": mask}, 0)
     assert set(v) == {"loss", "label", "preds", "aleatoric_std_map", "epistemic_std_map", "err_map", "mask"}
@@ -627,7 +700,7 @@ def test_bf16_precision_mode(name):
         g, r = p.grad.detach().cpu().double(), torch.from_numpy(fx["s0/grad/" + k[len("model."):]]).double()
         dot, n1, n2 = dot + float((g * r).sum()), n1 + float((g * g).sum()), n2 + float((r * r).sum())
     cos = dot / (n1 * n2) ** 0.5
-    print(f"bf16 {name}: eval fwd vs bf16 oracle {e16:.2e} (vs fp32 {e32:.2e}); train out vs bf16 oracle {t16:.2e}, "
+    report(f"bf16 {name}: eval fwd vs bf16 oracle {e16:.2e} (vs fp32 {e32:.2e}); train out vs bf16 oracle {t16:.2e}, "
           f"vs fp32 golden {t32:.2e}; gradient cosine vs fp32 golden {cos:.4f}")
     assert e16 < 3e-4 and e16 < e32 and e32 < 2e-2
     assert t16 < 1e-1 and t32 < 1e-1 and cos > 0.9

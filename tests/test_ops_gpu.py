@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import mimo_oracle as O
-from tests.helpers import rel_err
+from tests.helpers import rel_err, report
 
 pytestmark = pytest.mark.gpu
 
@@ -90,7 +90,7 @@ def test_conv3x3_forward_dgrad_wgrad(case, precision):
                                       Co, cop, prec, st), "conv wgrad")
     errs["wgrad"] = rel_err(dwd.cpu(), wr.grad)
     errs["bgrad"] = rel_err(dbd.cpu(), br.grad)
-    print("conv", precision, case, {k: f"{v:.2e}" for k, v in errs.items()})
+    report("conv", precision, case, {k: f"{v:.2e}" for k, v in errs.items()})
     stat_tol = TOL if precision != "bf16" else 2e-2  # the statistics are sums of the (bf16-product) outputs
     bad = {k: v for k, v in errs.items() if not v < (TOL if k == "bgrad" else stat_tol if k in ("sum", "sumsq") else tol)}
     assert not bad, bad
@@ -126,7 +126,7 @@ def test_upsample_cat(case):
                                      L.current_stream()))
     torch.cuda.synchronize()
     e = rel_err(from_nhwc(od, Cs + Cl), ref)
-    print("upcat", case, f"{e:.2e}")
+    report("upcat", case, f"{e:.2e}")
     assert e < 1e-6
 
 
@@ -259,5 +259,5 @@ def test_bf16_conv_kernels_against_rounded_operand_reference(case):
                                       prec, st))
     torch.cuda.synchronize()
     errs = (rel_err(from_nhwc(zd, Co), z_ref), rel_err(from_nhwc(dxd, Ci), xr.grad), rel_err(dwd.cpu(), dw_ref))
-    print("bf16 exact", case, ["%.2e" % e for e in errs])
+    report("bf16 exact", case, ["%.2e" % e for e in errs])
     assert max(errs) < 2e-6
