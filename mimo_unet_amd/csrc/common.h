@@ -33,6 +33,17 @@ static inline int pad_channels(int c) { return round_up(c, 8); }
 
 constexpr int kWave = 64;
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with a private L2) in linear-id order.  This maps a
+// linear workgroup id to a "virtual" index such that every XCD owns one CONTIGUOUS range of virtual indices
+// (any total, bijective): kernels then decode the virtual index so that workgroups which read the same
+// operand tiles (the channel tiles of one pixel tile; neighbouring pixel tiles sharing halo rows) are
+// neighbours in virtual order and therefore meet in one L2 instead of eight.
+__device__ __forceinline__ int xcd_virtual_index(int linear, int total) {
+  const int k = linear & 7, slot = linear >> 3;
+  const int base = total >> 3, rem = total & 7;  // XCD j receives base + (j < rem) workgroups
+  return k * base + (k < rem ? k : rem) + slot;
+}
+
 // ------------------------------------------------------------------ conv3x3 (conv3x3.hip)
 // "forward-type" 3x3 correlation on the f32 MFMA: y[n,oy,ox,co] = bias[co] +
 //   sum_{kh,kw,ci} w[kh,kw][co][ci] * X(n, oy+kh-off, ox+kw-off, ci)

@@ -390,7 +390,8 @@ constexpr int kWsMaxMF = 4;
 template <int NF, int MODE, bool SWZ, int MF_>
 __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC,
                                                                                           int tilesY, int tilesX,
-                                                                                          int numTiles, int xcd_order) {
+                                                                                          int numTiles, int xcd_order,
+                                                                                          int gx, int coTiles) {
   MIMO_CONV_MODE_CONSTANTS
   typedef typename Elem<F16>::T ET;
   typedef typename Elem<F16>::V8 bf16x8;
@@ -416,14 +417,16 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   const int lane = tid & 63, wave = tid >> 6;
   const int TCP = TC + 2, TRP = TR + 2;
   const int npix_lds = TRP * TCP, npix_out = TR * TC;
-  const int co0 = blockIdx.y * NB;
   const int nchunks = (a.cin_p + 31) / 32;
-  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the 32
-  // workgroups of an XCD take 32 CONSECUTIVE tiles per round — vertically adjacent tile rows, whose halo
-  // rows they share, then meet in one L2 instead of eight
-  const int vbx = (xcd_order && gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8)
-                                                     : (int)blockIdx.x;
-  const int ntiles_mine = vbx < numTiles ? (numTiles - 1 - vbx) / (int)gridDim.x + 1 : 0;
+  // 1-D grid of gx * coTiles workgroups: gx persistent pixel-tile columns x coTiles output-channel tiles.
+  // XCD-aware order (xcd_virtual_index, common.h): virtual index v = column * coTiles + channel tile, so the
+  // coTiles workgroups that read the SAME input tiles sit on one XCD and fetch them from HBM once (measured
+  // before: 11 x re-read of the input on the 480-channel layers, one per channel tile), and an XCD owns
+  // gx / 8 CONSECUTIVE columns — vertically adjacent tile rows, whose halo rows they share.
+  const int v_ = xcd_order ? xcd_virtual_index((int)blockIdx.x, gx * coTiles) : (int)blockIdx.x;
+  const int vbx = v_ / coTiles;
+  const int co0 = (v_ - vbx * coTiles) * NB;
+  const int ntiles_mine = vbx < numTiles ? (numTiles - 1 - vbx) / gx + 1 : 0;
   const int nstages = ntiles_mine * nchunks;  // input-tile stages (tile, chunk); 3 phases each
 
   if (wave >= 4) {
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   {                                                                                                  \
     const int st_ = (STAGE);                                                                         \
     const int ti_ = st_ / nchunks, ck_ = st_ - ti_ * nchunks;                                        \
-    int t_ = vbx + ti_ * gridDim.x;                                                                  \
+    int t_ = vbx + ti_ * gx;                                                                         \
     const int tx_ = t_ % tilesX;                                                                     \
     t_ /= tilesX;                                                                                    \
     const int ty_ = t_ % tilesY;                                                                     \
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   // bias, store, BatchNorm partial sums of tile TI (its accumulators are complete), then clear them
 #define C_EPILOGUE(TI)                                                                               \
   {                                                                                                  \
-    int t_ = vbx + (TI) * gridDim.x;                                                                 \
+    int t_ = vbx + (TI) * gx;                                                                        \
     const int tx_ = t_ % tilesX;                                                                     \
     t_ /= tilesX;                                                                                    \
     const int ty_ = t_ % tilesY;                                                                     \
@@ -769,7 +772,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   }
   C_EPILOGUE(ti)
   if (CVT && a.stats) {
-    const size_t row = ((size_t)blockIdx.x * 4 + wave) * 2;
+    const size_t row = ((size_t)vbx * 4 + wave) * 2;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
@@ -818,15 +821,15 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   const int per = ceil_div(numTiles, gx);
   gx = ceil_div(numTiles, per);
   if (rows) *rows = gx * 4;  // one partial-statistics row per (workgroup, consumer wave)
-  dim3 grid(gx, coTiles);
+  dim3 grid(gx * coTiles);
   // conflict-free swizzled rows measured the same step time as the padded rows (6.97 / 7.20 vs 6.89 / 7.20 ms
   // forward / data gradient per step): the LDS array is not what the consumers wait for.  Opt-in.
   static const bool swz = getenv("MIMO_CONV_WS_SWIZZLE") && atoi(getenv("MIMO_CONV_WS_SWIZZLE")) != 0;
   static const int xcd = !(getenv("MIMO_CONV_XCD_ORDER") && atoi(getenv("MIMO_CONV_XCD_ORDER")) == 0);
   if (swz)
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, true, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, true, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
   else
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

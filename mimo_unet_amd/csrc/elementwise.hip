@@ -193,6 +193,66 @@ __device__ __forceinline__ void chunk_total2(const double* __restrict__ col_a, c
   *tb = (red[256 + cl] + red[320 + cl]) + (red[384 + cl] + red[448 + cl]);
 }
 
+// ---- one-launch column sums: 1024 threads = 64 columns x 16 row groups walk the fp32 partial rows directly
+// (double accumulation, fixed order: deterministic), so a reduction is ONE launch instead of the rowsum +
+// finalize pair (~150 launches of 4-6 us per step).  The partial tables are small (rows <= 2048, a few hundred
+// KB per 64 columns) and L2-resident right after the kernel that wrote them.
+constexpr int kColsumThreads = 1024;
+__device__ __forceinline__ void block_colsum2(const float* __restrict__ partial, int rows, size_t stride, int col_a,
+                                              int col_b, bool valid, bool two, double* red /*[2048]*/, double* ta,
+                                              double* tb) {
+  const int rg = threadIdx.x >> 6;
+  double sa = 0.0, sb = 0.0;
+  if (valid) {
+    const float* pa = partial + col_a;
+    const float* pb = partial + col_b;
+    int r = rg;
+    for (; r + 48 < rows; r += 64) {  // four independent loads in flight per plane
+      const float a0 = pa[(size_t)r * stride], a1 = pa[(size_t)(r + 16) * stride], a2 = pa[(size_t)(r + 32) * stride],
+                  a3 = pa[(size_t)(r + 48) * stride];
+      sa += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      if (two) {
+        const float b0 = pb[(size_t)r * stride], b1 = pb[(size_t)(r + 16) * stride], b2 = pb[(size_t)(r + 32) * stride],
+                    b3 = pb[(size_t)(r + 48) * stride];
+        sb += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+      }
+    }
+    for (; r < rows; r += 16) {
+      sa += (double)pa[(size_t)r * stride];
+      if (two) sb += (double)pb[(size_t)r * stride];
+    }
+  }
+  __syncthreads();
+  red[threadIdx.x] = sa;
+  red[1024 + threadIdx.x] = sb;
+  __syncthreads();
+  const int cl = threadIdx.x & 63;
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    a += red[k * 64 + cl];
+    b += red[1024 + k * 64 + cl];
+  }
+  *ta = a;
+  *tb = b;
+}
+
+// out[c] = sum over rows of partial[r][c]  (conv bias gradient)
+__global__ __launch_bounds__(kColsumThreads) void colsum_vec_kernel(const float* __restrict__ partial, int rows, int cols,
+                                                                    int C, float* __restrict__ out) {
+  __shared__ double red[2048];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s, unused;
+  block_colsum2(partial, rows, (size_t)cols, c, c, c < C, false, red, &s, &unused);
+  if (c < C && threadIdx.x < 64) out[c] = (float)s;
+}
+
+int colsum_vec_launch(const float* partial, int rows, int cols, int C, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_vec_kernel, dim3(ceil_div(C, 64)), dim3(kColsumThreads), 0, st, partial, rows, cols, C, out);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
 __global__ void vec_finalize_kernel(const double* __restrict__ sums, int chunks, int cols, int C, float* __restrict__ out) {
   __shared__ double red[256];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -288,6 +348,46 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ sums, int chun
   const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
   running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
   running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+}
+
+// rowsum + bn_fwd_finalize in one launch: partial rows [rows][2][cout_pad] straight from the convolution epilogue
+__global__ __launch_bounds__(kColsumThreads) void bn_fwd_stats_kernel(
+    const float* __restrict__ partial, int rows, int cout_pad, int C, int Cp, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+    float eps, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double red[2048];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s1, s2;
+  block_colsum2(partial, rows, (size_t)2 * cout_pad, c, cout_pad + c, c < C, true, red, &s1, &s2);
+  if (c >= Cp || threadIdx.x >= 64) return;
+  if (c >= C) {
+    mean[c] = 0.f;
+    invstd[c] = 0.f;
+    scale[c] = 0.f;
+    shift[c] = 0.f;
+    return;
+  }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  var = var > 0.0 ? var : 0.0;
+  const double is = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] * is;
+  mean[c] = (float)m;
+  invstd[c] = (float)is;
+  scale[c] = (float)sc;
+  shift[c] = (float)((double)beta[c] - m * sc);
+  const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+  running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+  running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+}
+
+int bn_fwd_stats_launch(const float* partial, int rows, int cout_pad, int C, int Cp, int64_t count, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                        float* invstd, float* scale, float* shift, hipStream_t st) {
+  hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(ceil_div(Cp, 64)), dim3(kColsumThreads), 0, st, partial, rows, cout_pad, C, Cp,
+                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
 }
 
 int bn_fwd_finalize_launch(const double* sums, int chunks, int cout_pad, int C, int Cp, int64_t count,
@@ -846,6 +946,32 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int chun
   }
 }
 
+// rowsum + bn_bwd_finalize in one launch: partial rows [rows][2][Cp] from bnrelu_bwd_reduce
+__global__ __launch_bounds__(kColsumThreads) void bn_bwd_stats_kernel(const float* __restrict__ partial, int rows, int C,
+                                                                      int Cp, double count, int training,
+                                                                      float* __restrict__ c1, float* __restrict__ c2,
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double red[2048];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s1, s2;
+  block_colsum2(partial, rows, (size_t)2 * Cp, c, Cp + c, c < Cp, true, red, &s1, &s2);
+  if (c >= Cp || threadIdx.x >= 64) return;
+  c1[c] = training ? (float)(s1 / count) : 0.f;
+  c2[c] = training ? (float)(s2 / count) : 0.f;
+  if (c < C) {
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+  }
+}
+
+int bn_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int64_t count, int training, float* c1, float* c2,
+                        float* dgamma, float* dbeta, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(ceil_div(Cp, 64)), dim3(kColsumThreads), 0, st, partial, rows, C, Cp,
+                     (double)count, training, c1, c2, dgamma, dbeta);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
 int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_t count, int training, float* c1,
                            float* c2, float* dgamma, float* dbeta, hipStream_t st) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(Cp, 64)), dim3(256), 0, st, sums, chunks, C, Cp, (double)count,
@@ -1199,6 +1325,31 @@ __global__ void head_bwd_finalize_kernel(const double* __restrict__ sums, int ch
   } else {
     db[i - Co * Cp] = (float)s;
   }
+}
+
+// rowsum + head_bwd_finalize in one launch: partial rows [rows][Co*Cp + Co] from head_bwd
+__global__ __launch_bounds__(kColsumThreads) void head_bwd_stats_kernel(const float* __restrict__ partial, int rows, int C,
+                                                                        int Cp, int Co, float* __restrict__ dw,
+                                                                        float* __restrict__ db) {
+  __shared__ double red[2048];
+  const int cols = Co * Cp + Co;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s, unused;
+  block_colsum2(partial, rows, (size_t)cols, i, i, i < cols, false, red, &s, &unused);
+  if (i >= cols || threadIdx.x >= 64) return;
+  if (i < Co * Cp) {
+    const int co = i / Cp, c = i - co * Cp;
+    if (c < C) dw[co * C + c] = (float)s;
+  } else {
+    db[i - Co * Cp] = (float)s;
+  }
+}
+
+int head_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int Co, float* dw, float* db, hipStream_t st) {
+  hipLaunchKernelGGL(head_bwd_stats_kernel, dim3(ceil_div(Co * Cp + Co, 64)), dim3(kColsumThreads), 0, st, partial, rows, C, Cp,
+                     Co, dw, db);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
 }
 
 int head_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int Co, float* dw, float* db, hipStream_t st) {

@@ -738,11 +738,17 @@ struct mimo_plan {
       MIMO_TRY(conv3x3_launch(a, &rows, st));
     prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     if (training) {
-      int chunks = 0;
-      MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_pad, s_sums, &chunks, st));
-      MIMO_TRY(bn_fwd_finalize_launch(s_sums, chunks, L.cout_pad, L.Cout, L.cout_p, P, params + L.off_gamma,
-                                      params + L.off_beta, bnbuf + L.off_rm, bnbuf + L.off_rv, cfg.bn_momentum,
-                                      cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
+      if (rows <= kColsumMaxRows) {
+        MIMO_TRY(bn_fwd_stats_launch(s_partial, rows, L.cout_pad, L.Cout, L.cout_p, P, params + L.off_gamma,
+                                     params + L.off_beta, bnbuf + L.off_rm, bnbuf + L.off_rv, cfg.bn_momentum, cfg.bn_eps,
+                                     L.mean, L.invstd, L.scale, L.shift, st));
+      } else {
+        int chunks = 0;
+        MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_pad, s_sums, &chunks, st));
+        MIMO_TRY(bn_fwd_finalize_launch(s_sums, chunks, L.cout_pad, L.Cout, L.cout_p, P, params + L.off_gamma,
+                                        params + L.off_beta, bnbuf + L.off_rm, bnbuf + L.off_rv, cfg.bn_momentum,
+                                        cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
+      }
     }
     if (!fused) {
       pr = prof_begin(MIMO_PROF_BN_RELU_FWD, st);
@@ -964,15 +970,14 @@ struct mimo_plan {
 
   int convbn_backward(ConvBN& L, const float* da, int ldda, const float* dxpad_src, const float* mask, bool need_dgrad,
                       float* dxpad_out, hipStream_t st) {
-    int rows = 0, chunks = 0;
+    int rows = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
     int pr = prof_begin(MIMO_PROF_BN_BWD_REDUCE, st);
     MIMO_TRY(bnrelu_bwd_reduce_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd,
                                       mask, L.Cout, L.cout_p, L.N, L.H, L.W, s_partial, &rows, st));
     prof_end(pr, 0.0, 8.0 * (double)P * L.cout_p, st);
-    MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_p, s_sums, &chunks, st));
-    MIMO_TRY(bn_bwd_finalize_launch(s_sums, chunks, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
-                                    grads + L.off_gamma, grads + L.off_beta, st));
+    MIMO_TRY(bn_bwd_stats_launch(s_partial, rows, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
+                                 grads + L.off_gamma, grads + L.off_beta, st));
     const int b = dz_idx;
     float* dz = s_dz2[b];
     if (wg_async) {
@@ -993,8 +998,7 @@ struct mimo_plan {
     // wgrad(L) may start as soon as dz exists, next to dgrad(L) (releasing it only after dgrad(L), i.e. next
     // to the bandwidth-bound kernels of the layer below, measured the same step time)
     if (wg_async) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
-    MIMO_TRY(rowsum_launch(s_partial, rows, L.cout_p, s_sums, &chunks, st));
-    MIMO_TRY(vec_finalize_launch(s_sums, chunks, L.cout_p, L.Cout, grads + L.off_b, st));
+    MIMO_TRY(colsum_vec_launch(s_partial, rows, L.cout_p, L.Cout, grads + L.off_b, st));
     if (need_dgrad) {
       ConvLaunch a;
       a.x = dz;
@@ -1175,15 +1179,14 @@ struct mimo_plan {
         const int fp = pad_channels(f);
         for (int s = S - 1; s >= 0; --s) {
           DoubleConv* dc = up4[s];
-          int rows = 0, chunks = 0;
+          int rows = 0;
           const int blk = prof_begin(kProfTierBase + 1, st);
           const int pr = prof_begin(MIMO_PROF_HEAD_BWD, st);
           MIMO_TRY(head_bwd_launch(dc->out.a, dc->out.ld, params + heads[s].off_w, f, fp, Co, N, S, s, H * W, out, dout, dloss,
                                    label, lmask, lperm, cfg.loss_kind, cfg.eps_min, cfg.eps_max, dc->out.da, s_partial, &rows,
                                    st));
           prof_end(pr, 0.0, 4.0 * (double)N * H * W * (2.0 * fp + Co + Co / 2), st);
-          MIMO_TRY(rowsum_launch(s_partial, rows, Co * fp + Co, s_sums, &chunks, st));
-          MIMO_TRY(head_bwd_finalize_launch(s_sums, chunks, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, st));
+          MIMO_TRY(head_bwd_stats_launch(s_partial, rows, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, st));
           if (!elem_masks.empty() && elem_masks[1 + s])
             MIMO_TRY(elem_mask_mul_launch(dc->out.da, dc->out.ldda, elem_masks[1 + s], N, dc->out.C, dc->out.Cp, H * W, st));
           prof_end(blk, 0.0, 0.0, st);

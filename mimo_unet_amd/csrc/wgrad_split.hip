@@ -278,9 +278,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int coTiles = a.cout_pad / CO;
-  const int ciT = blockIdx.x / coTiles, coT = blockIdx.x - ciT * coTiles;
+  // 1-D grid of wtiles * splits workgroups.  XCD-aware order (xcd_virtual_index, common.h): virtual index =
+  // split * wtiles + weight tile, so the (ci, co) weight tiles of one pixel split — which all read the same
+  // activation / dz tiles — occupy as few XCDs as possible and fetch those tiles from HBM once per XCD
+  // (before: every XCD held one co tile of every split, i.e. the activation operand was read 8 x).
+  const int wtiles = (a.cin_pad / CI) * coTiles;
+  const int v_ = xcd_virtual_index((int)blockIdx.x, wtiles * a.splits);
+  const int bsplit = v_ / wtiles, bwt = v_ - bsplit * wtiles;
+  const int ciT = bwt / coTiles, coT = bwt - ciT * coTiles;
   const int ci0 = ciT * CI, co0 = coT * CO;
-  const int ntiles_mine = blockIdx.y < numTiles ? (numTiles - 1 - blockIdx.y) / gridDim.y + 1 : 0;
+  const int ntiles_mine = bsplit < numTiles ? (numTiles - 1 - bsplit) / a.splits + 1 : 0;
 
   if (wave >= 4) {
     // =========================== producers ===========================
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     }                                                                                               \
   }
     // register set s (0/1) carries tile j with j&1 == s; loads are issued two tiles (= two barriers) ahead
-    const int T0 = blockIdx.y, TS = gridDim.y;
+    const int T0 = bsplit, TS = a.splits;
     if (ntiles_mine > 0) {
       WS_LOAD(xa0, xd0, T0)
       if (ntiles_mine > 1) WS_LOAD(xa1, xd1, T0 + TS)
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     }
     __syncthreads();
   }
-  float* out = a.partial + (size_t)blockIdx.y * 9 * a.cin_pad * a.cout_pad;
+  float* out = a.partial + (size_t)bsplit * 9 * a.cin_pad * a.cout_pad;
   const int t0 = tset ? 5 : 0, nt = TSPLIT ? (tset ? 4 : 5) : 9;
 #pragma unroll
   for (int tt = 0; tt < NTMAX; ++tt)
@@ -549,6 +556,7 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
   const int numTiles = a.N * tilesY * tilesX;
   dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
   if (ws) {
+    grid = dim3(grid.x * grid.y);  // 1-D, decoded XCD-aware inside the kernel
 #define WS_LAUNCH2(NI_, CI_, TR_)                                                                                       \
   if (a.np == 1)                                                                                                     \
     hipLaunchKernelGGL((wgrad_split_ws_kernel<1, NI_, CI_, TR_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \

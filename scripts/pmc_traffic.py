@@ -39,7 +39,7 @@ for k, (n, c) in F.items():
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
                  "--warmup 1 --no-cpu-baseline; FETCH_SIZE in KB x2 (gfx950: a wide coalesced read is tallied at half its "
                  "bytes, MI355X_MICROARCH.md HBM section), WRITE_SIZE in KB; summed over the executed steps",
-       "steps": steps, "total_gb_per_step": {"read": round(tot_r / steps / 1e9, 2), "write": round(tot_w / steps / 1e9, 2)},
+       "steps": steps, "step_bytes": round((tot_r + tot_w) / steps), "total_gb_per_step": {"read": round(tot_r / steps / 1e9, 2), "write": round(tot_w / steps / 1e9, 2)},
        "classes": {c_: {"launches_per_step": a["launches"] / steps, "read_bytes_per_launch": round(a["read"] / a["launches"]),
                         "write_bytes_per_launch": round(a["write"] / a["launches"]),
                         "bytes_per_launch": round((a["read"] + a["write"]) / a["launches"])} for c_, a in agg.items()}}

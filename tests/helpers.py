@@ -46,9 +46,10 @@ def free_port():
         return so.getsockname()[1]
 
 
-def report(msg):
+def report(*parts):
     """Print an observed-error line and, when MIMO_PARITY_LOG names a file, append it there (the GPU run's
     parity_errors.txt that is committed under profiles/)."""
+    msg = " ".join(str(p) for p in parts)
     print(msg)
     path = os.environ.get("MIMO_PARITY_LOG")
     if path:

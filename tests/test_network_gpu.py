@@ -460,6 +460,7 @@ def test_staged_backward_equals_monolithic_and_hook_ranges():
     assert dec_numel <= calls[0][1] - calls[0][0] <= dec_numel + 4 * len(names)
     # gradient accumulation under a hook: ranges are announced after the accumulation, with the accumulated values
     calls.clear()
+    model.loss_buffer.get_weights = lambda: torch.ones(cfg.num_subnetworks, device="cuda")  # as in the first step
     out = model.training_step_with_perms(image, label, None, perms)
     out["loss"].backward()  # .grad still set: accumulates
     assert len(calls) == 8
@@ -702,7 +703,9 @@ def test_bf16_precision_mode(name):
     cos = dot / (n1 * n2) ** 0.5
     report(f"bf16 {name}: eval fwd vs bf16 oracle {e16:.2e} (vs fp32 {e32:.2e}); train out vs bf16 oracle {t16:.2e}, "
           f"vs fp32 golden {t32:.2e}; gradient cosine vs fp32 golden {cos:.4f}")
-    assert e16 < 3e-4 and e16 < e32 and e32 < 2e-2
-    assert t16 < 1e-1 and t32 < 1e-1 and cos > 0.9
+    # observed (profiles/r02/parity_errors.txt): e16 3.0e-5 / 1.8e-5, e32 2.9e-4 / 9.0e-5, t16 1.3e-2 / 2.3e-2,
+    # t32 3.7e-2 / 4.3e-2, 1 - cosine 1.5e-2 / 4.7e-2 — bounds = about 5x the larger observation
+    assert e16 < 1.5e-4 and e16 < e32 and e32 < 1.5e-3
+    assert t16 < 1e-1 and t32 < 2e-1 and cos > 0.9
     np.testing.assert_allclose(out["loss"].item(), float(ref["total"]), rtol=2e-2, atol=2e-3)
     np.testing.assert_allclose(out["loss"].item(), fx["s0/total"], rtol=5e-2, atol=5e-3)
