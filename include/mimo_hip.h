@@ -120,6 +120,10 @@ typedef struct mimo_forward_args {
    *     the packed weight copies and BatchNorm scale/shift of the previous call. */
   int32_t no_grad;
   int64_t param_version;
+  /* batch rows of the x tensor (= of the label / mask tensors later given to mimo_loss_forward); 0 = the plan's
+   * batch.  With perm the gather may repeat rows (batch_repetitions, utils.py:27-31), so x can hold fewer rows than
+   * the plan's batch; the staged (hipGraph) paths copy exactly this many. */
+  int64_t x_rows;
 } mimo_forward_args;
 int mimo_plan_num_double_convs(const mimo_plan* plan);
 int mimo_plan_double_conv_channels(const mimo_plan* plan, int index); /* Cout of DoubleConv #index */

@@ -37,6 +37,7 @@ class ForwardArgs(C.Structure):
         ("x", C.c_void_p), ("stride_n", C.c_int64), ("stride_s", C.c_int64), ("perm", C.c_void_p),
         ("training", C.c_int32), ("drop_masks", C.POINTER(C.c_void_p)), ("out", C.c_void_p),
         ("elem_masks", C.POINTER(C.c_void_p)), ("no_grad", C.c_int32), ("param_version", C.c_int64),
+        ("x_rows", C.c_int64),
     ]
 
 

@@ -14,15 +14,23 @@ constexpr int kMaxHeadOut = 8;   // out_channels supported by the fused head ker
 // ---- generic two-level column reduction of per-workgroup partial rows -------------------
 // partial [rows][cols] (float) -> sums [chunks][cols] (double); returns chunks via *chunks.
 int rowsum_launch(const float* partial, int rows, int cols, double* sums, int* chunks, hipStream_t s);
-// one-launch reductions over fp32 partial rows (column sums + the finalize arithmetic); use while rows <= kColsumMaxRows
+// one-launch reductions over fp32 partial rows (column sums + the finalize arithmetic); use while rows <= kColsumMaxRows.
+// ColsumScratch: doubles [kMaxChunks][2][round_up(columns, 64)] + one zero-initialised int ticket per 64-column group
+// (kColsumMaxGroups), owned by the plan; launches sharing it must be ordered on one stream.
 constexpr int kColsumMaxRows = 2048;
-int colsum_vec_launch(const float* partial, int rows, int cols, int C, float* out, hipStream_t st);
+constexpr int kColsumMaxGroups = 256;
+struct ColsumScratch {
+  double* sums;
+  int* tickets;
+};
+int colsum_vec_launch(const float* partial, int rows, int cols, int C, float* out, const ColsumScratch& cs, hipStream_t st);
 int bn_fwd_stats_launch(const float* partial, int rows, int cout_pad, int C, int Cp, int64_t count, const float* gamma,
                         const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                        float* invstd, float* scale, float* shift, hipStream_t st);
+                        float* invstd, float* scale, float* shift, const ColsumScratch& cs, hipStream_t st);
 int bn_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int64_t count, int training, float* c1, float* c2,
-                        float* dgamma, float* dbeta, hipStream_t st);
-int head_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int Co, float* dw, float* db, hipStream_t st);
+                        float* dgamma, float* dbeta, const ColsumScratch& cs, hipStream_t st);
+int head_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int Co, float* dw, float* db, const ColsumScratch& cs,
+                          hipStream_t st);
 
 // ---- input / output layout conversion ---------------------------------------------------
 // x NCHW-strided (see mimo_forward_args) -> NHWC [N,H,W,cp] for subnetwork s (zero pad channels)

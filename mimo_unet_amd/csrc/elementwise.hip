@@ -193,31 +193,38 @@ __device__ __forceinline__ void chunk_total2(const double* __restrict__ col_a, c
   *tb = (red[256 + cl] + red[320 + cl]) + (red[384 + cl] + red[448 + cl]);
 }
 
-// ---- one-launch column sums: 1024 threads = 64 columns x 16 row groups walk the fp32 partial rows directly
-// (double accumulation, fixed order: deterministic), so a reduction is ONE launch instead of the rowsum +
-// finalize pair (~150 launches of 4-6 us per step).  The partial tables are small (rows <= 2048, a few hundred
-// KB per 64 columns) and L2-resident right after the kernel that wrote them.
+// ---- one-launch column sums (deterministic): grid = (64-column groups, R row chunks).  Every workgroup (1024
+// threads = 64 columns x 16 row groups) sums its chunk of the fp32 partial rows in double; with R > 1 it parks the
+// chunk totals in a double scratch table and takes a ticket — the LAST workgroup of a column group (ticket R-1)
+// adds the R totals in fixed order and runs the finalize arithmetic.  One launch instead of the rowsum + finalize
+// pair, and no single workgroup walks more than kColsumRowsPerChunk rows.  Tickets are zero on entry and reset by
+// the last workgroup; launches that share a ticket array are ordered on one stream.
 constexpr int kColsumThreads = 1024;
-__device__ __forceinline__ void block_colsum2(const float* __restrict__ partial, int rows, size_t stride, int col_a,
-                                              int col_b, bool valid, bool two, double* red /*[2048]*/, double* ta,
-                                              double* tb) {
+constexpr int kColsumRowsPerChunk = 128;
+static int colsum_chunks(int rows) { return std::max(1, std::min(kMaxChunks, ceil_div(rows, kColsumRowsPerChunk))); }
+
+// returns true in the workgroup that holds the final totals (valid in threads 0..63 of it)
+__device__ __forceinline__ bool grid_colsum2(const float* __restrict__ partial, int rows, size_t stride, int col_a, int col_b,
+                                             bool valid, bool two, double* red /*[2048]*/, double* __restrict__ scratch,
+                                             int scratch_cols, int* __restrict__ tickets, double* ta, double* tb) {
+  const int R = gridDim.y;
+  const int rpc = (rows + R - 1) / R;
+  const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
   const int rg = threadIdx.x >> 6;
   double sa = 0.0, sb = 0.0;
   if (valid) {
     const float* pa = partial + col_a;
     const float* pb = partial + col_b;
-    int r = rg;
-    for (; r + 48 < rows; r += 64) {  // four independent loads in flight per plane
-      const float a0 = pa[(size_t)r * stride], a1 = pa[(size_t)(r + 16) * stride], a2 = pa[(size_t)(r + 32) * stride],
-                  a3 = pa[(size_t)(r + 48) * stride];
-      sa += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    int r = r0 + rg;
+    for (; r + 16 < r1; r += 32) {  // two independent loads in flight per plane
+      const float a0 = pa[(size_t)r * stride], a1 = pa[(size_t)(r + 16) * stride];
+      sa += (double)a0 + (double)a1;
       if (two) {
-        const float b0 = pb[(size_t)r * stride], b1 = pb[(size_t)(r + 16) * stride], b2 = pb[(size_t)(r + 32) * stride],
-                    b3 = pb[(size_t)(r + 48) * stride];
-        sb += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        const float b0 = pb[(size_t)r * stride], b1 = pb[(size_t)(r + 16) * stride];
+        sb += (double)b0 + (double)b1;
       }
     }
-    for (; r < rows; r += 16) {
+    for (; r < r1; r += 16) {
       sa += (double)pa[(size_t)r * stride];
       if (two) sb += (double)pb[(size_t)r * stride];
     }
@@ -228,27 +235,62 @@ __device__ __forceinline__ void block_colsum2(const float* __restrict__ partial,
   __syncthreads();
   const int cl = threadIdx.x & 63;
   double a = 0.0, b = 0.0;
+  if (threadIdx.x < 64) {
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    a += red[k * 64 + cl];
-    b += red[1024 + k * 64 + cl];
+    for (int k = 0; k < 16; ++k) {
+      a += red[k * 64 + cl];
+      b += red[1024 + k * 64 + cl];
+    }
   }
+  if (R == 1) {
+    *ta = a;
+    *tb = b;
+    return true;
+  }
+  // scratch[chunk][plane][column of this group]
+  double* mine = scratch + ((size_t)blockIdx.y * 2) * scratch_cols + (size_t)blockIdx.x * 64;
+  if (threadIdx.x < 64) {
+    mine[cl] = a;
+    mine[scratch_cols + cl] = b;
+  }
+  __threadfence();
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.x], 1) == R - 1;
+  __syncthreads();
+  if (!s_last) return false;
+  __threadfence();
+  if (threadIdx.x < 64) {
+    a = 0.0;
+    b = 0.0;
+    const volatile double* src = scratch + (size_t)blockIdx.x * 64 + cl;
+    for (int k = 0; k < R; ++k) {
+      a += src[((size_t)k * 2) * scratch_cols];
+      b += src[((size_t)k * 2 + 1) * scratch_cols];
+    }
+  }
+  if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
   *ta = a;
   *tb = b;
+  return true;
 }
 
 // out[c] = sum over rows of partial[r][c]  (conv bias gradient)
 __global__ __launch_bounds__(kColsumThreads) void colsum_vec_kernel(const float* __restrict__ partial, int rows, int cols,
-                                                                    int C, float* __restrict__ out) {
+                                                                    int C, float* __restrict__ out,
+                                                                    double* __restrict__ scratch, int scratch_cols,
+                                                                    int* __restrict__ tickets) {
   __shared__ double red[2048];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s, unused;
-  block_colsum2(partial, rows, (size_t)cols, c, c, c < C, false, red, &s, &unused);
+  if (!grid_colsum2(partial, rows, (size_t)cols, c, c, c < C, false, red, scratch, scratch_cols, tickets, &s, &unused)) return;
   if (c < C && threadIdx.x < 64) out[c] = (float)s;
 }
 
-int colsum_vec_launch(const float* partial, int rows, int cols, int C, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_vec_kernel, dim3(ceil_div(C, 64)), dim3(kColsumThreads), 0, st, partial, rows, cols, C, out);
+int colsum_vec_launch(const float* partial, int rows, int cols, int C, float* out, const ColsumScratch& cs, hipStream_t st) {
+  const int groups = ceil_div(C, 64);
+  hipLaunchKernelGGL(colsum_vec_kernel, dim3(groups, colsum_chunks(rows)), dim3(kColsumThreads), 0, st, partial, rows, cols, C,
+                     out, cs.sums, groups * 64, cs.tickets);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -354,11 +396,14 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ sums, int chun
 __global__ __launch_bounds__(kColsumThreads) void bn_fwd_stats_kernel(
     const float* __restrict__ partial, int rows, int cout_pad, int C, int Cp, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-    float eps, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+    float eps, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+    double* __restrict__ scratch, int scratch_cols, int* __restrict__ tickets) {
   __shared__ double red[2048];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s1, s2;
-  block_colsum2(partial, rows, (size_t)2 * cout_pad, c, cout_pad + c, c < C, true, red, &s1, &s2);
+  if (!grid_colsum2(partial, rows, (size_t)2 * cout_pad, c, cout_pad + c, c < C, true, red, scratch, scratch_cols, tickets, &s1,
+                    &s2))
+    return;
   if (c >= Cp || threadIdx.x >= 64) return;
   if (c >= C) {
     mean[c] = 0.f;
@@ -383,9 +428,11 @@ __global__ __launch_bounds__(kColsumThreads) void bn_fwd_stats_kernel(
 
 int bn_fwd_stats_launch(const float* partial, int rows, int cout_pad, int C, int Cp, int64_t count, const float* gamma,
                         const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                        float* invstd, float* scale, float* shift, hipStream_t st) {
-  hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(ceil_div(Cp, 64)), dim3(kColsumThreads), 0, st, partial, rows, cout_pad, C, Cp,
-                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                        float* invstd, float* scale, float* shift, const ColsumScratch& cs, hipStream_t st) {
+  const int groups = ceil_div(Cp, 64);
+  hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(groups, colsum_chunks(rows)), dim3(kColsumThreads), 0, st, partial, rows,
+                     cout_pad, C, Cp, (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
+                     shift, cs.sums, groups * 64, cs.tickets);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -950,11 +997,13 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int chun
 __global__ __launch_bounds__(kColsumThreads) void bn_bwd_stats_kernel(const float* __restrict__ partial, int rows, int C,
                                                                       int Cp, double count, int training,
                                                                       float* __restrict__ c1, float* __restrict__ c2,
-                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                      double* __restrict__ scratch, int scratch_cols,
+                                                                      int* __restrict__ tickets) {
   __shared__ double red[2048];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s1, s2;
-  block_colsum2(partial, rows, (size_t)2 * Cp, c, Cp + c, c < Cp, true, red, &s1, &s2);
+  if (!grid_colsum2(partial, rows, (size_t)2 * Cp, c, Cp + c, c < Cp, true, red, scratch, scratch_cols, tickets, &s1, &s2)) return;
   if (c >= Cp || threadIdx.x >= 64) return;
   c1[c] = training ? (float)(s1 / count) : 0.f;
   c2[c] = training ? (float)(s2 / count) : 0.f;
@@ -965,9 +1014,10 @@ __global__ __launch_bounds__(kColsumThreads) void bn_bwd_stats_kernel(const floa
 }
 
 int bn_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int64_t count, int training, float* c1, float* c2,
-                        float* dgamma, float* dbeta, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(ceil_div(Cp, 64)), dim3(kColsumThreads), 0, st, partial, rows, C, Cp,
-                     (double)count, training, c1, c2, dgamma, dbeta);
+                        float* dgamma, float* dbeta, const ColsumScratch& cs, hipStream_t st) {
+  const int groups = ceil_div(Cp, 64);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(groups, colsum_chunks(rows)), dim3(kColsumThreads), 0, st, partial, rows, C, Cp,
+                     (double)count, training, c1, c2, dgamma, dbeta, cs.sums, groups * 64, cs.tickets);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1330,12 +1380,13 @@ __global__ void head_bwd_finalize_kernel(const double* __restrict__ sums, int ch
 // rowsum + head_bwd_finalize in one launch: partial rows [rows][Co*Cp + Co] from head_bwd
 __global__ __launch_bounds__(kColsumThreads) void head_bwd_stats_kernel(const float* __restrict__ partial, int rows, int C,
                                                                         int Cp, int Co, float* __restrict__ dw,
-                                                                        float* __restrict__ db) {
+                                                                        float* __restrict__ db, double* __restrict__ scratch,
+                                                                        int scratch_cols, int* __restrict__ tickets) {
   __shared__ double red[2048];
   const int cols = Co * Cp + Co;
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
   double s, unused;
-  block_colsum2(partial, rows, (size_t)cols, i, i, i < cols, false, red, &s, &unused);
+  if (!grid_colsum2(partial, rows, (size_t)cols, i, i, i < cols, false, red, scratch, scratch_cols, tickets, &s, &unused)) return;
   if (i >= cols || threadIdx.x >= 64) return;
   if (i < Co * Cp) {
     const int co = i / Cp, c = i - co * Cp;
@@ -1345,9 +1396,11 @@ __global__ __launch_bounds__(kColsumThreads) void head_bwd_stats_kernel(const fl
   }
 }
 
-int head_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int Co, float* dw, float* db, hipStream_t st) {
-  hipLaunchKernelGGL(head_bwd_stats_kernel, dim3(ceil_div(Co * Cp + Co, 64)), dim3(kColsumThreads), 0, st, partial, rows, C, Cp,
-                     Co, dw, db);
+int head_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int Co, float* dw, float* db, const ColsumScratch& cs,
+                          hipStream_t st) {
+  const int groups = ceil_div(Co * Cp + Co, 64);
+  hipLaunchKernelGGL(head_bwd_stats_kernel, dim3(groups, colsum_chunks(rows)), dim3(kColsumThreads), 0, st, partial, rows, C, Cp,
+                     Co, dw, db, cs.sums, groups * 64, cs.tickets);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

@@ -132,6 +132,8 @@ struct mimo_plan {
   float *s_dz = nullptr, *s_dxpadA = nullptr, *s_dxpadB = nullptr, *s_wslab = nullptr,
         *s_partial = nullptr, *s_losspart = nullptr;
   double* s_sums = nullptr;
+  int* s_tickets = nullptr;  // colsum tickets of the scratch set in use (zero between launches)
+  ColsumScratch colsum() const { return ColsumScratch{s_sums, s_tickets}; }
   size_t cap_act = 0, cap_pad = 0, cap_slab = 0, cap_partial = 0, cap_sums = 0;
 
   // MIMO_WGRAD_STREAM=1: weight gradients on a side stream — wgrad(L) (matrix-pipe bound, little HBM
@@ -222,6 +224,29 @@ struct mimo_plan {
   hipStream_t cap_stream = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   uint64_t graph_key = 0;
+  // hipGraph replay of the TRAINING step (MIMO_TRAIN_GRAPH, default on): one graph for the training forward, one per
+  // backward stage (~330 launches per step otherwise — at the 4 images per GPU of an 8-way strong-scaling run the
+  // step is launch-bound).  Same staging scheme: the captured kernels read plan-owned copies of image / permutation /
+  // Dropout2d masks / label / loss mask / dloss and write the plan-owned logits buffer.
+  struct GraphSlot {
+    hipGraphExec_t exec = nullptr;
+    uint64_t key = 0;
+  };
+  static constexpr int kBwdStagesDecl = 8;
+  bool train_graph = true;
+  GraphSlot tg_fwd, tg_bwd[kBwdStagesDecl];
+  bool staged_train = false;  // the last forward was a staged (graph) training forward
+  uint64_t staged_key = 0;
+  float *g_label = nullptr, *g_lmask = nullptr, *g_dloss = nullptr;
+  int64_t g_rows = 0;  // batch rows of the caller's image / label / mask tensors in the last staged forward
+  void drop_graphs() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    graph_exec = nullptr;
+    for (GraphSlot* g : {&tg_fwd, &tg_bwd[0], &tg_bwd[1], &tg_bwd[2], &tg_bwd[3], &tg_bwd[4], &tg_bwd[5], &tg_bwd[6], &tg_bwd[7]}) {
+      if (g->exec) (void)hipGraphExecDestroy(g->exec);
+      g->exec = nullptr;
+    }
+  }
   float *g_x = nullptr, *g_out = nullptr;
   int64_t* g_perm = nullptr;
   std::vector<float*> g_masks;
@@ -238,6 +263,7 @@ struct mimo_plan {
   hipEvent_t sub_fork = nullptr;
   std::vector<float*> set_partial;            // [S] forward partial-statistics rows
   std::vector<double*> set_sums;              // [S]
+  std::vector<int*> set_tickets;              // [S]
 
   // weight repack job tables (device): [0, n_fwd_jobs) forward packs (+ bias copies), then the data-gradient packs
   PackJob* pack_jobs = nullptr;
@@ -266,7 +292,7 @@ struct mimo_plan {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
     }
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    drop_graphs();
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     if (wg_stream) (void)hipStreamDestroy(wg_stream);
     for (hipStream_t t : sub_streams)
@@ -386,7 +412,7 @@ struct mimo_plan {
     const size_t stat_rows = std::max(conv3x3_stat_rows(n, h, w), conv3x3_ws_stat_rows(n, h, w));
     cap_partial = std::max(cap_partial, stat_rows * 2 * L.cout_pad);
     cap_partial = std::max(cap_partial, (size_t)kBnReduceMaxBlocks * 2 * L.cout_p);
-    cap_sums = std::max(cap_sums, (size_t)kMaxChunks * 2 * std::max(L.cout_pad, L.cout_p));
+    cap_sums = std::max(cap_sums, (size_t)kMaxChunks * 2 * round_up(std::max(L.cout_pad, L.cout_p), 64));
     return MIMO_OK;
   }
 
@@ -596,7 +622,7 @@ struct mimo_plan {
     // ---- scratch ----
     const int fp = pad_channels(f);
     cap_partial = std::max(cap_partial, (size_t)kEwMaxBlocks * (Co * fp + Co));
-    cap_sums = std::max(cap_sums, (size_t)kMaxChunks * (Co * fp + Co));
+    cap_sums = std::max(cap_sums, (size_t)kMaxChunks * 2 * round_up(Co * fp + Co, 64));
     if (cfg.inference_only) cap_act = cap_pad = cap_slab = 1;  // backward scratch: never touched
     MIMO_TRY(dalloc(&s_dz, cap_act));
     {
@@ -621,11 +647,13 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&s_wslab, cap_slab));
     MIMO_TRY(dalloc(&s_partial, cap_partial));
     MIMO_TRY(dalloc(&s_sums, cap_sums));
+    MIMO_TRY(dalloc(&s_tickets, kColsumMaxGroups));
     {
       const char* se = getenv("MIMO_SUBNET_STREAMS");
       subnet_streams = se && atoi(se) != 0 && S > 1;
       set_partial.assign(S, s_partial);
       set_sums.assign(S, s_sums);
+      set_tickets.assign(S, s_tickets);
       sub_streams.assign(S, nullptr);
       sub_join.assign(S, nullptr);
       if (subnet_streams) {
@@ -633,6 +661,7 @@ struct mimo_plan {
         for (int i = 1; i < S; ++i) {
           MIMO_TRY(dalloc(&set_partial[i], cap_partial));
           MIMO_TRY(dalloc(&set_sums[i], cap_sums));
+          MIMO_TRY(dalloc(&set_tickets[i], kColsumMaxGroups));
           MIMO_HIP_CHECK(hipStreamCreateWithFlags(&sub_streams[i], hipStreamNonBlocking));
           MIMO_HIP_CHECK(hipEventCreateWithFlags(&sub_join[i], hipEventDisableTiming));
         }
@@ -688,6 +717,15 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&g_x, (size_t)N * S * Ci * H * W));
     MIMO_TRY(dalloc(&g_out, (size_t)N * S * Co * H * W));
     MIMO_TRY(dalloc(&g_perm, (size_t)S * N));
+    {
+      const char* te = getenv("MIMO_TRAIN_GRAPH");
+      train_graph = graph_enabled && !(te && atoi(te) == 0) && !cfg.inference_only && !wg_async && !subnet_streams;
+      if (train_graph) {
+        MIMO_TRY(dalloc(&g_label, (size_t)N * (Co / 2) * H * W));
+        MIMO_TRY(dalloc(&g_lmask, (size_t)N * H * W));
+        MIMO_TRY(dalloc(&g_dloss, (size_t)S));
+      }
+    }
     g_masks.resize(dcs.size());
     g_mask_ptrs.assign(dcs.size(), nullptr);
     for (size_t i = 0; i < dcs.size(); ++i) MIMO_TRY(dalloc(&g_masks[i], (size_t)N * dcs[i]->c2.Cout));
@@ -741,7 +779,7 @@ struct mimo_plan {
       if (rows <= kColsumMaxRows) {
         MIMO_TRY(bn_fwd_stats_launch(s_partial, rows, L.cout_pad, L.Cout, L.cout_p, P, params + L.off_gamma,
                                      params + L.off_beta, bnbuf + L.off_rm, bnbuf + L.off_rv, cfg.bn_momentum, cfg.bn_eps,
-                                     L.mean, L.invstd, L.scale, L.shift, st));
+                                     L.mean, L.invstd, L.scale, L.shift, colsum(), st));
       } else {
         int chunks = 0;
         MIMO_TRY(rowsum_launch(s_partial, rows, 2 * L.cout_pad, s_sums, &chunks, st));
@@ -805,16 +843,19 @@ struct mimo_plan {
     const int64_t img = (int64_t)Ci * H * W;
     const bool x5 = args->stride_s == img && args->stride_n == (int64_t)S * img;
     const bool x4 = args->stride_s == 0 && args->stride_n == img;
-    if (!graph_enabled || args->training || prof_on || !(x5 || x4) || args->elem_masks || need_derive) {
+    const int64_t rows = args->x_rows > 0 ? args->x_rows : N;
+    const bool tgraph = train_graph && training_call && !prof_on && (x5 || x4) && !args->elem_masks && rows <= N;
+    staged_train = false;
+    if (!tgraph && (!graph_enabled || training_call || prof_on || !(x5 || x4) || args->elem_masks || need_derive || rows > N)) {
       const int rc = forward_impl(args, st);
       derived_version = rc == MIMO_OK ? version_after : -1;
       return rc;
     }
     // ---- stage the caller's tensors, (re)capture if the call shape changed, replay ----
-    uint64_t key = 1 | (x5 ? 2 : 0) | (args->perm ? 4 : 0) | (fwd_no_grad ? 8 : 0);
+    uint64_t key = 1 | (x5 ? 2 : 0) | (args->perm ? 4 : 0) | (fwd_no_grad ? 8 : 0) | (training_call ? 16 : 0);
     for (size_t i = 0; i < dcs.size(); ++i)
       if (args->drop_masks && args->drop_masks[i]) key |= 1ull << (8 + i);
-    MIMO_HIP_CHECK(hipMemcpyAsync(g_x, args->x, (size_t)N * (x5 ? S : 1) * img * sizeof(float), hipMemcpyDeviceToDevice, st));
+    MIMO_HIP_CHECK(hipMemcpyAsync(g_x, args->x, (size_t)rows * (x5 ? S : 1) * img * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (args->perm)
       MIMO_HIP_CHECK(hipMemcpyAsync(g_perm, args->perm, (size_t)S * N * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
     for (size_t i = 0; i < dcs.size(); ++i) {
@@ -824,41 +865,57 @@ struct mimo_plan {
         MIMO_HIP_CHECK(hipMemcpyAsync(g_masks[i], args->drop_masks[i], (size_t)N * dcs[i]->c2.Cout * sizeof(float),
                                       hipMemcpyDeviceToDevice, st));
     }
-    if (!graph_exec || key != graph_key) {
-      if (graph_exec) {
-        (void)hipGraphExecDestroy(graph_exec);
-        graph_exec = nullptr;
+    hipGraphExec_t* exec = tgraph ? &tg_fwd.exec : &graph_exec;
+    uint64_t* ekey = tgraph ? &tg_fwd.key : &graph_key;
+    if (!*exec || key != *ekey) {
+      if (*exec) {
+        (void)hipGraphExecDestroy(*exec);
+        *exec = nullptr;
       }
       mimo_forward_args ga = *args;
       ga.x = g_x;
       ga.perm = args->perm ? g_perm : nullptr;
       ga.drop_masks = args->drop_masks ? g_mask_ptrs.data() : nullptr;
       ga.out = g_out;
-      MIMO_HIP_CHECK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
-      capturing = true;
-      const int rc = forward_impl(&ga, cap_stream);
-      capturing = false;
-      hipGraph_t graph = nullptr;
-      const hipError_t ce = hipStreamEndCapture(cap_stream, &graph);
-      if (rc != MIMO_OK) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc;
-      }
-      MIMO_HIP_CHECK(ce);
-      const hipError_t ie = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      MIMO_HIP_CHECK(ie);
-      graph_key = key;
+      MIMO_TRY(capture([&](hipStream_t cs) { return forward_impl(&ga, cs); }, exec));
+      *ekey = key;
     }
     elem_masks.clear();
-    MIMO_HIP_CHECK(hipGraphLaunch(graph_exec, st));
+    MIMO_HIP_CHECK(hipGraphLaunch(*exec, st));
     MIMO_HIP_CHECK(hipMemcpyAsync(args->out, g_out, (size_t)N * S * Co * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
-    for (size_t i = 0; i < dcs.size(); ++i) dcs[i]->mask = args->drop_masks ? args->drop_masks[i] : nullptr;
-    out = args->out;
+    // what a later backward / loss reads: the staged copies for a training graph (the backward graphs hold those
+    // pointers), the caller's tensors otherwise
+    for (size_t i = 0; i < dcs.size(); ++i)
+      dcs[i]->mask = tgraph ? g_mask_ptrs[i] : (args->drop_masks ? args->drop_masks[i] : nullptr);
+    out = tgraph ? g_out : args->out;
     fwd_done = true;
-    fwd_training = false;
+    fwd_training = training_call;
     had_perm = args->perm != nullptr;
     loss_done = false;
+    staged_train = tgraph;
+    staged_key = key;
+    g_rows = rows;
+    derived_version = version_after;  // -1 after a training forward: the optimiser step invalidates the packed weights
+    return MIMO_OK;
+  }
+
+  // run `body` under stream capture on cap_stream and instantiate the resulting graph
+  template <typename F>
+  int capture(F body, hipGraphExec_t* exec) {
+    MIMO_HIP_CHECK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+    capturing = true;
+    const int rc = body(cap_stream);
+    capturing = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(cap_stream, &graph);
+    if (rc != MIMO_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    MIMO_HIP_CHECK(ce);
+    const hipError_t ie = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    MIMO_HIP_CHECK(ie);
     return MIMO_OK;
   }
 
@@ -872,6 +929,7 @@ struct mimo_plan {
   hipStream_t chain_stream(bool fork, int s, hipStream_t st) {
     s_partial = set_partial[fork ? s : 0];
     s_sums = set_sums[fork ? s : 0];
+    s_tickets = set_tickets[fork ? s : 0];
     return fork && s > 0 ? sub_streams[s] : st;
   }
   int join_streams(hipStream_t st) {
@@ -881,6 +939,7 @@ struct mimo_plan {
     }
     s_partial = set_partial[0];
     s_sums = set_sums[0];
+    s_tickets = set_tickets[0];
     return MIMO_OK;
   }
 
@@ -953,6 +1012,19 @@ struct mimo_plan {
       set_error("mimo_loss_forward: null argument");
       return MIMO_ERR_INVALID;
     }
+    if (staged_train) {
+      // the backward graphs read plan-owned copies (the caller's label / mask tensors move from step to step); perm_
+      // is the permutation of the forward, staged there
+      if ((perm_ != nullptr) != had_perm) {
+        set_error("mimo_loss_forward: permutation given to exactly one of forward / loss");
+        return MIMO_ERR_INVALID;
+      }
+      MIMO_HIP_CHECK(hipMemcpyAsync(g_label, label_, (size_t)g_rows * (Co / 2) * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (mask_) MIMO_HIP_CHECK(hipMemcpyAsync(g_lmask, mask_, (size_t)g_rows * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
+      label_ = g_label;
+      mask_ = mask_ ? g_lmask : nullptr;
+      perm_ = perm_ ? g_perm : nullptr;
+    }
     int blocks = 0;
     MIMO_TRY(loss_fwd_launch(out, label_, mask_, perm_, N, S, Co, H * W, cfg.loss_kind, cfg.eps_min, cfg.eps_max,
                              s_losspart, &blocks, st));
@@ -977,7 +1049,7 @@ struct mimo_plan {
                                       mask, L.Cout, L.cout_p, L.N, L.H, L.W, s_partial, &rows, st));
     prof_end(pr, 0.0, 8.0 * (double)P * L.cout_p, st);
     MIMO_TRY(bn_bwd_stats_launch(s_partial, rows, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
-                                 grads + L.off_gamma, grads + L.off_beta, st));
+                                 grads + L.off_gamma, grads + L.off_beta, colsum(), st));
     const int b = dz_idx;
     float* dz = s_dz2[b];
     if (wg_async) {
@@ -998,7 +1070,7 @@ struct mimo_plan {
     // wgrad(L) may start as soon as dz exists, next to dgrad(L) (releasing it only after dgrad(L), i.e. next
     // to the bandwidth-bound kernels of the layer below, measured the same step time)
     if (wg_async) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
-    MIMO_TRY(colsum_vec_launch(s_partial, rows, L.cout_p, L.Cout, grads + L.off_b, st));
+    MIMO_TRY(colsum_vec_launch(s_partial, rows, L.cout_p, L.Cout, grads + L.off_b, colsum(), st));
     if (need_dgrad) {
       ConvLaunch a;
       a.x = dz;
@@ -1111,7 +1183,7 @@ struct mimo_plan {
   // flat gradient buffer (laid out encoder | core down2..up3 | decoder | heads), final when the stage returns, so a
   // data-parallel caller can start that range's all-reduce while the later stages run:
   //   0 heads + decoders (up4)   1 up3   2 up2   3 up1   4 down4   5 down3   6 down2   7 encoders (+ dx)
-  static constexpr int kBwdStages = 8;
+  static constexpr int kBwdStages = kBwdStagesDecl;
   void stage_range(int stage, int64_t* b, int64_t* e) const {
     DoubleConv* core[6] = {up3, up2, up1, down4, down3, down2};
     if (stage == 0) {
@@ -1159,7 +1231,33 @@ struct mimo_plan {
       set_error("mimo_backward: stage %d requested, stage %d is next", stage_first, bwd_next_stage);
       return MIMO_ERR_STATE;
     }
-    for (int stage = stage_first; stage <= stage_last; ++stage) MIMO_TRY(backward_stage(stage, dout, dloss, dx, st));
+    const bool tgraph = staged_train && train_graph && !prof_on && dloss && !dout && !dx && loss_done;
+    if (tgraph) {
+      if (stage_first == 0)
+        MIMO_HIP_CHECK(hipMemcpyAsync(g_dloss, dloss, (size_t)S * sizeof(float), hipMemcpyDeviceToDevice, st));
+      const uint64_t key = staged_key | (lmask ? 1ull << 40 : 0);
+      // the stages are captured together, in order: the host-side bookkeeping that shapes the kernel arguments
+      // (first-writer / accumulate flags, skip-gradient hand-over) runs at capture time only
+      if (stage_first == 0 && (!tg_bwd[0].exec || tg_bwd[0].key != key))
+        for (GraphSlot& g : tg_bwd) {
+          if (g.exec) (void)hipGraphExecDestroy(g.exec);
+          g.exec = nullptr;
+        }
+      for (int stage = stage_first; stage <= stage_last; ++stage) {
+        GraphSlot& g = tg_bwd[stage];
+        if (!g.exec || g.key != key) {
+          if (g.exec) {
+            (void)hipGraphExecDestroy(g.exec);
+            g.exec = nullptr;
+          }
+          MIMO_TRY(capture([&](hipStream_t cs) { return backward_stage(stage, nullptr, g_dloss, nullptr, cs); }, &g.exec));
+          g.key = key;
+        }
+        MIMO_HIP_CHECK(hipGraphLaunch(g.exec, st));
+      }
+    } else {
+      for (int stage = stage_first; stage <= stage_last; ++stage) MIMO_TRY(backward_stage(stage, dout, dloss, dx, st));
+    }
     bwd_next_stage = stage_last + 1 < kBwdStages ? stage_last + 1 : 0;
     return wg_join(st);  // the gradients of the stages run so far are final for the caller (all-reduce)
   }
@@ -1186,7 +1284,7 @@ struct mimo_plan {
                                    label, lmask, lperm, cfg.loss_kind, cfg.eps_min, cfg.eps_max, dc->out.da, s_partial, &rows,
                                    st));
           prof_end(pr, 0.0, 4.0 * (double)N * H * W * (2.0 * fp + Co + Co / 2), st);
-          MIMO_TRY(head_bwd_stats_launch(s_partial, rows, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, st));
+          MIMO_TRY(head_bwd_stats_launch(s_partial, rows, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, colsum(), st));
           if (!elem_masks.empty() && elem_masks[1 + s])
             MIMO_TRY(elem_mask_mul_launch(dc->out.da, dc->out.ldda, elem_masks[1 + s], N, dc->out.C, dc->out.Cp, H * W, st));
           prof_end(blk, 0.0, 0.0, st);
@@ -1276,11 +1374,9 @@ int mimo_plan_bind(mimo_plan* plan, float* params, float* grads, float* bn_buffe
   }
   if (plan->params != params || plan->bnbuf != bn_buffers) {
     plan->derived_version = -1;  // other tensors: re-derive
-    if (plan->graph_exec) {      // the captured head kernels hold the old parameter pointer
-      (void)hipGraphExecDestroy(plan->graph_exec);
-      plan->graph_exec = nullptr;
-    }
+    plan->drop_graphs();         // the captured kernels hold the old parameter pointers
   }
+  if (plan->grads != grads) plan->drop_graphs();
   plan->params = params;
   plan->grads = grads;
   plan->bnbuf = bn_buffers;

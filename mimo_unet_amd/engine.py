@@ -137,7 +137,7 @@ class Plan:
         args = L.ForwardArgs(x.data_ptr(), stride_n, stride_s, L.ptr(perm) or None, int(training),
                              C.cast(mask_arr, C.POINTER(C.c_void_p)) if mask_arr is not None else None, out.data_ptr(),
                              C.cast(elem_arr, C.POINTER(C.c_void_p)) if elem_arr is not None else None,
-                             int(bool(no_grad) and not training), int(param_version))
+                             int(bool(no_grad) and not training), int(param_version), int(x.shape[0]))
         L.check(self.lib.mimo_forward(self.handle, C.byref(args), L.current_stream()), "mimo_forward")
 
     def loss_forward(self, label: torch.Tensor, mask: Optional[torch.Tensor], perm: Optional[torch.Tensor],

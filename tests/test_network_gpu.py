@@ -545,6 +545,46 @@ def test_inference_path_matches_eval_forward_and_tracks_parameter_changes():
     assert torch.isfinite(xg.grad).all()
 
 
+@pytest.mark.parametrize("staged", [False, True])
+def test_training_step_graph_replay_is_bit_identical_to_eager(staged, monkeypatch):
+    """MIMO_TRAIN_GRAPH (default on): the training forward and every backward stage are hipGraph replays reading
+    plan-owned copies of image / permutation / Dropout2d masks / label / loss mask / dloss.  Four optimiser steps
+    with data, masks and permutations that change every step (and move in memory) give bit-identical logits,
+    losses, gradients and parameters to the eager launch sequence; also through the staged (data-parallel) backward."""
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    S, N = cfg.num_subnetworks, 3
+    results = []
+    for graph in ("0", "1"):
+        monkeypatch.setenv("MIMO_TRAIN_GRAPH", graph)  # read when the plan is created
+        model = build_model(cfg, state_from(fx, "init/"), dropout=(0.2, 0.2, 0.2))
+        model.train()
+        if staged:
+            model.model.grad_ready_hook = lambda flat, b, e: None
+        opt = model.configure_optimizers()["optimizer"]
+        g = torch.Generator().manual_seed(9)
+        torch.manual_seed(9)
+        torch.cuda.manual_seed(9)  # the module's own Dropout2d draws
+        rec, keep = [], []
+        for it in range(4):
+            image = torch.rand(N, cfg.in_channels, 32, 32, generator=g).cuda()
+            label = torch.rand(N, 1, 32, 32, generator=g).cuda()
+            mask = (torch.rand(N, 1, 32, 32, generator=g) > 0.3).float().cuda()
+            perms = O.draw_perms(N, S, generator=g).cuda()
+            keep.append((image, label, mask, perms))  # fresh allocations every step: the caller's tensors move
+            opt.zero_grad()
+            out = model.training_step_with_perms(image, label, mask, perms)
+            out["loss"].backward()
+            rec.append((out["loss"].detach().clone(), out["preds"].clone(), model.model.flat_gradients().clone()))
+            opt.step()
+        rec.append(model.model.flat_parameters().clone())
+        results.append(rec)
+    for a, b in zip(results[0][:-1], results[1][:-1]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(results[0][-1], results[1][-1])
+    assert torch.isfinite(results[1][-1]).all()
+
+
 def test_inference_cache_is_invalidated_by_load_state_dict_alone():
     """no_grad forward, load_state_dict, no_grad forward — with NO grad-enabled call in between (which would reset
     the cache by itself): the second forward must use the new weights, also for in-place parameter writes torch
