@@ -373,8 +373,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
 //   tile = 256 output pixels (4 consumers x 4 fragments of 16 pixels) x NF*16 output channels
 //   LDS  = 2 input tiles (360 x 144 B) + 2 weight tap rows (3 x NB x 144 B) <= 159 KB
 //   one workgroup barrier per phase (tap row of a 32-channel chunk)
-// BatchNorm partial sums: accumulated in registers over the workgroup's tiles, one row per (workgroup,
-// consumer wave) — no cross-wave LDS reduction, 4 x gridDim.x rows for the column reduction that follows.
+// BatchNorm partial sums: accumulated in registers over the workgroup's tiles, the four consumer waves combined
+// through LDS once at the end: one row per workgroup for the column reduction that follows.
 // ---------------------------------------------------------------------------------------
 // MF = fragments of 16 pixels per consumer wave.  4: 256-pixel tiles, one workgroup per CU.  2: 128-pixel tiles
 // (180-pixel halo); with NF <= 2 the workgroup needs 79 KB of LDS and 128 registers per lane, so TWO workgroups
@@ -575,6 +575,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #undef WS_STORE_X
 #undef WS_LOAD_W
 #undef WS_STORE_W
+    if (CVT && a.stats) __syncthreads();  // the consumers combine their BatchNorm sums through LDS (see the end)
     return;
   }
 
@@ -771,8 +772,11 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     C_MFMA(1, 0, MF - 1)
   }
   C_EPILOGUE(ti)
+  __syncthreads();  // matches the producers' last barrier: their (dead) LDS stores are done
   if (CVT && a.stats) {
-    const size_t row = ((size_t)vbx * 4 + wave) * 2;
+    // one partial-statistics row per workgroup: the four consumer waves add their sums through LDS (4 x fewer rows
+    // for the column reduction that follows)
+    float* red = reinterpret_cast<float*>(xs);  // [4 waves][2][NB]
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
@@ -784,12 +788,18 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
         }
       }
       if (lr == 0) {
-        *reinterpret_cast<f32x4*>(a.stats + (row + 0) * a.cout_pad + co0 + nf * 16 + g * 4) = s1[nf];
-        *reinterpret_cast<f32x4*>(a.stats + (row + 1) * a.cout_pad + co0 + nf * 16 + g * 4) = s2[nf];
+        *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * NB + nf * 16 + g * 4) = s1[nf];
+        *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * NB + nf * 16 + g * 4) = s2[nf];
       }
     }
+    __syncthreads();  // second extra barrier, also executed by the producers
+    if (tid < 2 * NB) {
+      const int which = tid / NB, c = tid - which * NB;
+      const float v = (red[(0 * 2 + which) * NB + c] + red[(1 * 2 + which) * NB + c]) +
+                      (red[(2 * 2 + which) * NB + c] + red[(3 * 2 + which) * NB + c]);
+      a.stats[((size_t)vbx * 2 + which) * a.cout_pad + co0 + c] = v;
+    }
   }
-  __syncthreads();  // matches the producers' last barrier
 #undef C_READ_A
 #undef C_READ_B
 #undef C_TAP
@@ -820,7 +830,7 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   if (gx > numTiles) gx = numTiles;
   const int per = ceil_div(numTiles, gx);
   gx = ceil_div(numTiles, per);
-  if (rows) *rows = gx * 4;  // one partial-statistics row per (workgroup, consumer wave)
+  if (rows) *rows = gx;  // one partial-statistics row per workgroup
   dim3 grid(gx * coTiles);
   // conflict-free swizzled rows measured the same step time as the padded rows (6.97 / 7.20 vs 6.89 / 7.20 ms
   // forward / data gradient per step): the LDS array is not what the consumers wait for.  Opt-in.

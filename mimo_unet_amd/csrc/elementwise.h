@@ -28,7 +28,7 @@ int bn_fwd_stats_launch(const float* partial, int rows, int cout_pad, int C, int
                         const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
                         float* invstd, float* scale, float* shift, const ColsumScratch& cs, hipStream_t st);
 int bn_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int64_t count, int training, float* c1, float* c2,
-                        float* dgamma, float* dbeta, const ColsumScratch& cs, hipStream_t st);
+                        float* dgamma, float* dbeta, float* dbias_zero, const ColsumScratch& cs, hipStream_t st);
 int head_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int Co, float* dw, float* db, const ColsumScratch& cs,
                           hipStream_t st);
 

@@ -193,38 +193,44 @@ __device__ __forceinline__ void chunk_total2(const double* __restrict__ col_a, c
   *tb = (red[256 + cl] + red[320 + cl]) + (red[384 + cl] + red[448 + cl]);
 }
 
-// ---- one-launch column sums (deterministic): grid = (64-column groups, R row chunks).  Every workgroup (1024
-// threads = 64 columns x 16 row groups) sums its chunk of the fp32 partial rows in double; with R > 1 it parks the
-// chunk totals in a double scratch table and takes a ticket — the LAST workgroup of a column group (ticket R-1)
-// adds the R totals in fixed order and runs the finalize arithmetic.  One launch instead of the rowsum + finalize
-// pair, and no single workgroup walks more than kColsumRowsPerChunk rows.  Tickets are zero on entry and reset by
-// the last workgroup; launches that share a ticket array are ordered on one stream.
+// ---- one-launch column sums (deterministic): one workgroup of 1024 threads = 64 columns x 16 row groups walks the
+// fp32 partial rows of its 64 columns in double, eight independent loads in flight per thread, then runs the
+// finalize arithmetic — one launch instead of the rowsum + finalize pair.  (Spreading the rows over several
+// workgroups with a last-workgroup ticket was measured SLOWER, 24 vs 13 us: the device-scope fence it needs writes
+// back / invalidates the whole L2 on this multi-XCD part.)  `scratch` / `tickets` are unused, kept for the signature.
 constexpr int kColsumThreads = 1024;
-constexpr int kColsumRowsPerChunk = 128;
-static int colsum_chunks(int rows) { return std::max(1, std::min(kMaxChunks, ceil_div(rows, kColsumRowsPerChunk))); }
+static int colsum_chunks(int) { return 1; }
 
-// returns true in the workgroup that holds the final totals (valid in threads 0..63 of it)
 __device__ __forceinline__ bool grid_colsum2(const float* __restrict__ partial, int rows, size_t stride, int col_a, int col_b,
-                                             bool valid, bool two, double* red /*[2048]*/, double* __restrict__ scratch,
-                                             int scratch_cols, int* __restrict__ tickets, double* ta, double* tb) {
-  const int R = gridDim.y;
-  const int rpc = (rows + R - 1) / R;
-  const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+                                             bool valid, bool two, double* red /*[2048]*/, double* __restrict__, int,
+                                             int* __restrict__, double* ta, double* tb) {
   const int rg = threadIdx.x >> 6;
   double sa = 0.0, sb = 0.0;
   if (valid) {
     const float* pa = partial + col_a;
     const float* pb = partial + col_b;
-    int r = r0 + rg;
-    for (; r + 16 < r1; r += 32) {  // two independent loads in flight per plane
-      const float a0 = pa[(size_t)r * stride], a1 = pa[(size_t)(r + 16) * stride];
-      sa += (double)a0 + (double)a1;
-      if (two) {
-        const float b0 = pb[(size_t)r * stride], b1 = pb[(size_t)(r + 16) * stride];
-        sb += (double)b0 + (double)b1;
+    int r = rg;
+    if (two) {
+      for (; r + 48 < rows; r += 64) {
+        float a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          a[k] = pa[(size_t)(r + 16 * k) * stride];
+          b[k] = pb[(size_t)(r + 16 * k) * stride];
+        }
+        sa += ((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3]);
+        sb += ((double)b[0] + (double)b[1]) + ((double)b[2] + (double)b[3]);
+      }
+    } else {
+      for (; r + 112 < rows; r += 128) {
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = pa[(size_t)(r + 16 * k) * stride];
+        sa += (((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) +
+              (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]));
       }
     }
-    for (; r < r1; r += 16) {
+    for (; r < rows; r += 16) {
       sa += (double)pa[(size_t)r * stride];
       if (two) sb += (double)pb[(size_t)r * stride];
     }
@@ -242,34 +248,6 @@ __device__ __forceinline__ bool grid_colsum2(const float* __restrict__ partial, 
       b += red[1024 + k * 64 + cl];
     }
   }
-  if (R == 1) {
-    *ta = a;
-    *tb = b;
-    return true;
-  }
-  // scratch[chunk][plane][column of this group]
-  double* mine = scratch + ((size_t)blockIdx.y * 2) * scratch_cols + (size_t)blockIdx.x * 64;
-  if (threadIdx.x < 64) {
-    mine[cl] = a;
-    mine[scratch_cols + cl] = b;
-  }
-  __threadfence();
-  __shared__ int s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.x], 1) == R - 1;
-  __syncthreads();
-  if (!s_last) return false;
-  __threadfence();
-  if (threadIdx.x < 64) {
-    a = 0.0;
-    b = 0.0;
-    const volatile double* src = scratch + (size_t)blockIdx.x * 64 + cl;
-    for (int k = 0; k < R; ++k) {
-      a += src[((size_t)k * 2) * scratch_cols];
-      b += src[((size_t)k * 2 + 1) * scratch_cols];
-    }
-  }
-  if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
   *ta = a;
   *tb = b;
   return true;
@@ -998,6 +976,7 @@ __global__ __launch_bounds__(kColsumThreads) void bn_bwd_stats_kernel(const floa
                                                                       int Cp, double count, int training,
                                                                       float* __restrict__ c1, float* __restrict__ c2,
                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                      float* __restrict__ dbias_zero,
                                                                       double* __restrict__ scratch, int scratch_cols,
                                                                       int* __restrict__ tickets) {
   __shared__ double red[2048];
@@ -1010,14 +989,17 @@ __global__ __launch_bounds__(kColsumThreads) void bn_bwd_stats_kernel(const floa
   if (c < C) {
     if (dgamma) dgamma[c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
+    // training-mode BatchNorm removes any per-channel shift of its input: the gradient of the convolution bias
+    // in front of it is exactly zero (the reference's autograd produces rounding noise around zero)
+    if (dbias_zero) dbias_zero[c] = 0.f;
   }
 }
 
 int bn_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int64_t count, int training, float* c1, float* c2,
-                        float* dgamma, float* dbeta, const ColsumScratch& cs, hipStream_t st) {
+                        float* dgamma, float* dbeta, float* dbias_zero, const ColsumScratch& cs, hipStream_t st) {
   const int groups = ceil_div(Cp, 64);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(groups, colsum_chunks(rows)), dim3(kColsumThreads), 0, st, partial, rows, C, Cp,
-                     (double)count, training, c1, c2, dgamma, dbeta, cs.sums, groups * 64, cs.tickets);
+                     (double)count, training, c1, c2, dgamma, dbeta, dbias_zero, cs.sums, groups * 64, cs.tickets);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1094,6 +1076,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, cons
       acc = f4add(acc, r);
     }
   }
+  if (!partial) return;  // training mode: the bias gradient is exactly zero, no column sums wanted
   const float4 s = quad_block_sum(acc, t, red);
   if (t.pl == 0 && t.q < Cv) st4(partial + (size_t)blockIdx.x * Cp + 4 * t.q, s);
 }

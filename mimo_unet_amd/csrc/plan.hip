@@ -224,7 +224,7 @@ struct mimo_plan {
   hipStream_t cap_stream = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   uint64_t graph_key = 0;
-  // hipGraph replay of the TRAINING step (MIMO_TRAIN_GRAPH, default on): one graph for the training forward, one per
+  // hipGraph replay of the TRAINING step (MIMO_TRAIN_GRAPH=1, opt-in): one graph for the training forward, one per
   // backward stage (~330 launches per step otherwise — at the 4 images per GPU of an 8-way strong-scaling run the
   // step is launch-bound).  Same staging scheme: the captured kernels read plan-owned copies of image / permutation /
   // Dropout2d masks / label / loss mask / dloss and write the plan-owned logits buffer.
@@ -719,7 +719,9 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&g_perm, (size_t)S * N));
     {
       const char* te = getenv("MIMO_TRAIN_GRAPH");
-      train_graph = graph_enabled && !(te && atoi(te) == 0) && !cfg.inference_only && !wg_async && !subnet_streams;
+      // opt-in: measured on cfg3 at 32 and at 4 images per GPU the replay is no faster than the eager launch sequence
+      // (30.2 vs 30.0 ms and 7.43 vs 7.36 ms per step: the step is not launch-bound even at 4 images)
+      train_graph = graph_enabled && te && atoi(te) != 0 && !cfg.inference_only && !wg_async && !subnet_streams;
       if (train_graph) {
         MIMO_TRY(dalloc(&g_label, (size_t)N * (Co / 2) * H * W));
         MIMO_TRY(dalloc(&g_lmask, (size_t)N * H * W));
@@ -1049,7 +1051,7 @@ struct mimo_plan {
                                       mask, L.Cout, L.cout_p, L.N, L.H, L.W, s_partial, &rows, st));
     prof_end(pr, 0.0, 8.0 * (double)P * L.cout_p, st);
     MIMO_TRY(bn_bwd_stats_launch(s_partial, rows, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
-                                 grads + L.off_gamma, grads + L.off_beta, colsum(), st));
+                                 grads + L.off_gamma, grads + L.off_beta, fwd_training ? grads + L.off_b : nullptr, colsum(), st));
     const int b = dz_idx;
     float* dz = s_dz2[b];
     if (wg_async) {
@@ -1058,7 +1060,8 @@ struct mimo_plan {
     }
     pr = prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
     MIMO_TRY(bn_bwd_apply_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
-                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, L.dg_split ? 1 : 0, s_partial, &rows, st));
+                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, L.dg_split ? 1 : 0,
+                                 fwd_training ? nullptr : s_partial, &rows, st));
     prof_end(pr, 0.0, 12.0 * (double)P * L.cout_p, st);
     // dz storage: bf16 hi|lo pairs when the data-gradient kernel is the bf16-pair one (then the weight
     // gradient is too); fp32 otherwise, with a split copy for a bf16-pair weight gradient
@@ -1070,7 +1073,9 @@ struct mimo_plan {
     // wgrad(L) may start as soon as dz exists, next to dgrad(L) (releasing it only after dgrad(L), i.e. next
     // to the bandwidth-bound kernels of the layer below, measured the same step time)
     if (wg_async) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
-    MIMO_TRY(colsum_vec_launch(s_partial, rows, L.cout_p, L.Cout, grads + L.off_b, colsum(), st));
+    // conv bias gradient: exactly zero in front of a training-mode BatchNorm (written by bn_bwd_stats above);
+    // a real column sum of dz only after an eval-mode forward (running statistics: dz = scale * dy)
+    if (!fwd_training) MIMO_TRY(colsum_vec_launch(s_partial, rows, L.cout_p, L.Cout, grads + L.off_b, colsum(), st));
     if (need_dgrad) {
       ConvLaunch a;
       a.x = dz;
