@@ -13,7 +13,8 @@ forward (gather fused into the first kernel), Laplace NLL, loss-buffer weighting
 [gradient all-reduce over RCCL when N>1], fused Adam.  Synthetic inputs resident in HBM: image ~ U[0,1),
 label = `learnable_label(image)` (a smoothed channel mix + uniform noise; SURVEY 8d's U[0,1) labels make the
 NLL's scale head collapse on single pixels after ~100 steps in every arithmetic), the same batch every
-step, PyTorch default random init, fp32 storage.
+step, PyTorch default random init, fp32 storage (MIMO_PRECISION=bf16-mixed | 16-mixed select the 16-bit storage modes — reduced precision, never the
+headline metric).
 
 Scaling: "weak" (default) = the per-GPU batch is fixed at the config's batch (32: the reference README's
 SEN12TP batch size with Lightning-DDP semantics, batch_size = per device); "strong" = the config's batch is
@@ -90,13 +91,13 @@ def conv_layers(c):
     return L
 
 
-def algorithmic_bytes_per_image(c):
-    """train = 3 x forward, forward = sum over conv layers of (input + output) tensor bytes (fp32),
-    every other operator fused away.  Returns ([bytes per tier], total).  cfg3: 525.3 / 188.7 / 94.4 / 47.2 /
-    5.9 MB = 861.5 MB per image."""
+def algorithmic_bytes_per_image(c, elem_bytes=4):
+    """train = 3 x forward, forward = sum over conv layers of (input + output) tensor bytes (fp32; 2 bytes
+    per element in the 16-bit storage modes), every other operator fused away.  Returns ([bytes per tier], total).
+    cfg3: 525.3 / 188.7 / 94.4 / 47.2 / 5.9 MB = 861.5 MB per image; cfg4 in bf16: 1050 MB."""
     tiers = [0.0] * 5
     for t, cin, cout, h, w, _ in conv_layers(c):
-        tiers[t] += 3.0 * 4.0 * (cin + cout) * h * w
+        tiers[t] += 3.0 * elem_bytes * (cin + cout) * h * w
     return tiers, sum(tiers)
 
 
@@ -216,7 +217,7 @@ def main():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
     opt = model.configure_optimizers()["optimizer"]
-    opt.grad_scale = 1.0 / world
+    opt.reduce_scale = 1.0 / world
     if args.scaling == "strong":
         # the global batch, identical on every rank, sharded by rank (ddp.shard_batch: rows [r*B, (r+1)*B))
         from mimo_unet_amd.ddp import shard_batch
@@ -236,21 +237,32 @@ def main():
         reducer.attach(model.model)  # all-reduces start from inside the backward, as gradient ranges become final
 
     adam_events = []
+    precision = os.environ.get("MIMO_PRECISION", "split16")
+    # "16-mixed" = the reference's production precision: fp16 storage / operands under torch's GradScaler (FlatAdam
+    # unscales, checks for inf / nan and skips on the device)
+    scaler = torch.amp.GradScaler("cuda") if precision == "16-mixed" else None
+
+    def optimizer_step():
+        if scaler is not None:
+            scaler.step(opt)
+            scaler.update()
+        else:
+            opt.step()
 
     def step(i, time_adam=False):
         opt.zero_grad()
         out = model.training_step(batch, i)
-        out["loss"].backward()
+        (scaler.scale(out["loss"]) if scaler is not None else out["loss"]).backward()
         if reducer is not None:
             reducer.finish()  # bucketed sums over RCCL were started from inside backward; FlatAdam scales by 1/world
         if time_adam:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            opt.step()
+            optimizer_step()
             e1.record()
             adam_events.append((e0, e1))
         else:
-            opt.step()
+            optimizer_step()
         return out["loss"]
 
     for i in range(args.warmup):
@@ -295,8 +307,8 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
-    precision = os.environ.get("MIMO_PRECISION", "split16")
-    tier_bytes, bytes_per_image = algorithmic_bytes_per_image(c)
+    mixed = precision in ("bf16-mixed", "16-mixed")
+    tier_bytes, bytes_per_image = algorithmic_bytes_per_image(c, 2 if mixed else 4)
     weight_bytes = 3.0 * 4.0 * sum(cin * cout * k * k for _, cin, cout, _, _, k in conv_layers(c))
     step_bytes = bytes_per_image * B + weight_bytes
     line = {
@@ -304,7 +316,10 @@ def main():
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": {"fp32": "f32", "split16": "f32 (split into 16-bit hi/lo pairs on the MFMA)",
-                  "bf16": "bf16 MFMA operands, f32 accumulate/storage (reduced precision)"}.get(precision, precision),
+                  "bf16": "bf16 MFMA operands, f32 accumulate/storage (reduced precision)",
+                  "bf16-mixed": "bf16 storage + MFMA operands, f32 accumulate / master weights / statistics (reduced precision)",
+                  "16-mixed": "fp16 storage + MFMA operands under a loss scaler, f32 accumulate / master weights / statistics "
+                              "(the reference's precision=16-mixed; reduced precision)"}.get(precision, precision),
         "data": "synthetic",
         "config": {"workload": f"{c['name']}, batch {c['batch']} " + ("global" if args.scaling == "strong" else "per GPU"),
                    "global_batch": world * B, "per_gpu_batch": B, "image": [c["H"], c["W"]], "scaling": args.scaling,
@@ -356,7 +371,11 @@ def main():
                            "split16": "3x 16-bit MFMA per product (fp16 hi/lo forward, bf16 hi/lo gradients), fp32 "
                                       "accumulate; peak = 2500 TFLOP/s dense 16-bit MFMA / 3",
                            "bf16": "bf16 MFMA operands (one MFMA per product), fp32 accumulate and storage — reduced "
-                                   "precision, NOT the fp32 metric"}.get(precision, precision),
+                                   "precision, NOT the fp32 metric",
+                           "bf16-mixed": "bf16 storage and MFMA operands (one MFMA per product), fp32 accumulate — reduced "
+                                         "precision, NOT the fp32 metric",
+                           "16-mixed": "fp16 storage and MFMA operands (one MFMA per product), fp32 accumulate, loss "
+                                       "scaling — reduced precision, NOT the fp32 metric"}.get(precision, precision),
             "source": f"second pass of {psteps} steps with HIP events on the launch stream (the timed region is not instrumented)",
             "hbm_frac_algorithmic": round(kernels[dom]["algorithmic_gbs"] / HBM_PEAK_GBS, 4),
             "conv_ms_per_step": round(sum(k["ms_per_step"] for k in kernels.values()), 2), "kernels": kernels,

@@ -34,7 +34,8 @@ enum mimo_status {
   MIMO_ERR_STATE = -3    /* call order violated (e.g. backward before forward) */
 };
 
-/* Arithmetic of the 3x3 convolutions (storage, BatchNorm statistics and the loss are always fp32).
+/* Arithmetic of the 3x3 convolutions (BatchNorm statistics, the loss and the optimiser are always fp32; storage is
+ * fp32 except in the two *_MIXED modes).
  * MIMO_PREC_FP32: f32-input MFMA everywhere (bit-exact fp32 fma chains).
  * MIMO_PREC_SPLIT16: each fp32 operand is split into a 16-bit hi + lo pair and every product block
  *   is three 16-bit MFMAs with fp32 accumulation: fp16 pairs in the forward convolution (~2^-22 per
@@ -44,8 +45,20 @@ enum mimo_status {
  *   (scripts/train/train_ndvi.py:71) and of BASELINE config 4: convolution operands are rounded to bf16
  *   on the way into the MFMA (one MFMA per product block, fp32 accumulation); master weights, BatchNorm
  *   statistics, the loss, the optimiser and — in this version — the stored activations stay fp32.
- *   Parity against the fp32 oracle at bf16 tolerance (~1e-2). */
-enum mimo_precision { MIMO_PREC_FP32 = 0, MIMO_PREC_SPLIT16 = 1, MIMO_PREC_BF16 = 2 };
+ *   Parity against the fp32 oracle at bf16 tolerance (~1e-2).
+ * MIMO_PREC_BF16_MIXED / MIMO_PREC_FP16_MIXED: 16-bit STORAGE as well — activations, convolution outputs and their
+ *   gradients live in HBM as bf16 / fp16 (half the bytes of every bandwidth-bound pass), convolution operands are that
+ *   type (one MFMA per product, fp32 accumulation); master weights, BatchNorm statistics (taken from the fp32
+ *   accumulators), the logits, the loss and the optimiser stay fp32.  FP16_MIXED is the reference's production mode
+ *   `precision="16-mixed"` (scripts/train/train_ndvi.py:71): run it under a loss scaler (torch.cuda.amp.GradScaler;
+ *   FlatAdam unscales, checks for inf / nan and skips the step on the device).  BASELINE config 4 = BF16_MIXED. */
+enum mimo_precision {
+  MIMO_PREC_FP32 = 0,
+  MIMO_PREC_SPLIT16 = 1,
+  MIMO_PREC_BF16 = 2,
+  MIMO_PREC_BF16_MIXED = 3,
+  MIMO_PREC_FP16_MIXED = 4
+};
 
 enum mimo_loss_kind { MIMO_LOSS_LAPLACE_NLL = 0, MIMO_LOSS_GAUSSIAN_NLL = 1 };
 
@@ -189,6 +202,14 @@ int mimo_plan_profile_read_tier(mimo_plan* plan, int tier, double* forward_ms, d
 int mimo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float grad_scale, mimo_stream stream);
+
+/* The same step under a loss scaler (the reference trains with Lightning precision="16-mixed" = torch.cuda.amp.GradScaler,
+ * scripts/train/train_ndvi.py:71).  step_dev: device float, the optimiser's step count, advanced here unless
+ * *found_inf != 0; amp_scale / found_inf: device floats as GradScaler hands them to a fused optimiser (gradients are
+ * divided by *amp_scale; the whole update is skipped when *found_inf != 0) or NULL.  No host synchronisation. */
+int mimo_adam_step_amp(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float* step_dev, float grad_scale,
+                       const float* amp_scale, const float* found_inf, mimo_stream stream);
 
 /* ---- uncertainties: replaces compute_uncertainties (utils.py:76-101) --------------------
  * p1, p2 [N,S,C,HW] contiguous -> mean, aleatoric_var, epistemic_var [N,C,HW]. */

@@ -42,7 +42,8 @@ class ForwardArgs(C.Structure):
 
 
 LOSS_KINDS = {"laplace_nll": 0, "gaussian_nll": 1}
-PRECISIONS = {"fp32": 0, "split16": 1, "bf16": 2}
+# "bf16-mixed" / "16-mixed": Lightning's names for bf16 / fp16 autocast training — here 16-bit storage + operands
+PRECISIONS = {"fp32": 0, "split16": 1, "bf16": 2, "bf16-mixed": 3, "16-mixed": 4}
 
 _lib = None
 
@@ -73,6 +74,7 @@ _SIGNATURES = {
                                          C.POINTER(C.c_double)]),
     "mimo_plan_profile_read_tier": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mimo_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "mimo_adam_step_amp": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _F, _P, _P, _P]),
     "mimo_uncertainties": (C.c_int, [_P, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P]),
     "mimo_validation_epilogue": (C.c_int, [_P, _P, _P, _I, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mimo_training_epilogue": (C.c_int, [_P, _P, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -33,6 +33,11 @@ static inline int pad_channels(int c) { return round_up(c, 8); }
 
 constexpr int kWave = 64;
 
+// Element type of the activation-like tensors in HBM (conv outputs, activations and their gradients): fp32, or bf16 /
+// fp16 in the 16-bit storage modes MIMO_PREC_BF16_MIXED / MIMO_PREC_FP16_MIXED.  Arithmetic is always fp32.
+enum StoreType { ST_F32 = 0, ST_BF16 = 1, ST_F16 = 2 };
+static inline int store_bytes(int dt) { return dt == ST_F32 ? 4 : 2; }
+
 // Workgroups are dealt round-robin to the 8 XCDs (each with a private L2) in linear-id order.  This maps a
 // linear workgroup id to a "virtual" index such that every XCD owns one CONTIGUOUS range of virtual indices
 // (any total, bijective): kernels then decode the virtual index so that workgroups which read the same
@@ -94,6 +99,9 @@ struct WgradLaunch {
   int cin_pad, cout_pad;  // multiples of 32
   int splits;
   int np = 3;  // split kernels: MFMAs per product block — 3 (hi/lo pairs, fp32-class) or 1 (bf16 compute)
+  // split kernels, operand storage: 0 = activations fp32 + dz pre-split bf16 pair records; 1 / 2 = activations and dz
+  // plain NHWC bf16 / fp16 (ldx, lddz in elements); 3 / 4 = activations fp32 (the packed image) + dz plain bf16 / fp16
+  int store = 0;
 };
 int wgrad_launch(const WgradLaunch& a, hipStream_t stream);
 // split-bf16 variant (wgrad_split.hip): cin_pad / cout_pad must be multiples of its (CI, CO) tile

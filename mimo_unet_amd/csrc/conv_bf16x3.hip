@@ -26,6 +26,7 @@
 //   * LDS rows are 64 bf16 (32 hi | 32 lo) + 16 B pad = 144 B: ds_read_b128 fragment reads with
 //     compile-time offsets, 16 consecutive pixels land on distinct bank quads
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -59,12 +60,19 @@ constexpr float kF16WeightScale = 256.f;  // 2^8, exact
 //   1  split16 forward       : fp16 (hi, lo) pairs, fp32 input split on the way, 3 MFMAs per product
 //   2  bf16 forward          : bf16 hi only,        fp32 input rounded on the way, 1 MFMA per product
 //   3  bf16 data gradient    : bf16 hi only,        input pre-split (lo ignored),  1 MFMA per product
-// (modes 2 / 3 = mimo_precision BF16: "bf16 compute, fp32 accumulate"; the LDS rows keep the
-// [hi 32 | lo 32] image and simply leave the lo half unused)
-#define MIMO_CONV_MODE_CONSTANTS                                                    \
-  constexpr bool F16 = MODE == 1;              /* element type fp16 (else bf16) */   \
-  constexpr bool CVT = MODE == 1 || MODE == 2; /* loader converts fp32 input */      \
-  constexpr int NP = MODE >= 2 ? 1 : 3;        /* MFMAs per product block */
+//   4  bf16-mixed forward    : bf16, input AND output stored as plain NHWC bf16,  1 MFMA per product
+//   5  bf16-mixed data grad  : same, dz / dx stored as bf16
+//   6  fp16-mixed forward    : fp16 storage and operands (the reference's precision="16-mixed"), weights x 2^8
+//   7  fp16-mixed data grad  : same (gradients arrive multiplied by the loss scale)
+// (modes 2 / 3 = mimo_precision BF16: "bf16 compute, fp32 accumulate"; modes >= 2 keep the [hi 32 | lo 32] LDS row
+// image and simply leave the lo half unused)
+#define MIMO_CONV_MODE_CONSTANTS                                                                         \
+  constexpr bool F16 = MODE == 1 || MODE >= 6;  /* element type fp16 (else bf16) */                       \
+  constexpr bool CVT = MODE == 1 || MODE == 2;  /* loader converts fp32 input */                          \
+  constexpr bool IN16 = MODE >= 4;              /* input = plain NHWC of the 16-bit element type */       \
+  constexpr bool OUT16 = MODE >= 4;             /* output stored in the 16-bit element type */            \
+  constexpr bool FWD = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6; /* bias, BatchNorm sums, inference epilogue */ \
+  constexpr int NP = MODE >= 2 ? 1 : 3;         /* MFMAs per product block */
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -103,6 +111,7 @@ struct TileCfg {
 template <int MF, int NF, int MODE>
 __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX) {
   MIMO_CONV_MODE_CONSTANTS
+  (void)FWD;  // this kernel's epilogue keys on the argument pointers (bias / stats / ep_scale null for the data gradient)
   typedef typename Elem<F16>::T ET;
   typedef typename Elem<F16>::V8 bf16x8;
   typedef typename Elem<F16>::V4 bf16x4;
@@ -151,6 +160,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
   __syncthreads();
 
   const float* ximg = a.x + (size_t)n * a.Hi * a.Wi * a.ldx;
+  const unsigned short* ximg16 = reinterpret_cast<const unsigned short*>(a.x) + (size_t)n * a.Hi * a.Wi * a.ldx;  // IN16
   const int nchunks = (a.cin_p + 31) / 32;
   const u32x4* wpk = reinterpret_cast<const u32x4*>(a.wpk);
 
@@ -167,6 +177,11 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
       const int ch_ = (CHUNK) * 32 + 4 * q_;                                                    \
       const bool ok_ = o_ >= 0 && ch_ < a.cin_p;                                                \
       xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg + o_ + ch_ : kZeroPage);            \
+    } else if (IN16) { /* plain 16-bit NHWC: units 0..3 = 8 channels each (the hi half of the row), 4..7 unused */ \
+      const int rc_ = min(32, a.cin_p - (CHUNK) * 32);                                          \
+      const bool ok_ = o_ >= 0 && q_ < 4 && 8 * q_ < rc_;                                       \
+      xreg[k_] = *reinterpret_cast<const f32x4*>(                                               \
+          ok_ ? reinterpret_cast<const float*>(ximg16 + o_ + (CHUNK) * 32 + 8 * q_) : kZeroPage); \
     } else { /* pre-split input, chunk record [hi rc | lo rc] bf16: unit q_ = 8 channels, 16 bytes */ \
       const int rc_ = min(32, a.cin_p - (CHUNK) * 32);                                          \
       const bool ok_ = o_ >= 0 && 8 * (q_ & 3) < rc_;                                           \
@@ -308,7 +323,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
     esh[nf] = a.ep_scale ? a.ep_shift[co0 + nf * 16 + lr] : 0.f;
     emk[nf] = (a.ep_mask && co0 + nf * 16 + lr < a.ep_mask_ld) ? a.ep_mask[(size_t)n * a.ep_mask_ld + co0 + nf * 16 + lr] : 1.f;
   }
-  float* yimg = a.y + (size_t)n * a.Ho * a.Wo * a.ldy;
+  typedef typename std::conditional<OUT16, ET, float>::type OT;
+  OT* yimg = reinterpret_cast<OT*>(a.y) + (size_t)n * a.Ho * a.Wo * a.ldy;
 #pragma unroll
   for (int m = 0; m < MF; ++m) {
 #pragma unroll
@@ -317,12 +333,12 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
       const int orow = idx / TC, ocol = idx - orow * TC;
       const int oy = y0 + orow, ox = x0 + ocol;
       if (idx < npix_out && oy < a.Ho && ox < a.Wo) {
-        float* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy + co0 + lr;
+        OT* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy + co0 + lr;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
           float v = acc[m][nf][r4] * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];
           if (a.ep_scale) v = fmaxf(fmaf(v, esc[nf], esh[nf]), 0.f) * emk[nf];
-          if (co0 + nf * 16 + lr < a.cout_store) yp[nf * 16] = v;
+          if (co0 + nf * 16 + lr < a.cout_store) yp[nf * 16] = (OT)v;
           s1[nf] += v;
           s2[nf] += v * v;
         }
@@ -396,11 +412,15 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   typedef typename Elem<F16>::T ET;
   typedef typename Elem<F16>::V8 bf16x8;
   typedef typename Elem<F16>::V4 bf16x4;
+  typedef typename std::conditional<OUT16, ET, float>::type OT;  // element type of the output tensor
   constexpr int NB = NF * 16;
   constexpr int MF = MF_;
   constexpr int kWsMaxPix = WsTile<MF>::MAXPIX;
-  constexpr int XU = (kWsMaxPix * 8 + 255) / 256;  // 16-byte units of an input tile per producer thread (12 / 6)
-  constexpr int XP = XU / 3;                        // units handled per phase
+  // 16-byte units per LDS row that carry data: 8 (fp32 input: 4 channels each; pre-split input: hi + lo halves) or,
+  // for plain 16-bit input, the 4 units of the hi half (8 channels each)
+  constexpr int UPP = IN16 ? 4 : 8, UPPS = IN16 ? 2 : 3;
+  constexpr int XU = (kWsMaxPix * UPP + 255) / 256;  // units of an input tile per producer thread (12 / 6; IN16: 6 / 3)
+  constexpr int XP = XU / 3;                          // units handled per phase
   static_assert(XU % 3 == 0, "input tile staged in three equal parts");
   constexpr int WUNITS = 3 * NB * 8;
   constexpr int WU = (WUNITS + 255) / 256;
@@ -439,10 +459,10 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     int u_rc[XU], u_off[XU];
 #pragma unroll
     for (int k = 0; k < XU; ++k) {
-      const int p = min((ptid + k * 256) >> 3, npix_lds - 1);
+      const int p = min((ptid + k * 256) >> UPPS, npix_lds - 1);
       const int tr = p / TCP, tc = p - tr * TCP;
       u_rc[k] = (tr << 16) | tc;
-      u_off[k] = ((tr * a.Wi + tc) * a.ldx + 4 * ((ptid + k * 256) & 7)) * 4;
+      u_off[k] = ((tr * a.Wi + tc) * a.ldx + 4 * ((ptid + k * 256) & 7)) * 4;  // pre-split input only
     }
     const u32x4* wpk = reinterpret_cast<const u32x4*>(a.wpk);
     // stage j = (tile j / nchunks, chunk j % nchunks)
@@ -457,12 +477,13 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     const int n_ = t_ / tilesY;                                                                      \
     const int y0_ = ty_ * TR - a.off, x0_ = tx_ * TC - a.off;                                        \
     const float* ximg_ = a.x + (size_t)n_ * a.Hi * a.Wi * a.ldx;                                     \
+    const unsigned short* ximg16_ = reinterpret_cast<const unsigned short*>(a.x) + (size_t)n_ * a.Hi * a.Wi * a.ldx; \
     /* halo inside the image and a full 32-channel chunk (a wave-uniform test): no reflection, no     \
        masking, address = scalar tile base + per-thread constant -- the ~20 vector instructions per    \
        unit of the general path compete with the MFMAs for the SIMD's issue port.  Data gradient     \
        only: measured -8 % on its thin layers, nothing on the forward (whose producers are bound by   \
        the fp32 -> fp16 split) */                                                                     \
-    if (!CVT && y0_ >= 0 && y0_ + TRP <= a.Hi && x0_ >= 0 && x0_ + TCP <= a.Wi && ck_ * 32 + 32 <= a.cin_p) { \
+    if (!CVT && !IN16 && y0_ >= 0 && y0_ + TRP <= a.Hi && x0_ >= 0 && x0_ + TCP <= a.Wi && ck_ * 32 + 32 <= a.cin_p) { \
       const char* tb_ = reinterpret_cast<const char*>(ximg_ + ((size_t)y0_ * a.Wi + x0_) * a.ldx) + ck_ * 128; \
       _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_)                                         \
         xreg[k_] = *reinterpret_cast<const f32x4*>(tb_ + u_off[k_]);                                 \
@@ -478,9 +499,14 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
       } else { /* zero padding (transposed convolution) */                                           \
         in_ = iy_ >= 0 && iy_ < a.Hi && ix_ >= 0 && ix_ < a.Wi;                                      \
       }                                                                                              \
-      const int q_ = (ptid + k_ * 256) & 7;                                                          \
+      const int q_ = (ptid + k_ * 256) & (UPP - 1);                                                  \
       const int o_ = in_ ? (iy_ * a.Wi + ix_) * a.ldx : 0;                                           \
-      if (CVT) {                                                                                     \
+      if (IN16) { /* plain 16-bit NHWC: unit q_ = 8 channels of the chunk */                         \
+        const int rc_ = min(32, a.cin_p - ck_ * 32);                                                 \
+        const bool ok_ = in_ && 8 * q_ < rc_;                                                        \
+        xreg[k_] = *reinterpret_cast<const f32x4*>(                                                  \
+            ok_ ? reinterpret_cast<const float*>(ximg16_ + o_ + ck_ * 32 + 8 * q_) : kZeroPage);     \
+      } else if (CVT) {                                                                              \
         const int ch_ = ck_ * 32 + 4 * q_;                                                           \
         const bool ok_ = in_ && ch_ < a.cin_p;                                                       \
         xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg_ + o_ + ch_ : kZeroPage);              \
@@ -497,7 +523,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #define WS_STORE_X(K0, K1, BUF)                                                                      \
   _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                           \
     const int u_ = ptid + k_ * 256;                                                                  \
-    const int p_ = u_ >> 3, q_ = u_ & 7;                                                             \
+    const int p_ = u_ >> UPPS, q_ = u_ & (UPP - 1);                                                  \
     if (p_ < npix_lds) {                                                                             \
       const f32x4 v_ = xreg[k_];                                                                     \
       unsigned char* row_ = xs + (BUF) * XBYTES + p_ * PITCH;                                        \
@@ -575,7 +601,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #undef WS_STORE_X
 #undef WS_LOAD_W
 #undef WS_STORE_W
-    if (CVT && a.stats) __syncthreads();  // the consumers combine their BatchNorm sums through LDS (see the end)
+    if (FWD && a.stats) __syncthreads();  // the consumers combine their BatchNorm sums through LDS (see the end)
     return;
   }
 
@@ -606,7 +632,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   f32x4 bv[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
-    bv[nf] = (CVT && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + co0 + nf * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bv[nf] = (FWD && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + co0 + nf * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   // tile-relative (row, column) of this lane's pixel in each of its MF fragments; row 0x4000 = not in the tile
   int prc[kWsMaxMF];
 #pragma unroll
@@ -702,18 +728,19 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     const int ty_ = t_ % tilesY;                                                                     \
     const int n_ = t_ / tilesY;                                                                      \
     const int y0_ = ty_ * TR, x0_ = tx_ * TC;                                                        \
-    float* yimg = a.y + (size_t)n_ * a.Ho * a.Wo * a.ldy + co0 + g * 4;                              \
+    OT* yimg = reinterpret_cast<OT*>(a.y) + (size_t)n_ * a.Ho * a.Wo * a.ldy + co0 + g * 4;          \
     _Pragma("unroll") for (int m = 0; m < MF; ++m) {                                                 \
       const int oy = y0_ + (prc[m] >> 16), ox = x0_ + (prc[m] & 0xffff);                             \
       if (oy < a.Ho && ox < a.Wo) {                                                                  \
-        float* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy;                                         \
+        OT* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy;                                            \
         _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                          \
           /* bias, inference epilogue and BatchNorm sums exist on the forward only (CVT); the data   \
              gradient stores its accumulators as they are */                                         \
           f32x4 v = acc[m][nf];                                                                      \
-          if (CVT) v = v * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];                             \
+          if (F16) v = v * (1.f / kF16WeightScale);                                                  \
+          if (FWD) v = v + bv[nf];                                                                   \
           const int c_ = co0 + nf * 16 + g * 4;                                                      \
-          if (CVT && a.ep_scale) {                                                                   \
+          if (FWD && a.ep_scale) {                                                                   \
             const f32x4 esc_ = *reinterpret_cast<const f32x4*>(a.ep_scale + c_);                     \
             const f32x4 esh_ = *reinterpret_cast<const f32x4*>(a.ep_shift + c_);                     \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \
@@ -722,8 +749,19 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
               v[i_] = fmaxf(fmaf(v[i_], esc_[i_], esh_[i_]), 0.f) * mk_;                             \
             }                                                                                        \
           }                                                                                          \
-          if (c_ < a.cout_store) *reinterpret_cast<f32x4*>(yp + nf * 16) = v;                        \
-          if (CVT) {                                                                                 \
+          if (c_ < a.cout_store) {                                                                   \
+            if (OUT16) {                                                                             \
+              bf16x4 o_;                                                                             \
+              o_[0] = (ET)v[0];                                                                      \
+              o_[1] = (ET)v[1];                                                                      \
+              o_[2] = (ET)v[2];                                                                      \
+              o_[3] = (ET)v[3];                                                                      \
+              *reinterpret_cast<bf16x4*>(yp + nf * 16) = o_;                                         \
+            } else {                                                                                 \
+              *reinterpret_cast<f32x4*>(yp + nf * 16) = v;                                           \
+            }                                                                                        \
+          }                                                                                          \
+          if (FWD) {                                                                                 \
             s1[nf] += v;                                                                             \
             s2[nf] += v * v;                                                                         \
           }                                                                                          \
@@ -773,7 +811,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   }
   C_EPILOGUE(ti)
   __syncthreads();  // matches the producers' last barrier: their (dead) LDS stores are done
-  if (CVT && a.stats) {
+  if (FWD && a.stats) {
     // one partial-statistics row per workgroup: the four consumer waves add their sums through LDS (4 x fewer rows
     // for the column reduction that follows)
     float* red = reinterpret_cast<float*>(xs);  // [4 waves][2][NB]
@@ -871,7 +909,7 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
     // 128-pixel tiles / two workgroups per CU: forward only (measured per layer on one box: forward 30->30 at
     // 256x256 169 -> 147 us, 45->30 282 -> 253 us; the data gradient of the same shapes 132 -> 145 us)
     static const bool mf2_on = !(getenv("MIMO_CONV_WS_MF2") && atoi(getenv("MIMO_CONV_WS_MF2")) == 0);
-    const bool mf2 = mf2_on && (MODE == 1 || MODE == 2);
+    const bool mf2 = mf2_on && (MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6);
     switch (nf) {
       case 4: return launch_ws<4, MODE, 4>(a, rows, stream);
       case 3: return launch_ws<3, MODE, 4>(a, rows, stream);
@@ -897,7 +935,8 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
 
 // mode: see MIMO_CONV_MODE_CONSTANTS (0 split16 dgrad, 1 split16 forward, 2 bf16 forward, 3 bf16 dgrad)
 int conv3x3_bf16x3_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t stream) {
-  if (!a.wpk || a.ldx % 4 != 0 || a.cout_pad % 16 != 0 || a.Hi < 2 || a.Wi < 2 || mode < 0 || mode > 3) {
+  if (!a.wpk || a.ldx % 4 != 0 || a.cout_pad % 16 != 0 || a.Hi < 2 || a.Wi < 2 || mode < 0 || mode > 7 ||
+      (mode >= 4 && (a.ldx % 8 != 0 || a.cin_p % 8 != 0 || a.ldy % 4 != 0))) {
     set_error("conv3x3 split: bad geometry or mode");
     return MIMO_ERR_INVALID;
   }
@@ -905,7 +944,11 @@ int conv3x3_bf16x3_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t 
     case 0: return conv3x3_split_dispatch<0>(a, rows, stream);
     case 1: return conv3x3_split_dispatch<1>(a, rows, stream);
     case 2: return conv3x3_split_dispatch<2>(a, rows, stream);
-    default: return conv3x3_split_dispatch<3>(a, rows, stream);
+    case 3: return conv3x3_split_dispatch<3>(a, rows, stream);
+    case 4: return conv3x3_split_dispatch<4>(a, rows, stream);
+    case 5: return conv3x3_split_dispatch<5>(a, rows, stream);
+    case 6: return conv3x3_split_dispatch<6>(a, rows, stream);
+    default: return conv3x3_split_dispatch<7>(a, rows, stream);
   }
 }
 

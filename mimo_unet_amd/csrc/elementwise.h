@@ -1,6 +1,9 @@
-// Launch wrappers of the bandwidth-class kernels (elementwise.hip).  All tensors NHWC, fp32,
-// channel count padded to a multiple of 8; "ld" = floats per pixel of the buffer a pointer
-// indexes (a tensor may be a channel slice of a wider concat buffer).
+// Launch wrappers of the bandwidth-class kernels (elementwise.hip).  All tensors NHWC, channel count padded to a
+// multiple of 8; "ld" = ELEMENTS per pixel of the buffer a pointer indexes (a tensor may be a channel slice of a
+// wider concat buffer).  Activation-like tensors (conv outputs z, activations a, their gradients da / dxpad / dz)
+// are fp32, or — in the 16-bit storage modes (mimo_precision *_MIXED) — bf16 / fp16: such pointers are passed
+// untyped together with a StoreType ("dt"; "dtz" for a conv output, which stays fp32 for the image convolution).
+// Statistics, masks, BatchNorm vectors, logits and every accumulation stay fp32.
 #pragma once
 #include "common.h"
 
@@ -37,7 +40,7 @@ int head_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int Co,
 int pack_input_launch(const float* x, int64_t stride_n, int64_t stride_s, const int64_t* perm, int s, int N, int C,
                       int H, int W, float* out, int cp, hipStream_t st);
 // dx[n][s][c][y][x] = fold(dxpad)[n][y][x][c]
-int unpack_dx_launch(const float* dxpad, int ldp, int N, int S, int s, int C, int H, int W, float* dx, hipStream_t st);
+int unpack_dx_launch(const void* dxpad, int dt, int ldp, int N, int S, int s, int C, int H, int W, float* dx, hipStream_t st);
 
 // ---- BatchNorm + ReLU (+ Dropout2d) forward ---------------------------------------------
 // training: sums = rowsum of the conv epilogue partials ([chunks][2*cout_pad]).
@@ -49,42 +52,42 @@ int bn_eval_prepare_launch(int C, int Cp, const float* gamma, const float* beta,
                            const float* running_var, float eps, float* mean, float* invstd, float* scale,
                            float* shift, hipStream_t st);
 // a = relu(z*scale+shift) * mask[n][c]
-int bn_relu_fwd_launch(const float* z, int ldz, float* a, int lda, const float* scale, const float* shift,
+int bn_relu_fwd_launch(const void* z, int dtz, int ldz, void* a, int dta, int lda, const float* scale, const float* shift,
                        const float* mask, int C, int Cp, int64_t P, int HW, hipStream_t st);
 
 // same, for a tensor that feeds MaxPool2d(2): also writes pool[N,H/2,W/2] = maxpool2x2(a) (one pass, 2x2 window per thread)
-int bn_relu_pool_fwd_launch(const float* z, int ldz, float* a, int lda, const float* scale, const float* shift,
-                            const float* mask, int C, int Cp, int N, int H, int W, float* pool, int ldpool, hipStream_t st);
+int bn_relu_pool_fwd_launch(const void* z, int dtz, int ldz, void* a, int dta, int lda, const float* scale, const float* shift,
+                            const float* mask, int C, int Cp, int N, int H, int W, void* pool, int ldpool, hipStream_t st);
 
 // ---- pooling / upsampling ---------------------------------------------------------------
-int maxpool_fwd_launch(const float* a, int lda, int N, int H, int W, int Cp, float* out, int ldo, hipStream_t st);
+int maxpool_fwd_launch(const void* a, int dt, int lda, int N, int H, int W, int Cp, void* out, int ldo, hipStream_t st);
 // out[N,H,W,csp+clp] = cat(skip, zero_pad(bilinear_x2_align_corners(low))); skip == nullptr: channels [0, csp) of
 // out already hold the skip tensor (its producer writes it in place), only the up-sampled part is written
-int upcat_fwd_launch(const float* skip, int lds, int csp, const float* low, int ldl, int clp, int N, int H, int W,
-                     int h, int w, float* out, hipStream_t st);
+int upcat_fwd_launch(const void* skip, int dt, int lds, int csp, const void* low, int ldl, int clp, int N, int H, int W,
+                     int h, int w, void* out, hipStream_t st);
 
 // ---- backward gathers.  "dxpad" = gradient on the reflect-padded domain [N,H+2,W+2,ldp]
 // produced by the dgrad convolution; fold = transpose of reflect padding. ------------------
 // da[N,H,W] (lda) (=|+=) maxpool2x2 backward of fold(dxpad at pooled size), argmax from a
 // skip != nullptr: + fold(skip [N,H+2,W+2] (ldsk))[..., 0 : Cp] — the skip-connection gradient of the same tensor,
 // read straight from the Up block's padded-domain data gradient
-int pool_bwd_launch(const float* dxpad, int ldp, int choff, const float* a, int lda, float* da, int ldda, int N,
-                    int H, int W, int Cp, int accumulate, hipStream_t st, const float* skip = nullptr, int ldsk = 0);
+int pool_bwd_launch(const void* dxpad, int dt, int ldp, int choff, const void* a, int lda, void* da, int ldda, int N,
+                    int H, int W, int Cp, int accumulate, hipStream_t st, const void* skip = nullptr, int ldsk = 0);
 // da (=|+=) fold(dxpad)[..., choff : choff+Cp]
-int fold_slice_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, int N, int H, int W, int Cp,
+int fold_slice_launch(const void* dxpad, int dt, int ldp, int choff, void* da, int ldda, int N, int H, int W, int Cp,
                       int accumulate, hipStream_t st);
 // da_low[N,h,w] (=|+=) bilinear^T(fold(dxpad [N,H+2,W+2])[..., choff : choff+Cp])
-int up_bwd_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, int N, int H, int W, int h, int w,
+int up_bwd_launch(const void* dxpad, int dt, int ldp, int choff, void* da, int ldda, int N, int H, int W, int h, int w,
                   int Cp, int accumulate, hipStream_t st);
 
 // a[N,HW] (ld) *= mask, mask in the reference's NCHW layout [N][C][HW] (nn.Dropout multipliers)
-int elem_mask_mul_launch(float* a, int ld, const float* mask, int N, int C, int Cp, int HW, hipStream_t st);
+int elem_mask_mul_launch(void* a, int dt, int ld, const float* mask, int N, int C, int Cp, int HW, hipStream_t st);
 
 // ---- BatchNorm + ReLU backward ------------------------------------------------------------
 // dy = da * mask * [z*scale+shift > 0] is evaluated on the fly by both passes (never stored).
 // da source: plain (da != nullptr, ldda) or folded from dxpad (da == nullptr).
 // pass 1: partial rows of (sum dy, sum dy*xhat)
-int bnrelu_bwd_reduce_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
+int bnrelu_bwd_reduce_launch(const void* da, int dta, int ldda, const void* dxpad, int ldp, const void* z, int dtz, int ldz,
                              const float* scale, const float* shift, const float* mean, const float* invstd,
                              const float* mask, int C, int Cp, int N, int H, int W, float* partial, int* rows,
                              hipStream_t st);
@@ -92,9 +95,9 @@ int bnrelu_bwd_reduce_launch(const float* da, int ldda, const float* dxpad, int 
 int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_t count, int training, float* c1,
                            float* c2, float* dgamma, float* dbeta, hipStream_t st);
 // pass 2: dz = scale * (dy - c1 - xhat*c2); partial rows of sum dz (conv bias gradient)
-int bn_bwd_apply_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
+int bn_bwd_apply_launch(const void* da, int dta, int ldda, const void* dxpad, int ldp, const void* z, int dtz, int ldz,
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
-                        int C, const float* c1, const float* c2, int Cp, int N, int H, int W, float* dz, int split_out,
+                        int C, const float* c1, const float* c2, int Cp, int N, int H, int W, void* dz, int split_out,
                         float* partial, int* rows, hipStream_t st);
 // dst[p] = [hi Cp bf16 | lo Cp bf16] of src[p][Cp] — the storage the bf16-pair convolution kernels read
 // (split_out != 0 above writes dz in this form directly)
@@ -104,7 +107,7 @@ int vec_finalize_launch(const double* sums, int chunks, int cols, int C, float* 
 
 // ---- 1x1 head + loss ------------------------------------------------------------------------
 // out[n][s][co][yx] = bias[co] + sum_c a[n,yx,c] * w[co][c]      (components.py:126)
-int head_fwd_launch(const float* a, int lda, const float* w, const float* bias, int C, int Co, int N, int S, int s,
+int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float* bias, int C, int Co, int N, int S, int s,
                     int HW, float* out, hipStream_t st);
 // per-subnetwork sum of the un-reduced NLL (losses.py:151-160) -> partial [S][blocks]
 int loss_fwd_launch(const float* out, const float* label, const float* mask, const int64_t* perm, int N, int S,
@@ -112,9 +115,9 @@ int loss_fwd_launch(const float* out, const float* label, const float* mask, con
                     hipStream_t st);
 int loss_finalize_launch(const float* partial, int S, int blocks, double count, float* loss_out, hipStream_t st);
 // dlogit = dout + dloss[s]/count * dNLL/dlogit; da = W^T dlogit; partial rows of (dW [Co][Cp], db [Co])
-int head_bwd_launch(const float* a, int lda, const float* w, int C, int Cp, int Co, int N, int S, int s, int HW,
+int head_bwd_launch(const void* a, int dt, int lda, const float* w, int C, int Cp, int Co, int N, int S, int s, int HW,
                     const float* out, const float* dout, const float* dloss, const float* label, const float* mask,
-                    const int64_t* perm, int kind, float eps_min, float eps_max, float* da, float* partial,
+                    const int64_t* perm, int kind, float eps_min, float eps_max, void* da, float* partial,
                     int* rows, hipStream_t st);
 int head_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int Co, float* dw, float* db,
                              hipStream_t st);

@@ -63,6 +63,65 @@ static dim3 pq_grid(int Cv, int64_t P, int max_blocks = kEwMaxBlocks) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// 16-bit storage (mimo_precision *_MIXED): four channels = one 8-byte access, arithmetic stays fp32
+typedef __bf16 bf16x4_st __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_st __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+  const bf16x4_st v = *reinterpret_cast<const bf16x4_st*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4(__bf16* p, float4 v) {
+  bf16x4_st r;
+  r[0] = (__bf16)v.x;
+  r[1] = (__bf16)v.y;
+  r[2] = (__bf16)v.z;
+  r[3] = (__bf16)v.w;
+  *reinterpret_cast<bf16x4_st*>(p) = r;
+}
+__device__ __forceinline__ float4 ld4(const _Float16* p) {
+  const f16x4_st v = *reinterpret_cast<const f16x4_st*>(p);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4(_Float16* p, float4 v) {
+  f16x4_st r;
+  r[0] = (_Float16)v.x;
+  r[1] = (_Float16)v.y;
+  r[2] = (_Float16)v.z;
+  r[3] = (_Float16)v.w;
+  *reinterpret_cast<f16x4_st*>(p) = r;
+}
+// Launch wrappers take untyped pointers plus a StoreType (elementwise.h); BODY sees the element type as T.
+#define MIMO_ST_DISPATCH(DT, T, ...) \
+  switch (DT) {                      \
+    case ST_BF16: {                  \
+      typedef __bf16 T;              \
+      __VA_ARGS__;                   \
+    } break;                         \
+    case ST_F16: {                   \
+      typedef _Float16 T;            \
+      __VA_ARGS__;                   \
+    } break;                         \
+    default: {                       \
+      typedef float T;               \
+      __VA_ARGS__;                   \
+    } break;                         \
+  }
+// (z type, activation type) pairs of the BatchNorm kernels: z is fp32 where the convolution that wrote it runs on the
+// fp32 kernel family (the 2..4-channel image convolution) even in the 16-bit storage modes
+#define MIMO_ST_DISPATCH2(DTZ, DTA, TZ, TA, ...) \
+  if ((DTZ) == ST_F32) {                         \
+    typedef float TZ;                            \
+    MIMO_ST_DISPATCH(DTA, TA, __VA_ARGS__)       \
+  } else if ((DTA) == ST_BF16) {                 \
+    typedef __bf16 TZ;                           \
+    typedef __bf16 TA;                           \
+    __VA_ARGS__;                                 \
+  } else {                                       \
+    typedef _Float16 TZ;                         \
+    typedef _Float16 TA;                         \
+    __VA_ARGS__;                                 \
+  }
+
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4max(float4 a, float4 b) {
@@ -82,8 +141,9 @@ __device__ __forceinline__ float4 quad_block_sum(float4 v, const PQ& t, float4* 
 
 // gradient on the reflect-padded domain folded back onto the image (transpose of reflect pad):
 // pad row -1 lands on row 1, pad row H on row H-2 (same for columns).
-__device__ __forceinline__ float4 fold_read(const float* dxpad, int ldp, int n, int y, int x, int H, int W, int ch) {
-  const float* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + ch;
+template <typename T>
+__device__ __forceinline__ float4 fold_read(const T* dxpad, int ldp, int n, int y, int x, int H, int W, int ch) {
+  const T* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + ch;
   float4 s = ld4(base + ((size_t)(y + 1) * (W + 2) + (x + 1)) * ldp);  // interior pixels: this one load
   const bool ya = y == 1, yb = y == H - 2, xa = x == 1, xb = x == W - 2;
   if (ya | yb | xa | xb) {  // rows 1 / H-2 and columns 1 / W-2 also receive the reflected border
@@ -312,7 +372,8 @@ int pack_input_launch(const float* x, int64_t stride_n, int64_t stride_s, const 
   return MIMO_OK;
 }
 
-__global__ void unpack_dx_kernel(const float* __restrict__ dxpad, int ldp, int N, int S, int s, int C, int H, int W,
+template <typename T>
+__global__ void unpack_dx_kernel(const T* __restrict__ dxpad, int ldp, int N, int S, int s, int C, int H, int W,
                                  float* __restrict__ dx) {
   const int64_t total = (int64_t)N * H * W;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -327,10 +388,11 @@ __global__ void unpack_dx_kernel(const float* __restrict__ dxpad, int ldp, int N
   }
 }
 
-int unpack_dx_launch(const float* dxpad, int ldp, int N, int S, int s, int C, int H, int W, float* dx, hipStream_t st) {
+int unpack_dx_launch(const void* dxpad, int dt, int ldp, int N, int S, int s, int C, int H, int W, float* dx, hipStream_t st) {
   const int64_t total = (int64_t)N * H * W;
   const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 4096);
-  hipLaunchKernelGGL(unpack_dx_kernel, dim3(blocks), dim3(256), 0, st, dxpad, ldp, N, S, s, C, H, W, dx);
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(unpack_dx_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)dxpad, ldp, N, S, s,
+                                             C, H, W, dx));
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -466,7 +528,8 @@ __device__ __forceinline__ float4 mask4(const float* mask, int n, int C, int c0)
   return m;
 }
 
-__global__ void bn_relu_fwd_kernel(const float* __restrict__ z, int ldz, float* __restrict__ a, int lda,
+template <typename TZ, typename TA>
+__global__ void bn_relu_fwd_kernel(const TZ* __restrict__ z, int ldz, TA* __restrict__ a, int lda,
                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                    const float* __restrict__ mask, int C, int Cv, int P, int HW) {
   const PQ t = pixquad(Cv);
@@ -490,11 +553,12 @@ __global__ void bn_relu_fwd_kernel(const float* __restrict__ z, int ldz, float* 
   }
 }
 
-int bn_relu_fwd_launch(const float* z, int ldz, float* a, int lda, const float* scale, const float* shift,
+int bn_relu_fwd_launch(const void* z, int dtz, int ldz, void* a, int dta, int lda, const float* scale, const float* shift,
                        const float* mask, int C, int Cp, int64_t P, int HW, hipStream_t st) {
   const int Cv = Cp / 4;
-  hipLaunchKernelGGL(bn_relu_fwd_kernel, pq_grid(Cv, P, kBlocksBnRelu), dim3(256), 0, st, z, ldz, a, lda, scale, shift, mask, C,
-                     Cv, (int)P, HW);
+  MIMO_ST_DISPATCH2(dtz, dta, TZ, TA,
+                    hipLaunchKernelGGL((bn_relu_fwd_kernel<TZ, TA>), pq_grid(Cv, P, kBlocksBnRelu), dim3(256), 0, st,
+                                       (const TZ*)z, ldz, (TA*)a, lda, scale, shift, mask, C, Cv, (int)P, HW))
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -502,10 +566,11 @@ int bn_relu_fwd_launch(const float* z, int ldz, float* a, int lda, const float* 
 // BatchNorm + ReLU (+ Dropout2d multipliers) of a tensor whose only spatial consumer is MaxPool2d(2): one thread
 // owns a 2x2 window, writes its four activations and their maximum into the pooled tensor — the separate
 // pooling pass (a second read of the activation) disappears.  Same arithmetic, bit-identical results.
-__global__ void bn_relu_pool_fwd_kernel(const float* __restrict__ z, int ldz, float* __restrict__ a, int lda,
+template <typename TZ, typename TA>
+__global__ void bn_relu_pool_fwd_kernel(const TZ* __restrict__ z, int ldz, TA* __restrict__ a, int lda,
                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                         const float* __restrict__ mask, int C, int Cv, int N, int H, int W,
-                                        float* __restrict__ pool, int ldpool) {
+                                        TA* __restrict__ pool, int ldpool) {
   const PQ t = pixquad(Cv);
   if (!t.active) return;
   const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q);
@@ -524,14 +589,15 @@ __global__ void bn_relu_pool_fwd_kernel(const float* __restrict__ z, int ldz, fl
     const int n = it.n, py = it.y, px = it.x;
     const float4 m = mask ? mask4(mask, n, C, 4 * t.q) : make_float4(1.f, 1.f, 1.f, 1.f);
     const size_t pix = ((size_t)n * H + 2 * py) * W + 2 * px;
-    const float* zs = z + pix * ldz + 4 * t.q;
-    float* as = a + pix * lda + 4 * t.q;
+    const TZ* zs = z + pix * ldz + 4 * t.q;
+    TA* as = a + pix * lda + 4 * t.q;
     const float4 z00 = ld4(zs), z01 = ld4(zs + ldz), z10 = ld4(zs + (size_t)W * ldz), z11 = ld4(zs + (size_t)(W + 1) * ldz);
     const float4 r00 = act(z00, m), r01 = act(z01, m), r10 = act(z10, m), r11 = act(z11, m);
     st4(as, r00);
     st4(as + lda, r01);
     st4(as + (size_t)W * lda, r10);
     st4(as + (size_t)(W + 1) * lda, r11);
+    // rounding to the storage type is monotonic: max of the rounded values == rounded max
     st4(pool + (size_t)p * ldpool + 4 * t.q, f4max(f4max(r00, r01), f4max(r10, r11)));
     // odd sizes: the last column / row belongs to no window but is still an activation
     if ((W & 1) && px == Wp - 1) {
@@ -546,11 +612,13 @@ __global__ void bn_relu_pool_fwd_kernel(const float* __restrict__ z, int ldz, fl
   }
 }
 
-int bn_relu_pool_fwd_launch(const float* z, int ldz, float* a, int lda, const float* scale, const float* shift,
-                            const float* mask, int C, int Cp, int N, int H, int W, float* pool, int ldpool, hipStream_t st) {
+int bn_relu_pool_fwd_launch(const void* z, int dtz, int ldz, void* a, int dta, int lda, const float* scale, const float* shift,
+                            const float* mask, int C, int Cp, int N, int H, int W, void* pool, int ldpool, hipStream_t st) {
   const int Cv = Cp / 4;
-  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, pq_grid(Cv, (int64_t)N * (H / 2) * (W / 2), 4096), dim3(256), 0, st, z, ldz, a, lda,
-                     scale, shift, mask, C, Cv, N, H, W, pool, ldpool);
+  MIMO_ST_DISPATCH2(dtz, dta, TZ, TA,
+                    hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<TZ, TA>), pq_grid(Cv, (int64_t)N * (H / 2) * (W / 2), 4096),
+                                       dim3(256), 0, st, (const TZ*)z, ldz, (TA*)a, lda, scale, shift, mask, C, Cv, N, H, W,
+                                       (TA*)pool, ldpool))
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -559,8 +627,9 @@ int bn_relu_pool_fwd_launch(const float* z, int ldz, float* a, int lda, const fl
 // max pooling 2x2 (floor) and bilinear x2 upsample + zero pad + concat
 // ---------------------------------------------------------------------------------------
 
-__global__ void maxpool_fwd_kernel(const float* __restrict__ a, int lda, int N, int H, int W, int Cv,
-                                   float* __restrict__ out, int ldo) {
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ a, int lda, int N, int H, int W, int Cv,
+                                   T* __restrict__ out, int ldo) {
   const PQ t = pixquad(Cv);
   if (!t.active) return;
   const int Ho = H / 2, Wo = W / 2;
@@ -568,16 +637,17 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ a, int lda, int N, 
   PixIter it = pix_iter(t.p, t.pstep, Ho, Wo);
   for (int p = t.p; p < P; p += t.pstep, pix_next(it, Ho, Wo)) {
     const int n = it.n, oy = it.y, ox = it.x;
-    const float* src = a + (((size_t)n * H + 2 * oy) * W + 2 * ox) * lda + 4 * t.q;
+    const T* src = a + (((size_t)n * H + 2 * oy) * W + 2 * ox) * lda + 4 * t.q;
     const float4 v = f4max(f4max(ld4(src), ld4(src + lda)), f4max(ld4(src + (size_t)W * lda), ld4(src + (size_t)(W + 1) * lda)));
     st4(out + (size_t)p * ldo + 4 * t.q, v);
   }
 }
 
-int maxpool_fwd_launch(const float* a, int lda, int N, int H, int W, int Cp, float* out, int ldo, hipStream_t st) {
+int maxpool_fwd_launch(const void* a, int dt, int lda, int N, int H, int W, int Cp, void* out, int ldo, hipStream_t st) {
   const int Cv = Cp / 4;
   const int64_t P = (int64_t)N * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, pq_grid(Cv, P, 4096), dim3(256), 0, st, a, lda, N, H, W, Cv, out, ldo);
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, pq_grid(Cv, P, 4096), dim3(256), 0, st, (const T*)a, lda, N, H,
+                                             W, Cv, (T*)out, ldo));
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -610,9 +680,10 @@ __device__ __forceinline__ float lerp_weight(int o, int i, int in) {
   return (l.i0 == i ? l.l0 : 0.f) + (l.i1 == i ? l.l1 : 0.f);
 }
 
-__global__ void upcat_fwd_kernel(const float* __restrict__ skip, int lds, int csv, const float* __restrict__ low,
+template <typename T>
+__global__ void upcat_fwd_kernel(const T* __restrict__ skip, int lds, int csv, const T* __restrict__ low,
                                  int ldl, int clv, int N, int H, int W, int h, int w, int padT, int padL,
-                                 float* __restrict__ out) {
+                                 T* __restrict__ out) {
   const int Cv = csv + clv;
   // skip == nullptr: the skip tensor already lives in channels [0, 4*csv) of `out` (its producer writes it
   // there); only the up-sampled part is written, and the threads are mapped over those channels alone
@@ -632,7 +703,7 @@ __global__ void upcat_fwd_kernel(const float* __restrict__ skip, int lds, int cs
       v = f4zero();
       if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w) {
         const Lerp ly = lerp_src(uy, h, 2 * h), lx = lerp_src(ux, w, 2 * w);
-        const float* b = low + (size_t)n * h * w * ldl + 4 * (t.q - csv);
+        const T* b = low + (size_t)n * h * w * ldl + 4 * (t.q - csv);
         const float4 v00 = ld4(b + ((size_t)ly.i0 * w + lx.i0) * ldl), v01 = ld4(b + ((size_t)ly.i0 * w + lx.i1) * ldl);
         const float4 v10 = ld4(b + ((size_t)ly.i1 * w + lx.i0) * ldl), v11 = ld4(b + ((size_t)ly.i1 * w + lx.i1) * ldl);
         v.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
@@ -645,16 +716,17 @@ __global__ void upcat_fwd_kernel(const float* __restrict__ skip, int lds, int cs
   }
 }
 
-int upcat_fwd_launch(const float* skip, int lds, int csp, const float* low, int ldl, int clp, int N, int H, int W,
-                     int h, int w, float* out, hipStream_t st) {
+int upcat_fwd_launch(const void* skip, int dt, int lds, int csp, const void* low, int ldl, int clp, int N, int H, int W,
+                     int h, int w, void* out, hipStream_t st) {
   const int Cv = (csp + clp) / 4;
   const int padT = (H - 2 * h) / 2, padL = (W - 2 * w) / 2;  // F.pad(diff//2, diff - diff//2), components.py:110-115
   if (H < 2 * h || W < 2 * w) {
     set_error("upcat: skip smaller than upsampled input");
     return MIMO_ERR_INVALID;
   }
-  hipLaunchKernelGGL(upcat_fwd_kernel, pq_grid(skip ? Cv : clp / 4, (int64_t)N * H * W, 4096), dim3(256), 0, st, skip, lds,
-                     csp / 4, low, ldl, clp / 4, N, H, W, h, w, padT, padL, out);
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(upcat_fwd_kernel<T>, pq_grid(skip ? Cv : clp / 4, (int64_t)N * H * W, 4096), dim3(256), 0,
+                                             st, (const T*)skip, lds, csp / 4, (const T*)low, ldl, clp / 4, N, H, W, h, w, padT, padL,
+                                             (T*)out));
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -678,9 +750,10 @@ __device__ __forceinline__ float route_max(float g, float v00, float v01, float 
 // (channels [0, Cp) of its own buffer, pixel pitch ldsk) is folded and added here, so the skip slice is never
 // copied out (da = pool route + skip fold, the same two operands in the same order as the former
 // fold_slice + accumulating pool_bwd pair).
-__global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int choff, const float* __restrict__ a,
-                                int lda, float* __restrict__ da, int ldda, int N, int H, int W, int Cv, int accumulate,
-                                const float* __restrict__ skip, int ldsk) {
+template <typename T>
+__global__ void pool_bwd_kernel(const T* __restrict__ dxpad, int ldp, int choff, const T* __restrict__ a,
+                                int lda, T* __restrict__ da, int ldda, int N, int H, int W, int Cv, int accumulate,
+                                const T* __restrict__ skip, int ldsk) {
   const PQ t = pixquad(Cv);
   if (!t.active) return;
   const int Hp = H / 2, Wp = W / 2;
@@ -690,9 +763,9 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int ch
     const int n = it.n, py = it.y, px = it.x;
     const float4 g = fold_read(dxpad, ldp, n, py, px, Hp, Wp, choff + 4 * t.q);
     const size_t pix = ((size_t)n * H + 2 * py) * W + 2 * px;
-    const float* src = a + pix * lda + 4 * t.q;
+    const T* src = a + pix * lda + 4 * t.q;
     const float4 v00 = ld4(src), v01 = ld4(src + lda), v10 = ld4(src + (size_t)W * lda), v11 = ld4(src + (size_t)(W + 1) * lda);
-    float* dst = da + pix * ldda + 4 * t.q;
+    T* dst = da + pix * ldda + 4 * t.q;
     float4 r[4];
 #pragma unroll
     for (int self = 0; self < 4; ++self) {
@@ -701,7 +774,7 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int ch
       r[self].z = route_max(g.z, v00.z, v01.z, v10.z, v11.z, self);
       r[self].w = route_max(g.w, v00.w, v01.w, v10.w, v11.w, self);
     }
-    float* d4[4] = {dst, dst + ldda, dst + (size_t)W * ldda, dst + (size_t)(W + 1) * ldda};
+    T* d4[4] = {dst, dst + ldda, dst + (size_t)W * ldda, dst + (size_t)(W + 1) * ldda};
     if (accumulate) {
       float4 o[4];
 #pragma unroll
@@ -733,7 +806,7 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int ch
       }
     } else if (skip) {
       auto rest = [&](int y, int x) {
-        float* d = da + (((size_t)n * H + y) * W + x) * ldda + 4 * t.q;
+        T* d = da + (((size_t)n * H + y) * W + x) * ldda + 4 * t.q;
         st4(d, f4add(ld4(d), fold_read(skip, ldsk, n, y, x, H, W, 4 * t.q)));
       };
       if ((W & 1) && px == Wp - 1) {
@@ -749,16 +822,18 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dxpad, int ldp, int ch
   }
 }
 
-int pool_bwd_launch(const float* dxpad, int ldp, int choff, const float* a, int lda, float* da, int ldda, int N, int H,
-                    int W, int Cp, int accumulate, hipStream_t st, const float* skip, int ldsk) {
+int pool_bwd_launch(const void* dxpad, int dt, int ldp, int choff, const void* a, int lda, void* da, int ldda, int N, int H,
+                    int W, int Cp, int accumulate, hipStream_t st, const void* skip, int ldsk) {
   const int Cv = Cp / 4;
-  hipLaunchKernelGGL(pool_bwd_kernel, pq_grid(Cv, (int64_t)N * (H / 2) * (W / 2), kBlocksPoolBwd), dim3(256), 0, st, dxpad, ldp, choff,
-                     a, lda, da, ldda, N, H, W, Cv, accumulate, skip, ldsk);
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(pool_bwd_kernel<T>, pq_grid(Cv, (int64_t)N * (H / 2) * (W / 2), kBlocksPoolBwd), dim3(256),
+                                             0, st, (const T*)dxpad, ldp, choff, (const T*)a, lda, (T*)da, ldda, N, H, W, Cv,
+                                             accumulate, (const T*)skip, ldsk));
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
 
-__global__ void fold_slice_kernel(const float* __restrict__ dxpad, int ldp, int choff, float* __restrict__ da, int ldda,
+template <typename T>
+__global__ void fold_slice_kernel(const T* __restrict__ dxpad, int ldp, int choff, T* __restrict__ da, int ldda,
                                   int N, int H, int W, int Cv, int accumulate) {
   const PQ t = pixquad(Cv);
   if (!t.active) return;
@@ -766,17 +841,17 @@ __global__ void fold_slice_kernel(const float* __restrict__ dxpad, int ldp, int 
   PixIter it = pix_iter(t.p, t.pstep, H, W);
   for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
     float4 v = fold_read(dxpad, ldp, it.n, it.y, it.x, H, W, choff + 4 * t.q);
-    float* dst = da + (size_t)p * ldda + 4 * t.q;
+    T* dst = da + (size_t)p * ldda + 4 * t.q;
     if (accumulate) v = f4add(v, ld4(dst));
     st4(dst, v);
   }
 }
 
-int fold_slice_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, int N, int H, int W, int Cp,
+int fold_slice_launch(const void* dxpad, int dt, int ldp, int choff, void* da, int ldda, int N, int H, int W, int Cp,
                       int accumulate, hipStream_t st) {
   const int Cv = Cp / 4;
-  hipLaunchKernelGGL(fold_slice_kernel, pq_grid(Cv, (int64_t)N * H * W, 4096), dim3(256), 0, st, dxpad, ldp, choff, da,
-                     ldda, N, H, W, Cv, accumulate);
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(fold_slice_kernel<T>, pq_grid(Cv, (int64_t)N * H * W, 4096), dim3(256), 0, st,
+                                             (const T*)dxpad, ldp, choff, (T*)da, ldda, N, H, W, Cv, accumulate));
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -784,14 +859,15 @@ int fold_slice_launch(const float* dxpad, int ldp, int choff, float* da, int ldd
 // ---- element-wise dropout (nn.Dropout after down4 and in front of each 1x1 head) -------------
 // a[n,p,c] *= mask[n,c,p]: the multipliers arrive in the reference's NCHW layout, so one thread owns a
 // pixel (coalesced mask reads per channel plane) and walks its own contiguous channel row of `a`.
-__global__ void elem_mask_mul_kernel(float* __restrict__ a, int ld, const float* __restrict__ mask, int N, int C, int Cv,
+template <typename T>
+__global__ void elem_mask_mul_kernel(T* __restrict__ a, int ld, const float* __restrict__ mask, int N, int C, int Cv,
                                      int HW) {
   const int64_t P = (int64_t)N * HW;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(p / HW);
     const int r = (int)(p - (int64_t)n * HW);
     const float* m = mask + (size_t)n * C * HW + r;
-    float* row = a + (size_t)p * ld;
+    T* row = a + (size_t)p * ld;
     for (int q = 0; q < Cv; ++q) {
       float4 v = ld4(row + 4 * q);
       const int c = 4 * q;
@@ -804,17 +880,18 @@ __global__ void elem_mask_mul_kernel(float* __restrict__ a, int ld, const float*
   }
 }
 
-int elem_mask_mul_launch(float* a, int ld, const float* mask, int N, int C, int Cp, int HW, hipStream_t st) {
+int elem_mask_mul_launch(void* a, int dt, int ld, const float* mask, int N, int C, int Cp, int HW, hipStream_t st) {
   const int64_t P = (int64_t)N * HW;
   const int blocks = (int)std::min<int64_t>((P + 255) / 256, 4096);
-  hipLaunchKernelGGL(elem_mask_mul_kernel, dim3(blocks), dim3(256), 0, st, a, ld, mask, N, C, Cp / 4, HW);
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(elem_mask_mul_kernel<T>, dim3(blocks), dim3(256), 0, st, (T*)a, ld, mask, N, C, Cp / 4, HW));
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
 
 // Input pixel i of an x2 align_corners upsample is read by outputs 2i-1 .. 2i+2 only (2i-2 lands on
 // i-2 / i-1 for every size; checked exhaustively for in <= 300 and 512..2048 on the CPU).
-__global__ void up_bwd_kernel(const float* __restrict__ dxpad, int ldp, int choff, float* __restrict__ da, int ldda,
+template <typename T>
+__global__ void up_bwd_kernel(const T* __restrict__ dxpad, int ldp, int choff, T* __restrict__ da, int ldda,
                               int N, int H, int W, int h, int w, int padT, int padL, int Cv, int accumulate) {
   const PQ t = pixquad(Cv, true);
   if (!t.active) return;
@@ -836,7 +913,7 @@ __global__ void up_bwd_kernel(const float* __restrict__ dxpad, int ldp, int chof
     if (cy[0] >= 2 && cy[3] <= H - 3 && cx[0] >= 2 && cx[3] <= W - 3) {
       // none of the 16 candidates receives a reflected border: 16 independent loads, weights 0 where the
       // candidate does not read this input (adds an exact zero, same sum as skipping it)
-      const float* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + choff + 4 * t.q;
+      const T* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + choff + 4 * t.q;
       float4 g[4][4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -866,18 +943,18 @@ __global__ void up_bwd_kernel(const float* __restrict__ dxpad, int ldp, int chof
         }
       }
     }
-    float* dst = da + (size_t)p * ldda + 4 * t.q;
+    T* dst = da + (size_t)p * ldda + 4 * t.q;
     if (accumulate) v = f4add(v, ld4(dst));
     st4(dst, v);
   }
 }
 
-int up_bwd_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, int N, int H, int W, int h, int w,
+int up_bwd_launch(const void* dxpad, int dt, int ldp, int choff, void* da, int ldda, int N, int H, int W, int h, int w,
                   int Cp, int accumulate, hipStream_t st) {
   const int Cv = Cp / 4;
   const int padT = (H - 2 * h) / 2, padL = (W - 2 * w) / 2;
-  hipLaunchKernelGGL(up_bwd_kernel, pq_grid(Cv, (int64_t)N * h * w, kBlocksUpBwd), dim3(256), 0, st, dxpad, ldp, choff, da, ldda,
-                     N, H, W, h, w, padT, padL, Cv, accumulate);
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(up_bwd_kernel<T>, pq_grid(Cv, (int64_t)N * h * w, kBlocksUpBwd), dim3(256), 0, st,
+                                             (const T*)dxpad, ldp, choff, (T*)da, ldda, N, H, W, h, w, padT, padL, Cv, accumulate));
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -887,7 +964,8 @@ int up_bwd_launch(const float* dxpad, int ldp, int choff, float* da, int ldda, i
 // ---------------------------------------------------------------------------------------
 // dy = (gradient arriving at the activation) * dropout mask * [relu input > 0], evaluated on the fly by
 // both passes (never stored): the source is a plain NHWC buffer or the padded-domain dgrad output
-__device__ __forceinline__ float4 relu_grad4(const float* da, int ldda, const float* dxpad, int ldp, const float* mask, int C,
+template <typename TA>
+__device__ __forceinline__ float4 relu_grad4(const TA* da, int ldda, const TA* dxpad, int ldp, const float* mask, int C,
                                              int p, const PixIter& it, int q, int H, int W, float4 v, float4 sc, float4 sh) {
   float4 g;
   const int n = it.n;
@@ -910,8 +988,9 @@ __device__ __forceinline__ float4 relu_grad4(const float* da, int ldda, const fl
   return g;
 }
 
-__global__ void bnrelu_bwd_reduce_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ dxpad,
-                                         int ldp, const float* __restrict__ z, int ldz, const float* __restrict__ scale,
+template <typename TZ, typename TA>
+__global__ void bnrelu_bwd_reduce_kernel(const TA* __restrict__ da, int ldda, const TA* __restrict__ dxpad,
+                                         int ldp, const TZ* __restrict__ z, int ldz, const float* __restrict__ scale,
                                          const float* __restrict__ shift, const float* __restrict__ mean,
                                          const float* __restrict__ invstd, const float* __restrict__ mask, int C, int Cv,
                                          int N, int H, int W, float* __restrict__ partial) {
@@ -942,15 +1021,17 @@ __global__ void bnrelu_bwd_reduce_kernel(const float* __restrict__ da, int ldda,
   }
 }
 
-int bnrelu_bwd_reduce_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
+int bnrelu_bwd_reduce_launch(const void* da, int dta, int ldda, const void* dxpad, int ldp, const void* z, int dtz, int ldz,
                              const float* scale, const float* shift, const float* mean, const float* invstd,
                              const float* mask, int C, int Cp, int N, int H, int W, float* partial, int* rows,
                              hipStream_t st) {
   const int Cv = Cp / 4;
   const dim3 grid = pq_grid(Cv, (int64_t)N * H * W, kBlocksBnBwd);
   *rows = grid.x;
-  hipLaunchKernelGGL(bnrelu_bwd_reduce_kernel, grid, dim3(256), 0, st, da, ldda, dxpad, ldp, z, ldz, scale, shift, mean,
-                     invstd, mask, C, Cv, N, H, W, partial);
+  MIMO_ST_DISPATCH2(dtz, dta, TZ, TA,
+                    hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<TZ, TA>), grid, dim3(256), 0, st, (const TA*)da, ldda,
+                                       (const TA*)dxpad, ldp, (const TZ*)z, ldz, scale, shift, mean, invstd, mask, C, Cv, N, H, W,
+                                       partial))
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1046,12 +1127,13 @@ int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStrea
   return MIMO_OK;
 }
 
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, const float* __restrict__ dxpad, int ldp,
-                                    const float* __restrict__ z, int ldz, const float* __restrict__ scale,
+template <typename TZ, typename TA>
+__global__ void bn_bwd_apply_kernel(const TA* __restrict__ da, int ldda, const TA* __restrict__ dxpad, int ldp,
+                                    const TZ* __restrict__ z, int ldz, const float* __restrict__ scale,
                                     const float* __restrict__ shift, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ mask, int C,
                                     const float* __restrict__ c1, const float* __restrict__ c2, int Cv, int N, int H,
-                                    int W, float* __restrict__ dz, int split_out, float* __restrict__ partial) {
+                                    int W, TA* __restrict__ dz, int split_out, float* __restrict__ partial) {
   __shared__ float4 red[256];
   const PQ t = pixquad(Cv);
   const int Cp = 4 * Cv;
@@ -1069,8 +1151,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, cons
       r.y = sc.y * (g.y - k1.y - (v.y - mu.y) * is.y * k2.y);
       r.z = sc.z * (g.z - k1.z - (v.z - mu.z) * is.z * k2.z);
       r.w = sc.w * (g.w - k1.w - (v.w - mu.w) * is.w * k2.w);
-      if (split_out)
-        st_split4(dz, p, Cp, t.q, r);
+      if (split_out)  // fp32 storage only: bf16 (hi, lo) pair records
+        st_split4(reinterpret_cast<float*>(dz), p, Cp, t.q, r);
       else
         st4(dz + (size_t)p * Cp + 4 * t.q, r);
       acc = f4add(acc, r);
@@ -1081,15 +1163,21 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda, cons
   if (t.pl == 0 && t.q < Cv) st4(partial + (size_t)blockIdx.x * Cp + 4 * t.q, s);
 }
 
-int bn_bwd_apply_launch(const float* da, int ldda, const float* dxpad, int ldp, const float* z, int ldz,
+int bn_bwd_apply_launch(const void* da, int dta, int ldda, const void* dxpad, int ldp, const void* z, int dtz, int ldz,
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
-                        int C, const float* c1, const float* c2, int Cp, int N, int H, int W, float* dz, int split_out,
+                        int C, const float* c1, const float* c2, int Cp, int N, int H, int W, void* dz, int split_out,
                         float* partial, int* rows, hipStream_t st) {
   const int Cv = Cp / 4;
   const dim3 grid = pq_grid(Cv, (int64_t)N * H * W, kBlocksBnBwd);
   *rows = grid.x;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, da, ldda, dxpad, ldp, z, ldz, scale, shift, mean, invstd,
-                     mask, C, c1, c2, Cv, N, H, W, dz, split_out, partial);
+  if (split_out && dta != ST_F32) {
+    set_error("bn_bwd_apply: pair-split dz exists for fp32 storage only");
+    return MIMO_ERR_INVALID;
+  }
+  MIMO_ST_DISPATCH2(dtz, dta, TZ, TA,
+                    hipLaunchKernelGGL((bn_bwd_apply_kernel<TZ, TA>), grid, dim3(256), 0, st, (const TA*)da, ldda, (const TA*)dxpad,
+                                       ldp, (const TZ*)z, ldz, scale, shift, mean, invstd, mask, C, c1, c2, Cv, N, H, W, (TA*)dz,
+                                       split_out, partial))
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1101,8 +1189,8 @@ int bn_bwd_apply_launch(const float* da, int ldda, const float* dxpad, int ldp, 
 // channel row — a wave reads 64 consecutive float4, fully coalesced — multiplies it with its slice of the
 // 1x1 weights, and a butterfly of G-lane shuffles completes the Co dot products.  (One thread per pixel
 // reading its own 128-byte row touched 64 cache lines per load instruction and ran at 1 TB/s.)
-template <int G>
-__global__ void head_fwd_kernel(const float* __restrict__ a, int lda, const float* __restrict__ w,
+template <int G, typename T>
+__global__ void head_fwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
                                 const float* __restrict__ bias, int C, int Cp, int Co, int N, int S, int s, int HW,
                                 float* __restrict__ out) {
   const int g = threadIdx.x % G, pl = threadIdx.x / G;
@@ -1135,7 +1223,7 @@ __global__ void head_fwd_kernel(const float* __restrict__ a, int lda, const floa
   }
 }
 
-int head_fwd_launch(const float* a, int lda, const float* w, const float* bias, int C, int Co, int N, int S, int s,
+int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float* bias, int C, int Co, int N, int S, int s,
                     int HW, float* out, hipStream_t st) {
   if (Co > kMaxHeadOut || C > 256) {
     set_error("head: out_channels %d > %d or filter_base_count %d > 256 unsupported", Co, kMaxHeadOut, C);
@@ -1147,7 +1235,8 @@ int head_fwd_launch(const float* a, int lda, const float* w, const float* bias, 
   const int64_t P = (int64_t)N * HW;
   const int blocks = (int)std::min<int64_t>(ceil_div64(P, 256 / G), 4096);
 #define HEAD_LAUNCH(GG)                                                                                              \
-  hipLaunchKernelGGL(head_fwd_kernel<GG>, dim3(blocks), dim3(256), 0, st, a, lda, w, bias, C, Cp, Co, N, S, s, HW, out)
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL((head_fwd_kernel<GG, T>), dim3(blocks), dim3(256), 0, st, (const T*)a, lda, w, bias, C, \
+                                             Cp, Co, N, S, s, HW, out))
   switch (G) {
     case 2: HEAD_LAUNCH(2); break;
     case 4: HEAD_LAUNCH(4); break;
@@ -1242,12 +1331,13 @@ int loss_finalize_launch(const float* partial, int S, int blocks, double count, 
   return MIMO_OK;
 }
 
-__global__ void head_bwd_kernel(const float* __restrict__ a, int lda, const float* __restrict__ w, int C, int Cv, int Co,
+template <typename T>
+__global__ void head_bwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w, int C, int Cv, int Co,
                                 int N, int S, int s, int HW, const float* __restrict__ out,
                                 const float* __restrict__ dout, const float* __restrict__ dloss,
                                 const float* __restrict__ label, const float* __restrict__ mask,
                                 const int64_t* __restrict__ perm, int kind, float eps_min, float eps_max, float inv_count,
-                                float* __restrict__ da, float* __restrict__ partial) {
+                                T* __restrict__ da, float* __restrict__ partial) {
   __shared__ float4 red[256];
   const PQ t = pixquad(Cv);
   const int Cp = 4 * Cv, Ct = Co / 2;
@@ -1326,9 +1416,9 @@ __global__ void head_bwd_kernel(const float* __restrict__ a, int lda, const floa
   }
 }
 
-int head_bwd_launch(const float* a, int lda, const float* w, int C, int Cp, int Co, int N, int S, int s, int HW,
+int head_bwd_launch(const void* a, int dt, int lda, const float* w, int C, int Cp, int Co, int N, int S, int s, int HW,
                     const float* out, const float* dout, const float* dloss, const float* label, const float* mask,
-                    const int64_t* perm, int kind, float eps_min, float eps_max, float* da, float* partial, int* rows,
+                    const int64_t* perm, int kind, float eps_min, float eps_max, void* da, float* partial, int* rows,
                     hipStream_t st) {
   if (Co > kMaxHeadOut || (Co & 1)) {
     set_error("head: out_channels %d unsupported", Co);
@@ -1339,8 +1429,8 @@ int head_bwd_launch(const float* a, int lda, const float* w, int C, int Cp, int 
   grid.y = 1;  // Cv <= 64 for the head (filter_base_count <= 256)
   *rows = grid.x;
   const float inv_count = 1.f / (float)((double)N * (Co / 2) * HW);
-  hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(256), 0, st, a, lda, w, C, Cv, Co, N, S, s, HW, out, dout, dloss, label,
-                     mask, perm, kind, eps_min, eps_max, inv_count, da, partial);
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(head_bwd_kernel<T>, grid, dim3(256), 0, st, (const T*)a, lda, w, C, Cv, Co, N, S, s, HW,
+                                             out, dout, dloss, label, mask, perm, kind, eps_min, eps_max, inv_count, (T*)da, partial));
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

@@ -171,7 +171,7 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
     MIMO_TRY(conv3x3_bf16x3_launch(a, bf16 ? 3 : 0, nullptr, st));
   else
     MIMO_TRY(conv3x3_launch(a, nullptr, st));
-  MIMO_TRY(fold_slice_launch(dxpad, cin_p, 0, dx, cin_p, n, h, wd, cin_p, 0, st));
+  MIMO_TRY(fold_slice_launch(dxpad, ST_F32, cin_p, 0, dx, cin_p, n, h, wd, cin_p, 0, st));
   MIMO_HIP_CHECK(hipStreamSynchronize(st));
   return MIMO_OK;
 }
@@ -233,13 +233,13 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
 }
 
 int mimo_op_maxpool2x2(const float* x, float* y, int32_t n, int32_t h, int32_t w, int32_t c_p, mimo_stream stream) {
-  MIMO_TRY(maxpool_fwd_launch(x, c_p, n, h, w, c_p, y, c_p, (hipStream_t)stream));
+  MIMO_TRY(maxpool_fwd_launch(x, ST_F32, c_p, n, h, w, c_p, y, c_p, (hipStream_t)stream));
   return MIMO_OK;
 }
 
 int mimo_op_upsample_cat(const float* skip, const float* low, float* out, int32_t n, int32_t hs, int32_t ws, int32_t cs_p,
                          int32_t hl, int32_t wl, int32_t cl_p, mimo_stream stream) {
-  MIMO_TRY(upcat_fwd_launch(skip, cs_p, cs_p, low, cl_p, cl_p, n, hs, ws, hl, wl, out, (hipStream_t)stream));
+  MIMO_TRY(upcat_fwd_launch(skip, ST_F32, cs_p, cs_p, low, cl_p, cl_p, n, hs, ws, hl, wl, out, (hipStream_t)stream));
   return MIMO_OK;
 }
 

@@ -10,9 +10,25 @@
 
 namespace mimo {
 
+// amp (loss-scaled training, torch.cuda.amp.GradScaler protocol): step_dev counts the optimiser steps ON THE DEVICE —
+// amp_step_kernel advances it unless the scaler found an inf / nan — and the update below then derives its bias
+// corrections from it, divides the gradients by *amp_scale and is skipped as a whole when *found_inf != 0: no
+// host synchronisation anywhere in the step.
+__global__ void amp_step_kernel(float* __restrict__ step_dev, const float* __restrict__ found_inf) {
+  if (!found_inf || *found_inf == 0.f) *step_dev += 1.f;
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
-                            float bc1, float bc2_sqrt, float grad_scale) {
+                            float bc1, float bc2_sqrt, float grad_scale, const float* __restrict__ step_dev,
+                            const float* __restrict__ amp_scale, const float* __restrict__ found_inf) {
+  if (found_inf && *found_inf != 0.f) return;  // the scaler saw an inf / nan gradient: skip this step
+  if (step_dev) {
+    const float t = *step_dev;
+    bc1 = 1.f - powf(beta1, t);
+    bc2_sqrt = sqrtf(1.f - powf(beta2, t));
+  }
+  if (amp_scale) grad_scale /= *amp_scale;
   const int64_t n4 = n / 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -303,7 +319,26 @@ extern "C" int mimo_adam_step(float* params, const float* grads, float* exp_avg,
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const int blocks = (int)std::min<int64_t>(ceil_div64(n / 4 + 1, 256), 2048);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
-                     lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+                     lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_adam_step_amp(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, float* step_dev, float grad_scale,
+                                  const float* amp_scale, const float* found_inf, mimo_stream stream) {
+  using namespace mimo;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || !step_dev) {
+    set_error("mimo_adam_step_amp: invalid argument");
+    return MIMO_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(amp_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, found_inf);
+  MIMO_KERNEL_CHECK();
+  if (n == 0) return MIMO_OK;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(n / 4 + 1, 256), 2048);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
+                     lr, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale, (const float*)step_dev, amp_scale, found_inf);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

@@ -72,6 +72,7 @@ struct ConvBN {
   bool fwd_split = false, dg_split = false, wg_split = false;
   int *cin_map = nullptr, *fwd_row_map = nullptr, *dg_row_map = nullptr, *dg_col_map = nullptr;
   float* z = nullptr;
+  int dtz = ST_F32;  // element type of z: the plan's storage type, fp32 where the fp32 kernel family writes it
   float *mean = nullptr, *invstd = nullptr, *scale = nullptr, *shift = nullptr, *c1 = nullptr, *c2 = nullptr;
   const float* in = nullptr;
   int ld_in = 0;
@@ -116,6 +117,21 @@ using namespace mimo;
 struct mimo_plan {
   mimo_config cfg;
   int S, f, N, H, W, Ci, Co, Ci_p;
+  // 16-bit storage modes (MIMO_PREC_BF16_MIXED / MIMO_PREC_FP16_MIXED): activations, conv outputs and their gradients
+  // live in HBM as bf16 / fp16 (st, esz bytes per element); every "float*" of such a tensor is then an untyped byte
+  // address and channel offsets go through eoff()
+  bool mixed = false, f16 = false;
+  int st = ST_F32, esz = 4;
+  float* eoff(float* p, size_t elems) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + elems * esz); }
+  int alloc_act(float** p, size_t elems, int dt) {  // activation-like tensor of `elems` elements of StoreType dt
+    return dalloc(p, (elems * store_bytes(dt) + 3) / 4);
+  }
+  int fwd_mode() const {  // conv3x3_bf16x3_launch modes
+    return cfg.precision == MIMO_PREC_BF16 ? 2 : cfg.precision == MIMO_PREC_BF16_MIXED ? 4 : cfg.precision == MIMO_PREC_FP16_MIXED ? 6 : 1;
+  }
+  int dgrad_mode() const {
+    return cfg.precision == MIMO_PREC_BF16 ? 3 : cfg.precision == MIMO_PREC_BF16_MIXED ? 5 : cfg.precision == MIMO_PREC_FP16_MIXED ? 7 : 0;
+  }
   std::vector<TensorInfo> tensors;
   int64_t param_floats = 0, buffer_floats = 0;
   float *params = nullptr, *grads = nullptr, *bnbuf = nullptr;
@@ -351,7 +367,7 @@ struct mimo_plan {
     L.N = n;
     L.H = h;
     L.W = w;
-    const bool mfma16 = cfg.precision == MIMO_PREC_SPLIT16 || cfg.precision == MIMO_PREC_BF16;
+    const bool mfma16 = cfg.precision != MIMO_PREC_FP32;
     L.wg_split = mfma16;
     if (L.wg_split) {
       int CI, CO;
@@ -375,8 +391,10 @@ struct mimo_plan {
     if (train_bufs) MIMO_TRY(dalloc(&L.wd, (size_t)9 * L.dg_rows * L.cout_p));
     MIMO_TRY(dalloc(&L.bias_p, L.cout_pad));
     // split-bf16 MFMA needs a K chunk of 32 channels; the 2..4-channel image conv stays on the fp32 kernel
-    L.fwd_split = mfma16 && L.cin_p >= 16;
-    L.dg_split = mfma16 && L.cout_p >= 16;
+    // (16-bit storage: every layer but the image convolution runs on the 16-bit kernels, whose loaders move 8-channel units)
+    L.fwd_split = mfma16 && L.cin_p >= (mixed ? 8 : 16);
+    L.dg_split = mfma16 && (mixed || L.cout_p >= 16);
+    L.dtz = L.fwd_split ? st : ST_F32;
     if (L.wg_split && !L.dg_split) any_mixed_dz = true;
     if (L.fwd_split) {
       uint16_t* q = nullptr;
@@ -396,7 +414,8 @@ struct mimo_plan {
     MIMO_TRY(upload_ints(&L.fwd_row_map, frm));
     MIMO_TRY(upload_ints(&L.dg_row_map, drm));
     MIMO_TRY(upload_ints(&L.dg_col_map, dcm));
-    if (train_bufs) MIMO_TRY(dalloc(&L.z, (size_t)n * h * w * L.cout_p));
+    // (16-bit storage: the image convolution runs on the fp32 kernels and always goes through an fp32 z)
+    if (train_bufs || (mixed && !L.fwd_split)) MIMO_TRY(alloc_act(&L.z, (size_t)n * h * w * L.cout_p, L.dtz));
     MIMO_TRY(dalloc(&L.mean, L.cout_p));
     MIMO_TRY(dalloc(&L.invstd, L.cout_p));
     MIMO_TRY(dalloc(&L.scale, L.cout_p));
@@ -428,7 +447,7 @@ struct mimo_plan {
     for (size_t i = 0; i < midmap.size(); ++i) midmap[i] = (int)i < Cmid ? (int)i : -1;
     MIMO_TRY(init_convbn(dc->c2, prefix, 3, 4, Cmid, Cout, midmap, N, h, w));
     dc->p_end = param_floats;
-    MIMO_TRY(dalloc(&dc->mid, (size_t)N * h * w * dc->c1.cout_p));
+    MIMO_TRY(alloc_act(&dc->mid, (size_t)N * h * w * dc->c1.cout_p, st));
     Act& o = dc->out;
     o.N = N;
     o.H = h;
@@ -443,8 +462,8 @@ struct mimo_plan {
       o.da = out_da;
       o.ldda = out_ldda;
     } else {
-      MIMO_TRY(dalloc(&o.a, (size_t)N * h * w * o.Cp));
-      if (!cfg.inference_only) MIMO_TRY(dalloc(&o.da, (size_t)N * h * w * o.Cp));
+      MIMO_TRY(alloc_act(&o.a, (size_t)N * h * w * o.Cp, st));
+      if (!cfg.inference_only) MIMO_TRY(alloc_act(&o.da, (size_t)N * h * w * o.Cp, st));
       o.ld = o.ldda = o.Cp;
     }
     dc->c1.a = dc->mid;
@@ -467,7 +486,7 @@ struct mimo_plan {
     sk.ld = up->in_ld;
     for (auto& pr : producers) {
       DoubleConv* dc = pr.first;
-      dc->c2.a = up->in_buf + pr.second;
+      dc->c2.a = eoff(up->in_buf, pr.second);
       dc->c2.ld_a = up->in_ld;
       dc->out.a = dc->c2.a;
       dc->out.ld = up->in_ld;
@@ -479,11 +498,11 @@ struct mimo_plan {
     dc->kind = kind;
     dc->src0 = s0;
     dc->src1 = s1;
-    MIMO_TRY(dalloc(&dc->in_buf, (size_t)N * h * w * in_cp));
+    MIMO_TRY(alloc_act(&dc->in_buf, (size_t)N * h * w * in_cp, kind == IN_IMAGE ? ST_F32 : st));  // the packed image stays fp32
     if (kind == IN_POOL) s0->pooled = true;
     static const bool skip_keep = !(getenv("MIMO_SKIP_GRAD_IN_PLACE") && atoi(getenv("MIMO_SKIP_GRAD_IN_PLACE")) == 0);
     if (kind == IN_UPCAT && skip_keep && s0->pooled && !cfg.inference_only)
-      MIMO_TRY(dalloc(&dc->dxpad_own, (size_t)N * (h + 2) * (w + 2) * in_cp));
+      MIMO_TRY(alloc_act(&dc->dxpad_own, (size_t)N * (h + 2) * (w + 2) * in_cp, st));
     dc->in_ld = in_cp;
     dc->c1.in = dc->in_buf;
     dc->c1.ld_in = in_cp;
@@ -497,6 +516,14 @@ struct mimo_plan {
   }
 
   int build() {
+    mixed = cfg.precision == MIMO_PREC_BF16_MIXED || cfg.precision == MIMO_PREC_FP16_MIXED;
+    f16 = cfg.precision == MIMO_PREC_FP16_MIXED;
+    st = !mixed ? ST_F32 : f16 ? ST_F16 : ST_BF16;
+    esz = store_bytes(st);
+    if (cfg.precision < MIMO_PREC_FP32 || cfg.precision > MIMO_PREC_FP16_MIXED) {
+      set_error("unknown precision %d", cfg.precision);
+      return MIMO_ERR_INVALID;
+    }
     S = cfg.num_subnetworks;
     f = cfg.filter_base_count;
     N = cfg.batch;
@@ -535,16 +562,16 @@ struct mimo_plan {
     x2cat.C = 2 * f * S;
     x2cat.Cp = c2p * S;
     x2cat.ld = x2cat.ldda = x2cat.Cp;
-    MIMO_TRY(dalloc(&x2cat.a, (size_t)N * H2 * W2 * x2cat.Cp));
-    if (!cfg.inference_only) MIMO_TRY(dalloc(&x2cat.da, (size_t)N * H2 * W2 * x2cat.Cp));
+    MIMO_TRY(alloc_act(&x2cat.a, (size_t)N * H2 * W2 * x2cat.Cp, st));
+    if (!cfg.inference_only) MIMO_TRY(alloc_act(&x2cat.da, (size_t)N * H2 * W2 * x2cat.Cp, st));
     x2cat.chmap.assign(x2cat.Cp, -1);
     for (int s = 0; s < S; ++s)
       for (int c = 0; c < 2 * f; ++c) x2cat.chmap[s * c2p + c] = s * 2 * f + c;
     for (int s = 0; s < S; ++s) {
       DoubleConv* dc;
       MIMO_TRY(make_dc(&dc, "encoder.down1s." + std::to_string(s) + ".conv.double_conv", enc_in[s]->out.chmap, f, 2 * f,
-                       2 * f, H2, W2, cfg.encoder_dropout_rate, x2cat.a + s * c2p, x2cat.Cp, x2cat.da + s * c2p,
-                       x2cat.Cp));
+                       2 * f, H2, W2, cfg.encoder_dropout_rate, eoff(x2cat.a, (size_t)s * c2p), x2cat.Cp,
+                       x2cat.da ? eoff(x2cat.da, (size_t)s * c2p) : nullptr, x2cat.Cp));
       MIMO_TRY(set_input(dc, IN_POOL, &enc_in[s]->out, nullptr, enc_in[s]->out.Cp, H2, W2));
       down1.push_back(dc);
     }
@@ -587,8 +614,8 @@ struct mimo_plan {
     }
     // MaxPool2d inputs are produced by the BatchNorm + ReLU pass of the tensor they pool (one pass less per Down block)
     if (!(getenv("MIMO_POOL_FUSED") && atoi(getenv("MIMO_POOL_FUSED")) == 0)) {
-      auto fuse = [](DoubleConv* producer, DoubleConv* consumer, int choff) {
-        producer->c2.pool_out = consumer->in_buf + choff;
+      auto fuse = [this](DoubleConv* producer, DoubleConv* consumer, int choff) {
+        producer->c2.pool_out = eoff(consumer->in_buf, choff);
         producer->c2.pool_ld = consumer->in_ld;
         consumer->pool_fused = true;
       };
@@ -624,7 +651,7 @@ struct mimo_plan {
     cap_partial = std::max(cap_partial, (size_t)kEwMaxBlocks * (Co * fp + Co));
     cap_sums = std::max(cap_sums, (size_t)kMaxChunks * 2 * round_up(Co * fp + Co, 64));
     if (cfg.inference_only) cap_act = cap_pad = cap_slab = 1;  // backward scratch: never touched
-    MIMO_TRY(dalloc(&s_dz, cap_act));
+    MIMO_TRY(alloc_act(&s_dz, cap_act, st));
     {
       const char* we = getenv("MIMO_WGRAD_STREAM");
       wg_async = we && atoi(we) != 0;
@@ -636,14 +663,14 @@ struct mimo_plan {
         if (wg_async) MIMO_TRY(dalloc(&s_dzs2[1], cap_act));
       }
       if (wg_async) {
-        MIMO_TRY(dalloc(&s_dz2[1], cap_act));
+        MIMO_TRY(alloc_act(&s_dz2[1], cap_act, st));
         MIMO_HIP_CHECK(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
         for (hipEvent_t* e : {&ev_dz[0], &ev_dz[1], &ev_wg[0], &ev_wg[1], &ev_join})
           MIMO_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
       }
     }
-    MIMO_TRY(dalloc(&s_dxpadA, cap_pad));
-    MIMO_TRY(dalloc(&s_dxpadB, cap_pad));
+    MIMO_TRY(alloc_act(&s_dxpadA, cap_pad, st));
+    MIMO_TRY(alloc_act(&s_dxpadB, cap_pad, st));
     MIMO_TRY(dalloc(&s_wslab, cap_slab));
     MIMO_TRY(dalloc(&s_partial, cap_partial));
     MIMO_TRY(dalloc(&s_sums, cap_sums));
@@ -685,7 +712,8 @@ struct mimo_plan {
           j.row_map = L->fwd_row_map;
           j.col_map = L->cin_map;
           j.transposed = 0;
-          j.kind = L->fwd_split ? (cfg.precision == MIMO_PREC_BF16 ? 2 : 1) : 0;
+          // split16 / fp16-mixed: fp16 (hi, lo) pairs x 2^8; bf16 / bf16-mixed: bf16 pairs (single-MFMA modes read hi only)
+          j.kind = L->fwd_split ? ((cfg.precision == MIMO_PREC_BF16 || cfg.precision == MIMO_PREC_BF16_MIXED) ? 2 : 1) : 0;
           j.dst = L->fwd_split ? L->wf16 : (void*)L->wf;
           j.total = L->fwd_split ? ceil_div(j.cols, 32) * 9 * j.rows_pad * 32 : 9 * j.rows_pad * j.cols;
           jobs.push_back(j);
@@ -699,7 +727,7 @@ struct mimo_plan {
           d.row_map = L->dg_row_map;
           d.col_map = L->dg_col_map;
           d.transposed = 1;
-          d.kind = L->dg_split ? 2 : 0;
+          d.kind = L->dg_split ? (f16 ? 1 : 2) : 0;
           d.dst = L->dg_split ? L->wd16 : (void*)L->wd;
           d.total = L->dg_split ? ceil_div(d.cols, 32) * 9 * d.rows_pad * 32 : 9 * d.rows_pad * d.cols;
           dg.push_back(d);
@@ -743,13 +771,15 @@ struct mimo_plan {
   }
 
   int convbn_forward(ConvBN& L, bool training, const float* mask, hipStream_t st) {
-    const bool fused = fwd_no_grad;  // inference: BN(eval) + ReLU (+ channel-dropout) in the conv epilogue
+    // inference: BN(eval) + ReLU (+ channel-dropout) in the conv epilogue — not for the fp32-kernel image convolution
+    // of the 16-bit storage modes, whose output type differs from the activation type
+    const bool fused = fwd_no_grad && !(mixed && !L.fwd_split);
     if (!training && need_derive)
       MIMO_TRY(bn_eval_prepare_launch(L.Cout, L.cout_p, params + L.off_gamma, params + L.off_beta, bnbuf + L.off_rm,
                                       bnbuf + L.off_rv, cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
     ConvLaunch a;
     a.x = L.in;
-    a.y = fused ? L.a : L.z;
+    a.y = fused ? L.a : L.z;  // fused: the activation type; else z (fp32 on the fp32 kernel family)
     if (fused) {
       a.ep_scale = L.scale;
       a.ep_shift = L.shift;
@@ -773,7 +803,7 @@ struct mimo_plan {
     a.wpk = L.wf16;
     int pr = prof_begin(MIMO_PROF_CONV_FWD, st);
     if (L.fwd_split)
-      MIMO_TRY(conv3x3_bf16x3_launch(a, cfg.precision == MIMO_PREC_BF16 ? 2 : 1, &rows, st));
+      MIMO_TRY(conv3x3_bf16x3_launch(a, fwd_mode(), &rows, st));
     else
       MIMO_TRY(conv3x3_launch(a, &rows, st));
     prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
@@ -793,10 +823,11 @@ struct mimo_plan {
     if (!fused) {
       pr = prof_begin(MIMO_PROF_BN_RELU_FWD, st);
       if (L.pool_out)
-        MIMO_TRY(bn_relu_pool_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, L.N, L.H, L.W,
-                                         L.pool_out, L.pool_ld, st));
+        MIMO_TRY(bn_relu_pool_fwd_launch(L.z, L.dtz, L.cout_p, L.a, this->st, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, L.N,
+                                         L.H, L.W, L.pool_out, L.pool_ld, st));
       else
-        MIMO_TRY(bn_relu_fwd_launch(L.z, L.cout_p, L.a, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, P, L.H * L.W, st));
+        MIMO_TRY(bn_relu_fwd_launch(L.z, L.dtz, L.cout_p, L.a, this->st, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, P,
+                                    L.H * L.W, st));
       prof_end(pr, 0.0, (L.pool_out ? 9.0 : 8.0) * (double)P * L.cout_p, st);
     }
     return MIMO_OK;
@@ -808,12 +839,12 @@ struct mimo_plan {
     if (dc->kind == IN_POOL) {
       Act* s = dc->src0;
       if (!(dc->pool_fused && !fwd_no_grad))  // else: already written by the producers' BatchNorm + ReLU pass
-        MIMO_TRY(maxpool_fwd_launch(s->a, s->ld, N, s->H, s->W, s->Cp, dc->in_buf, dc->in_ld, st));
+        MIMO_TRY(maxpool_fwd_launch(s->a, this->st, s->ld, N, s->H, s->W, s->Cp, dc->in_buf, dc->in_ld, st));
     } else if (dc->kind == IN_UPCAT) {
       Act *sk = dc->src0, *lo = dc->src1;
       const int pr = prof_begin(MIMO_PROF_UPCAT_FWD, st);
-      MIMO_TRY(upcat_fwd_launch(dc->skip_in_place ? nullptr : sk->a, sk->ld, sk->Cp, lo->a, lo->ld, lo->Cp, N, h, w, lo->H,
-                                lo->W, dc->in_buf, st));
+      MIMO_TRY(upcat_fwd_launch(dc->skip_in_place ? nullptr : sk->a, this->st, sk->ld, sk->Cp, lo->a, lo->ld, lo->Cp, N, h, w,
+                                lo->H, lo->W, dc->in_buf, st));
       // writes the up-sampled channels at (h, w), reads the low-resolution tensor once
       prof_end(pr, 0.0, 4.0 * lo->Cp * ((double)N * h * w + (double)N * lo->H * lo->W), st);
     }
@@ -976,7 +1007,7 @@ struct mimo_plan {
     MIMO_TRY(dc_forward(down4, training, st));
     // center_dropout: in place on down4's output, whose only reader is up1's upsample (the BN/ReLU
     // backward recomputes its mask from z, not from a)
-    if (elem_masks[0]) MIMO_TRY(elem_mask_mul_launch(down4->out.a, down4->out.ld, elem_masks[0], N, down4->out.C,
+    if (elem_masks[0]) MIMO_TRY(elem_mask_mul_launch(down4->out.a, this->st, down4->out.ld, elem_masks[0], N, down4->out.C,
                                                      down4->out.Cp, down4->out.H * down4->out.W, st));
     MIMO_TRY(dc_forward(up1, training, st));
     MIMO_TRY(dc_forward(up2, training, st));
@@ -988,10 +1019,10 @@ struct mimo_plan {
       MIMO_TRY(dc_forward(up4[s], training, st));
       const Act& o = up4[s]->out;
       // final_dropouts[s]: in place, the head (forward and weight gradient) is the only reader
-      if (elem_masks[1 + s]) MIMO_TRY(elem_mask_mul_launch(o.a, o.ld, elem_masks[1 + s], N, o.C, o.Cp, H * W, st));
+      if (elem_masks[1 + s]) MIMO_TRY(elem_mask_mul_launch(o.a, this->st, o.ld, elem_masks[1 + s], N, o.C, o.Cp, H * W, st));
       const int blk = prof_begin(kProfTierBase, st);
       const int pr = prof_begin(MIMO_PROF_HEAD_FWD, st);
-      MIMO_TRY(head_fwd_launch(o.a, o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co, N, S, s, H * W,
+      MIMO_TRY(head_fwd_launch(o.a, this->st, o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co, N, S, s, H * W,
                                args->out, st));
       prof_end(pr, 0.0, 4.0 * (double)N * H * W * (pad_channels(f) + Co), st);
       prof_end(blk, 0.0, 0.0, st);
@@ -1047,7 +1078,7 @@ struct mimo_plan {
     int rows = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
     int pr = prof_begin(MIMO_PROF_BN_BWD_REDUCE, st);
-    MIMO_TRY(bnrelu_bwd_reduce_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd,
+    MIMO_TRY(bnrelu_bwd_reduce_launch(da, this->st, ldda, dxpad_src, L.cout_p, L.z, L.dtz, L.cout_p, L.scale, L.shift, L.mean, L.invstd,
                                       mask, L.Cout, L.cout_p, L.N, L.H, L.W, s_partial, &rows, st));
     prof_end(pr, 0.0, 8.0 * (double)P * L.cout_p, st);
     MIMO_TRY(bn_bwd_stats_launch(s_partial, rows, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
@@ -1059,8 +1090,8 @@ struct mimo_plan {
       if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
     }
     pr = prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
-    MIMO_TRY(bn_bwd_apply_launch(da, ldda, dxpad_src, L.cout_p, L.z, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
-                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, L.dg_split ? 1 : 0,
+    MIMO_TRY(bn_bwd_apply_launch(da, this->st, ldda, dxpad_src, L.cout_p, L.z, L.dtz, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
+                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, (L.dg_split && !mixed) ? 1 : 0,
                                  fwd_training ? nullptr : s_partial, &rows, st));
     prof_end(pr, 0.0, 12.0 * (double)P * L.cout_p, st);
     // dz storage: bf16 hi|lo pairs when the data-gradient kernel is the bf16-pair one (then the weight
@@ -1097,7 +1128,7 @@ struct mimo_plan {
       a.wpk = L.wd16;
       pr = prof_begin(MIMO_PROF_CONV_DGRAD, st);
       if (L.dg_split)
-        MIMO_TRY(conv3x3_bf16x3_launch(a, cfg.precision == MIMO_PREC_BF16 ? 3 : 0, nullptr, st));
+        MIMO_TRY(conv3x3_bf16x3_launch(a, dgrad_mode(), nullptr, st));
       else
         MIMO_TRY(conv3x3_launch(a, nullptr, st));
       prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
@@ -1121,7 +1152,9 @@ struct mimo_plan {
     wg.cin_pad = L.wg_cin_pad;
     wg.cout_pad = L.wg_cout_pad;
     wg.splits = L.wg_splits;
-    wg.np = cfg.precision == MIMO_PREC_BF16 ? 1 : 3;
+    wg.np = (cfg.precision == MIMO_PREC_BF16 || mixed) ? 1 : 3;
+    // 16-bit storage: activations and dz plain NHWC 16-bit; the image convolution's input stays fp32
+    wg.store = !mixed ? 0 : (L.fwd_split ? (f16 ? 2 : 1) : (f16 ? 4 : 3));
     pr = prof_begin(MIMO_PROF_CONV_WGRAD, ws);
     if (L.wg_split)
       MIMO_TRY(wgrad_split_launch(wg, ws));
@@ -1163,7 +1196,7 @@ struct mimo_plan {
       Act* s = dc->src0;
       const int pr = prof_begin(MIMO_PROF_POOL_BWD, st);
       const bool acc = acc_flag(s) != 0;
-      MIMO_TRY(pool_bwd_launch(dxB, ldp, 0, s->a, s->ld, s->da, s->ldda, N, s->H, s->W, s->Cp, acc ? 1 : 0, st, s->skipgrad,
+      MIMO_TRY(pool_bwd_launch(dxB, this->st, ldp, 0, s->a, s->ld, s->da, s->ldda, N, s->H, s->W, s->Cp, acc ? 1 : 0, st, s->skipgrad,
                                s->skipgrad_ld));
       // reads the pooled gradient (1/4), the activation, [the skip gradient], [the old gradient]; writes the gradient
       prof_end(pr, 0.0, 4.0 * s->Cp * (double)N * s->H * s->W * (2.25 + (s->skipgrad ? 1.0 : 0.0) + (acc ? 1.0 : 0.0)), st);
@@ -1174,10 +1207,10 @@ struct mimo_plan {
         sk->skipgrad = dxB;
         sk->skipgrad_ld = ldp;
       } else {
-        MIMO_TRY(fold_slice_launch(dxB, ldp, 0, sk->da, sk->ldda, N, h, w, sk->Cp, acc_flag(sk), st));
+        MIMO_TRY(fold_slice_launch(dxB, this->st, ldp, 0, sk->da, sk->ldda, N, h, w, sk->Cp, acc_flag(sk), st));
       }
       const int pr = prof_begin(MIMO_PROF_UP_BWD, st);
-      MIMO_TRY(up_bwd_launch(dxB, ldp, sk->Cp, lo->da, lo->ldda, N, h, w, lo->H, lo->W, lo->Cp, acc_flag(lo), st));
+      MIMO_TRY(up_bwd_launch(dxB, this->st, ldp, sk->Cp, lo->da, lo->ldda, N, h, w, lo->H, lo->W, lo->Cp, acc_flag(lo), st));
       // reads the up-sampled slice of the padded-domain gradient once, writes the low-resolution gradient
       prof_end(pr, 0.0, 4.0 * lo->Cp * ((double)N * (h + 2) * (w + 2) + (double)N * lo->H * lo->W), st);
     }
@@ -1285,13 +1318,13 @@ struct mimo_plan {
           int rows = 0;
           const int blk = prof_begin(kProfTierBase + 1, st);
           const int pr = prof_begin(MIMO_PROF_HEAD_BWD, st);
-          MIMO_TRY(head_bwd_launch(dc->out.a, dc->out.ld, params + heads[s].off_w, f, fp, Co, N, S, s, H * W, out, dout, dloss,
+          MIMO_TRY(head_bwd_launch(dc->out.a, this->st, dc->out.ld, params + heads[s].off_w, f, fp, Co, N, S, s, H * W, out, dout, dloss,
                                    label, lmask, lperm, cfg.loss_kind, cfg.eps_min, cfg.eps_max, dc->out.da, s_partial, &rows,
                                    st));
           prof_end(pr, 0.0, 4.0 * (double)N * H * W * (2.0 * fp + Co + Co / 2), st);
           MIMO_TRY(head_bwd_stats_launch(s_partial, rows, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, colsum(), st));
           if (!elem_masks.empty() && elem_masks[1 + s])
-            MIMO_TRY(elem_mask_mul_launch(dc->out.da, dc->out.ldda, elem_masks[1 + s], N, dc->out.C, dc->out.Cp, H * W, st));
+            MIMO_TRY(elem_mask_mul_launch(dc->out.da, this->st, dc->out.ldda, elem_masks[1 + s], N, dc->out.C, dc->out.Cp, H * W, st));
           prof_end(blk, 0.0, 0.0, st);
           MIMO_TRY(dc_backward(dc, true, st));
         }
@@ -1302,7 +1335,7 @@ struct mimo_plan {
       case 3: return dc_backward(up1, true, st);
       case 4:
         if (!elem_masks.empty() && elem_masks[0])
-          MIMO_TRY(elem_mask_mul_launch(down4->out.da, down4->out.ldda, elem_masks[0], N, down4->out.C, down4->out.Cp,
+          MIMO_TRY(elem_mask_mul_launch(down4->out.da, this->st, down4->out.ldda, elem_masks[0], N, down4->out.C, down4->out.Cp,
                                         down4->out.H * down4->out.W, st));
         return dc_backward(down4, true, st);
       case 5: return dc_backward(down3, true, st);
@@ -1315,7 +1348,7 @@ struct mimo_plan {
     for (int s = S - 1; s >= 0; --s) MIMO_TRY(dc_backward(down1[s], true, st));
     for (int s = S - 1; s >= 0; --s) {
       MIMO_TRY(dc_backward(enc_in[s], dx != nullptr, st));
-      if (dx) MIMO_TRY(unpack_dx_launch(s_dxpadB, Ci_p, N, S, s, Ci, H, W, dx, st));
+      if (dx) MIMO_TRY(unpack_dx_launch(s_dxpadB, this->st, Ci_p, N, S, s, Ci, H, W, dx, st));
     }
     return MIMO_OK;
   }

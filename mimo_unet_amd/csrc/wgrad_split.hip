@@ -43,18 +43,55 @@ constexpr int wg_pitch(int C) {
   return 32 * m;
 }
 
+// Operand storage of the weight-gradient kernels (template parameter WM):
+//   0  activations fp32 (split into bf16 pairs / rounded to bf16 on the way in), dz pre-split bf16 (hi, lo) records
+//   1 / 2  16-bit storage modes: activations AND dz plain NHWC bf16 (1) / fp16 (2), copied as they are
+//   3 / 4  the image convolution in those modes: activations fp32 (the packed input image), dz plain bf16 / fp16
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_w;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_w;
+template <int WM>
+__device__ __forceinline__ f32x4 wg_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (WM == 2 || WM == 4)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_w, a), __builtin_bit_cast(f16x8_w, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// four fp32 values -> four 16-bit values of the mode's element type (as raw bf16x4 bits)
+template <int WM>
+__device__ __forceinline__ bf16x4 wg_round4(f32x4 v) {
+  if constexpr (WM == 2 || WM == 4) {
+    f16x4_w h;
+    h[0] = (_Float16)v[0];
+    h[1] = (_Float16)v[1];
+    h[2] = (_Float16)v[2];
+    h[3] = (_Float16)v[3];
+    return __builtin_bit_cast(bf16x4, h);
+  } else {
+    bf16x4 h;
+    h[0] = (__bf16)v[0];
+    h[1] = (__bf16)v[1];
+    h[2] = (__bf16)v[2];
+    h[3] = (__bf16)v[3];
+    return h;
+  }
+}
+
 __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
   const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
   const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int MI, int NI, int WM, int WN, int WK, int NP>
+template <int MI, int NI, int WM, int WN, int WK, int NP, int OM>
 __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+  static_assert(OM == 0 || NP == 1, "16-bit storage: one MFMA per product");
+  constexpr bool X16 = OM == 1 || OM == 2, D16 = OM >= 1;       // operand storage, see wg_mfma above
   constexpr int CI = 16 * MI * WM, CO = 16 * NI * WN;
   constexpr int PA = wg_pitch(CI), PD = wg_pitch(CO);
-  constexpr int QA = CI / 4, QD = CO / 4;                       // float4 units per pixel
+  // 16-byte units per pixel: fp32 activations 4 channels each, 16-bit activations 8; dz pre-split: hi and lo halves of
+  // 8 channels each, plain 16-bit dz: 8 channels each
+  constexpr int QA = X16 ? CI / 8 : CI / 4, QD = D16 ? CO / 8 : CO / 4;
   constexpr int XA = (kWgAPix * QA + 255) / 256, XD = (kWgDPix * QD + 255) / 256;
   constexpr int ABYTES = kWgAPix * PA, DBYTES = kWgDPix * PD;
   constexpr int REDBYTES = 4 * MI * NI * 256 * 4;               // cross-wave reduction scratch
@@ -102,14 +139,28 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
       ix_ = ix_ >= a.W ? 2 * a.W - 2 - ix_ : ix_;                                                   \
       iy_ = min(max(iy_, 0), a.H - 1);                                                              \
       ix_ = min(max(ix_, 0), a.W - 1);                                                              \
-      const bool ok_ = ci0 + 4 * qq_ < a.cin_p; /* masked-out units load from kZeroPage (common.h) */ \
-      xa[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg_ + ((size_t)iy_ * a.W + ix_) * a.ldx + ci0 + 4 * qq_ : kZeroPage); \
+      if (X16) {                                                                                    \
+        const bool ok_ = ci0 + 8 * qq_ < a.cin_p;                                                   \
+        const unsigned short* s_ = reinterpret_cast<const unsigned short*>(a.x) +                   \
+                                   (((size_t)n_ * a.H + iy_) * a.W + ix_) * a.ldx + ci0 + 8 * qq_;  \
+        xa[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
+      } else {                                                                                      \
+        const bool ok_ = ci0 + 4 * qq_ < a.cin_p; /* masked-out units load from kZeroPage (common.h) */ \
+        xa[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg_ + ((size_t)iy_ * a.W + ix_) * a.ldx + ci0 + 4 * qq_ : kZeroPage); \
+      }                                                                                             \
     }                                                                                               \
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
       const int u_ = tid + k_ * 256;                                                                \
       const int pix_ = u_ / QD, qq_ = u_ - pix_ * QD;                                               \
       const int r_ = pix_ / kWgTC, c_ = pix_ - r_ * kWgTC;                                          \
       const int y_ = y0_ + r_, x_ = x0_ + c_;                                                       \
+      if (D16) { /* plain 16-bit NHWC dz: unit = 8 channels */                                      \
+        const int ch_ = co0 + 8 * qq_;                                                              \
+        const bool ok_ = pix_ < kWgDPix && y_ < a.H && x_ < a.W && ch_ < a.cout_p;                  \
+        const unsigned short* s_ = reinterpret_cast<const unsigned short*>(a.dz) +                  \
+                                   (((size_t)n_ * a.H + y_) * a.W + x_) * a.lddz + ch_;             \
+        xd[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
+      } else {                                                                                      \
       /* dz is pre-split, per 32-channel chunk [hi rc | lo rc] bf16: unit = 8 channels, 16 bytes */ \
       const int half_ = qq_ / (CO / 8), ch_ = co0 + 8 * (qq_ - half_ * (CO / 8));                   \
       const int rc_ = min(32, a.cout_p - (ch_ & ~31));                                              \
@@ -117,17 +168,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
       const unsigned short* s_ = reinterpret_cast<const unsigned short*>(dimg_ + ((size_t)y_ * a.W + x_) * a.lddz) + \
                                  ((ch_ >> 5) * 64 + half_ * rc_ + (ch_ & 31));                      \
       xd[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
+      }                                                                                             \
     }                                                                                               \
   }
 #define WG_SPLIT_STORE(V, DST, CCH)                                                                 \
   {                                                                                                 \
-    bf16x4 hi_, lo_;                                                                                \
-    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                              \
-      hi_[e_] = (__bf16)(V)[e_];                                                                    \
-      lo_[e_] = (__bf16)((V)[e_] - (float)hi_[e_]);                                                 \
+    if (OM != 0) { /* 16-bit modes: one rounding to the element type, no lo part */                 \
+      *reinterpret_cast<bf16x4*>(DST) = wg_round4<OM>(V);                                           \
+    } else {                                                                                        \
+      bf16x4 hi_, lo_;                                                                              \
+      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                            \
+        hi_[e_] = (__bf16)(V)[e_];                                                                  \
+        lo_[e_] = (__bf16)((V)[e_] - (float)hi_[e_]);                                               \
+      }                                                                                             \
+      *reinterpret_cast<bf16x4*>(DST) = hi_;                                                        \
+      if (NP == 3) *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                             \
     }                                                                                               \
-    *reinterpret_cast<bf16x4*>(DST) = hi_;                                                          \
-    if (NP == 3) *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                               \
   }
 #define WG_STORE()                                                                                  \
   {                                                                                                 \
@@ -135,15 +191,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
       const int u_ = tid + k_ * 256;                                                                \
       const int pix_ = u_ / QA, qq_ = u_ - pix_ * QA;                                               \
       if (pix_ < kWgAPix) {                                                                         \
-        unsigned char* d_ = as_ + pix_ * PA + ((pix_ >> 3) & 1) * 32 + qq_ * 8;                     \
-        WG_SPLIT_STORE(xa[k_], d_, CI)                                                              \
+        if (X16) { /* 8 channels of the hi plane: plain 16-byte copy */                             \
+          *reinterpret_cast<f32x4*>(as_ + pix_ * PA + ((pix_ >> 3) & 1) * 32 + qq_ * 16) = xa[k_];  \
+        } else {                                                                                    \
+          unsigned char* d_ = as_ + pix_ * PA + ((pix_ >> 3) & 1) * 32 + qq_ * 8;                   \
+          WG_SPLIT_STORE(xa[k_], d_, CI)                                                            \
+        }                                                                                           \
       }                                                                                             \
     }                                                                                               \
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
       const int u_ = tid + k_ * 256;                                                                \
       const int pix_ = u_ / QD, qq_ = u_ - pix_ * QD;                                               \
       if (pix_ < kWgDPix) { /* row image [hi CO | lo CO]: plain 16-byte copy of the pre-split dz */ \
-        const int half_ = qq_ / (CO / 8), c8_ = qq_ - half_ * (CO / 8);                             \
+        const int half_ = D16 ? 0 : qq_ / (CO / 8), c8_ = qq_ - half_ * (CO / 8);                   \
         unsigned char* d_ = ds_ + pix_ * PD + ((pix_ >> 3) & 1) * 32 + half_ * 2 * CO + c8_ * 16;   \
         *reinterpret_cast<f32x4*>(d_) = xd[k_];                                                     \
       }                                                                                             \
@@ -193,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ni], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ni], c, 0, 0, 0);
               }
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ni], c, 0, 0, 0);
+              c = wg_mfma<OM>(ah, bh[ni], c);
               acc[kh * 3 + kw][mi][ni] = c;
             }
           }
@@ -258,8 +318,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
 // workgroup (128 KB of LDS); 4 rows with 32 (the thin 256x256 layers: twice the MFMAs per barrier, 127-157 KB)
 static int wgrad_ws_tr(int CI) { return CI == 32 ? 4 : 2; }
 
-template <int NP, int NI, int CI_, int TR_>
+template <int NP, int NI, int CI_, int TR_, int OM>
 __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
+  static_assert(OM == 0 || NP == 1, "16-bit storage: one MFMA per product");
+  constexpr bool X16 = OM == 1 || OM == 2, D16 = OM >= 1;  // operand storage, see wg_mfma above
   // consumer wave = 16 ci x CO co (MI = 1, NI = CO/16 = 2, 3 or 4): an A fragment (re-read for every tap)
   // feeds 3*NI MFMAs; at NI = 4, 52 instead of 80 transposed LDS reads per 108 MFMAs of a 32x32 arrangement.
   // CI_ = 64: the four consumer waves are stacked along ci, each accumulates all nine taps.  CI_ = 32 (layers
@@ -270,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   static_assert(CI == 64 || CI == 32, "64 or 32 input channels per workgroup");
   constexpr int kWsTR = TR_, kWsAPix = (kWsTR + 2) * kWgTCP, kWsDPix = kWsTR * kWgTC;
   constexpr int PA = wg_pitch(CI), PD = wg_pitch(CO);
-  constexpr int QA = CI / 4, QD = CO / 4;
+  constexpr int QA = X16 ? CI / 8 : CI / 4, QD = D16 ? CO / 8 : CO / 4;  // 16-byte units per pixel
   constexpr int XA = (kWsAPix * QA + 255) / 256, XD = (kWsDPix * QD + 255) / 256;  // per producer thread
   constexpr int ABYTES = kWsAPix * PA, DBYTES = kWsDPix * PD, BUFBYTES = ABYTES + DBYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFBYTES];
@@ -302,19 +364,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       const int pix = uc / QA, qq = uc - pix * QA;
       a_tr[k] = pix / kWgTCP - 1;
       a_tc[k] = pix % kWgTCP - 1;
-      a_ch[k] = ci0 + 4 * qq < a.cin_p ? ci0 + 4 * qq : -1;
-      a_dst[k] = u < kWsAPix * QA ? pix * PA + ((pix >> 3) & 1) * 32 + qq * 8 : -1;
+      constexpr int kChU = X16 ? 8 : 4;  // channels per unit; its hi-plane bytes = 2 * kChU
+      a_ch[k] = ci0 + kChU * qq < a.cin_p ? ci0 + kChU * qq : -1;
+      a_dst[k] = u < kWsAPix * QA ? pix * PA + ((pix >> 3) & 1) * 32 + qq * 2 * kChU : -1;
     }
 #pragma unroll
     for (int k = 0; k < XD; ++k) {
       const int u = ptid + k * 256;
       const int pix = u / QD, qq = u - pix * QD;
-      const int half = qq / (CO / 8), c8 = qq - half * (CO / 8);  // pre-split dz: 8 channels of the hi or lo plane
+      const int half = D16 ? 0 : qq / (CO / 8), c8 = qq - half * (CO / 8);  // pre-split dz: 8 channels of the hi or lo plane
       d_r[k] = pix / kWgTC;
       d_c[k] = pix % kWgTC;
       const int ch = co0 + 8 * c8, rc = min(32, a.cout_p - (ch & ~31));  // chunk record [hi rc | lo rc]
-      d_ch[k] = (pix < kWsDPix && ch < a.cout_p && (NP == 3 || half == 0)) ? (ch >> 5) * 64 + half * rc + (ch & 31)
-                                                                            : -1;  // in bf16 units
+      d_ch[k] = (pix < kWsDPix && ch < a.cout_p && (NP == 3 || half == 0))
+                    ? (D16 ? ch : (ch >> 5) * 64 + half * rc + (ch & 31))  // plain NHWC / pair records, in 16-bit units
+                    : -1;
       d_dst[k] = pix < kWsDPix ? ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + half * 2 * CO + c8 * 16 : -1;
     }
     const int H2 = 2 * a.H - 2, W2 = 2 * a.W - 2;
@@ -335,24 +399,38 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       ix_ = max(ix_, -ix_);                                                                         \
       ix_ = max(min(ix_, W2 - ix_), 0);                                                             \
       const bool ok_ = a_ch[k_] >= 0;                                                               \
-      XA_[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg_ + (iy_ * a.W + ix_) * a.ldx + a_ch[k_] : kZeroPage); \
+      if (X16) {                                                                                    \
+        const unsigned short* s_ = reinterpret_cast<const unsigned short*>(a.x) +                   \
+                                   (((size_t)n_ * a.H + iy_) * a.W + ix_) * a.ldx + a_ch[k_];       \
+        XA_[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
+      } else {                                                                                      \
+        XA_[k_] = *reinterpret_cast<const f32x4*>(ok_ ? ximg_ + (iy_ * a.W + ix_) * a.ldx + a_ch[k_] : kZeroPage); \
+      }                                                                                             \
     }                                                                                               \
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
       const int y_ = y0_ + d_r[k_], x_ = x0_ + d_c[k_];                                             \
       const bool ok_ = d_ch[k_] >= 0 && y_ < a.H && x_ < a.W;                                       \
-      const unsigned short* s_ = reinterpret_cast<const unsigned short*>(dimg_ + (y_ * a.W + x_) * a.lddz) + d_ch[k_]; \
+      const unsigned short* s_ = D16 ? reinterpret_cast<const unsigned short*>(a.dz) +              \
+                                           (((size_t)n_ * a.H + y_) * a.W + x_) * a.lddz + d_ch[k_] \
+                                     : reinterpret_cast<const unsigned short*>(dimg_ + (y_ * a.W + x_) * a.lddz) + d_ch[k_]; \
       XD_[k_] = *reinterpret_cast<const f32x4*>(ok_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
     }                                                                                               \
   }
 #define WS_SPLIT_STORE(V, DST, CCH)                                                                 \
   {                                                                                                 \
-    bf16x4 hi_, lo_;                                                                                \
-    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                              \
-      hi_[e_] = (__bf16)(V)[e_];                                                                    \
-      lo_[e_] = (__bf16)((V)[e_] - (float)hi_[e_]);                                                 \
+    if (X16) { /* 8 channels of the hi plane: plain 16-byte copy */                                 \
+      *reinterpret_cast<f32x4*>(DST) = (V);                                                         \
+    } else if (OM != 0) { /* fp32 image operand in a 16-bit mode: one rounding, no lo part */       \
+      *reinterpret_cast<bf16x4*>(DST) = wg_round4<OM>(V);                                           \
+    } else {                                                                                        \
+      bf16x4 hi_, lo_;                                                                              \
+      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                            \
+        hi_[e_] = (__bf16)(V)[e_];                                                                  \
+        lo_[e_] = (__bf16)((V)[e_] - (float)hi_[e_]);                                               \
+      }                                                                                             \
+      *reinterpret_cast<bf16x4*>(DST) = hi_;                                                        \
+      if (NP == 3) *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                             \
     }                                                                                               \
-    *reinterpret_cast<bf16x4*>(DST) = hi_;                                                          \
-    if (NP == 3) *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                               \
   }
 #define WS_STORE(XA_, XD_, BUF)                                                                      \
   {                                                                                                 \
@@ -454,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tt & 1][mi], bh[ni], c, 0, 0, 0);  \
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tt & 1][mi], bl[ni], c, 0, 0, 0);  \
           }                                                                                   \
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tt & 1][mi], bh[ni], c, 0, 0, 0);    \
+          c = wg_mfma<OM>(ah[tt & 1][mi], bh[ni], c);                                         \
           acc[tt][mi][ni] = c;                                                                \
         }                                                                                     \
       if (tt + 1 < (NT)) __builtin_amdgcn_sched_group_barrier(0x100, (NP == 3 ? 4 : 2) * MI, 0); /* DS reads of the next tap */ \
@@ -555,13 +633,29 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
   const int tilesY = ceil_div(a.H, ws ? wgrad_ws_tr(CI) : kWgTR), tilesX = ceil_div(a.W, kWgTC);
   const int numTiles = a.N * tilesY * tilesX;
   dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
+  const int om = a.store;  // operand storage (WgradLaunch::store), see wg_mfma
+  if (om < 0 || om > 4 || (om != 0 && a.np != 1) || ((om == 1 || om == 2) && (a.ldx % 8 || a.cin_p % 8)) ||
+      (om != 0 && (a.lddz % 8 || a.cout_p % 8))) {
+    set_error("wgrad_split: bad operand storage mode %d", om);
+    return MIMO_ERR_INVALID;
+  }
   if (ws) {
     grid = dim3(grid.x * grid.y);  // 1-D, decoded XCD-aware inside the kernel
-#define WS_LAUNCH2(NI_, CI_, TR_)                                                                                       \
-  if (a.np == 1)                                                                                                     \
-    hipLaunchKernelGGL((wgrad_split_ws_kernel<1, NI_, CI_, TR_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \
-  else                                                                                                               \
-    hipLaunchKernelGGL((wgrad_split_ws_kernel<3, NI_, CI_, TR_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles)
+#define WS_LAUNCH3(NP_, NI_, CI_, TR_, OM_) \
+  hipLaunchKernelGGL((wgrad_split_ws_kernel<NP_, NI_, CI_, TR_, OM_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles)
+#define WS_LAUNCH2(NI_, CI_, TR_)                \
+  switch (om) {                                  \
+    case 1: WS_LAUNCH3(1, NI_, CI_, TR_, 1); break; \
+    case 2: WS_LAUNCH3(1, NI_, CI_, TR_, 2); break; \
+    case 3: WS_LAUNCH3(1, NI_, CI_, TR_, 3); break; \
+    case 4: WS_LAUNCH3(1, NI_, CI_, TR_, 4); break; \
+    default:                                     \
+      if (a.np == 1) {                           \
+        WS_LAUNCH3(1, NI_, CI_, TR_, 0);         \
+      } else {                                   \
+        WS_LAUNCH3(3, NI_, CI_, TR_, 0);         \
+      }                                          \
+  }
 #define WS_LAUNCH(NI_)     \
   if (CI == 64) {          \
     WS_LAUNCH2(NI_, 64, 2); \
@@ -573,16 +667,27 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
       case 48: WS_LAUNCH(3); break;
       default: WS_LAUNCH(4); break;
     }
+#undef WS_LAUNCH3
 #undef WS_LAUNCH2
 #undef WS_LAUNCH
     MIMO_KERNEL_CHECK();
     return MIMO_OK;
   }
-#define WG_LAUNCH(MI, NI, WM, WN, WK)                                                                                  \
-  if (a.np == 1)                                                                                                       \
-    hipLaunchKernelGGL((wgrad_split_kernel<MI, NI, WM, WN, WK, 1>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles); \
-  else                                                                                                                 \
-    hipLaunchKernelGGL((wgrad_split_kernel<MI, NI, WM, WN, WK, 3>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles)
+#define WG_LAUNCH3(MI, NI, WM, WN, WK, NP_, OM_) \
+  hipLaunchKernelGGL((wgrad_split_kernel<MI, NI, WM, WN, WK, NP_, OM_>), grid, dim3(256), 0, stream, a, tilesY, tilesX, numTiles)
+#define WG_LAUNCH(MI, NI, WM, WN, WK)               \
+  switch (om) {                                     \
+    case 1: WG_LAUNCH3(MI, NI, WM, WN, WK, 1, 1); break; \
+    case 2: WG_LAUNCH3(MI, NI, WM, WN, WK, 1, 2); break; \
+    case 3: WG_LAUNCH3(MI, NI, WM, WN, WK, 1, 3); break; \
+    case 4: WG_LAUNCH3(MI, NI, WM, WN, WK, 1, 4); break; \
+    default:                                        \
+      if (a.np == 1) {                              \
+        WG_LAUNCH3(MI, NI, WM, WN, WK, 1, 0);       \
+      } else {                                      \
+        WG_LAUNCH3(MI, NI, WM, WN, WK, 3, 0);       \
+      }                                             \
+  }
   const int key = CI * 100 + CO;
   switch (key) {
     case 3232: WG_LAUNCH(2, 2, 1, 1, 4); break;
@@ -595,6 +700,7 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
     case 6448: WG_LAUNCH(2, 3, 2, 1, 2); break;
     default: WG_LAUNCH(2, 2, 2, 2, 1); break;
   }
+#undef WG_LAUNCH3
 #undef WG_LAUNCH
   MIMO_KERNEL_CHECK();
   return MIMO_OK;

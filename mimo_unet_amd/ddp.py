@@ -33,7 +33,7 @@ def shard_batch(batch: Dict[str, Optional[torch.Tensor]], rank: int, world_size:
 
 class FlatGradientAllReducer:
     """Sum all-reduce of a flat gradient buffer, started range by range while the backward is still running;
-    `scale` is what the optimiser must multiply gradients by afterwards (1/world: FlatAdam.grad_scale).
+    `scale` is what the optimiser must multiply gradients by afterwards (1/world: FlatAdam.reduce_scale).
 
     The engine announces ranges in backward order — heads + decoders, up3, up2, up1, down4, down3, down2,
     encoders — which walks the flat buffer (encoder | core | decoder | heads) from its tail to its head, so

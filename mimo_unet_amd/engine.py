@@ -37,7 +37,8 @@ class NetGeometry:
     core_dropout_rate: float = 0.0
     decoder_dropout_rate: float = 0.0
     loss: str = "laplace_nll"
-    precision: str = "split16"  # arithmetic of the 3x3 fwd/dgrad convolutions: "fp32" | "split16"
+    # arithmetic / storage: "fp32" | "split16" | "bf16" | "bf16-mixed" | "16-mixed" (include/mimo_hip.h mimo_precision)
+    precision: str = "split16"
 
 
 class Plan:
@@ -188,6 +189,21 @@ def adam_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, 
     L.check(lib.mimo_adam_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                params.numel(), lr, betas[0], betas[1], eps, weight_decay, step, grad_scale,
                                L.current_stream()), "mimo_adam_step")
+
+
+def adam_step_amp(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
+                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, step_dev: torch.Tensor,
+                  reduce_scale: float = 1.0, amp_scale: Optional[torch.Tensor] = None,
+                  found_inf: Optional[torch.Tensor] = None) -> None:
+    """Adam under a loss scaler: device-side step counter, gradients divided by `amp_scale`, the whole update skipped
+    when `found_inf` is non-zero (include/mimo_hip.h mimo_adam_step_amp)."""
+    lib = L.load()
+    for t in (step_dev, amp_scale, found_inf):
+        assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1)
+    L.check(lib.mimo_adam_step_amp(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                   params.numel(), lr, betas[0], betas[1], eps, weight_decay, step_dev.data_ptr(),
+                                   reduce_scale, L.ptr(amp_scale) or None, L.ptr(found_inf) or None, L.current_stream()),
+            "mimo_adam_step_amp")
 
 
 def uncertainties(p1: torch.Tensor, p2: torch.Tensor, loss: str = "laplace_nll"):

@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import torch
 
-from .engine import adam_step
+from .engine import adam_step, adam_step_amp
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -18,7 +18,12 @@ class FlatAdam(torch.optim.Optimizer):
         self._step = 0
         self._m = self._v = None
         self._ref_state = None  # per-parameter torch.optim.Adam state waiting for the flat layout (load_state_dict)
-        self.grad_scale = 1.0  # e.g. 1/world_size after a sum all-reduce
+        self.reduce_scale = 1.0  # multiplier applied to the gradients, e.g. 1/world_size after a sum all-reduce
+        # torch.cuda.amp.GradScaler protocol for fused optimisers: the scaler sets `self.grad_scale` (tensor: divide the
+        # gradients by it) and `self.found_inf` (tensor: skip the step when non-zero) around step() and deletes them
+        # afterwards; unscaling, the inf / nan skip and the step counter then all happen on the device
+        self._step_supports_amp_scaling = True
+        self._step_dev = None
 
     def _init_moments(self, p: torch.Tensor) -> None:
         self._m, self._v = torch.zeros_like(p), torch.zeros_like(p)
@@ -57,12 +62,26 @@ class FlatAdam(torch.optim.Optimizer):
         elif self._m.device != p.device:  # e.g. a checkpoint loaded with map_location="cpu", or module.to() since
             self._m, self._v = self._m.to(p.device), self._v.to(p.device)
         grp = self.param_groups[0]
-        self._step += 1
-        adam_step(p, g, self._m, self._v, lr=float(grp["lr"]), betas=grp["betas"], eps=grp["eps"],
-                  weight_decay=grp["weight_decay"], step=self._step, grad_scale=self.grad_scale)
+        amp_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        if amp_scale is not None or found_inf is not None or self._step_dev is not None:
+            if self._step_dev is None or self._step_dev.device != p.device:
+                self._step_dev = torch.full((1,), float(self.step_count), device=p.device, dtype=torch.float32)
+            adam_step_amp(p, g, self._m, self._v, lr=float(grp["lr"]), betas=grp["betas"], eps=grp["eps"],
+                          weight_decay=grp["weight_decay"], step_dev=self._step_dev, reduce_scale=self.reduce_scale,
+                          amp_scale=None if amp_scale is None else amp_scale.reshape(1).float(),
+                          found_inf=None if found_inf is None else found_inf.reshape(1).float())
+        else:
+            self._step += 1
+            adam_step(p, g, self._m, self._v, lr=float(grp["lr"]), betas=grp["betas"], eps=grp["eps"],
+                      weight_decay=grp["weight_decay"], step=self._step, grad_scale=self.reduce_scale)
         if hasattr(self.net, "mark_parameters_changed"):
             self.net.mark_parameters_changed()  # the kernel wrote the parameters through a raw pointer
         return loss
+
+    @property
+    def step_count(self) -> int:
+        """Optimiser steps taken (skipped loss-scaler steps not counted); reads the device counter when one exists."""
+        return int(self._step_dev.item()) if self._step_dev is not None else self._step
 
     def zero_grad(self, set_to_none: bool = True):
         # gradients are overwritten (not accumulated) by the engine when .grad is None
@@ -70,7 +89,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         d = super().state_dict()
-        d["flat"] = {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v}
+        d["flat"] = {"step": self.step_count, "exp_avg": self._m, "exp_avg_sq": self._v}
         return d
 
     def load_state_dict(self, state_dict):
@@ -93,6 +112,7 @@ class FlatAdam(torch.optim.Optimizer):
                     raise ValueError(f"FlatAdam: checkpoint moments have {m.numel()} elements, the network {p.numel()}")
                 m, v = m.to(p.device), v.to(p.device)
             self._step = int(flat["step"])
+            self._step_dev = None
             self._m = None if m is None else m.detach().clone().float()
             self._v = None if v is None else v.detach().clone().float()
         elif per_param:

@@ -130,6 +130,7 @@ def init_state(cfg: NetConfig, seed: int) -> Dict[str, Tensor]:
 # building blocks
 # --------------------------------------------------------------------------
 _CONV_OPERANDS = "fp32"
+_STORE16 = None  # None | torch.bfloat16 | torch.float16: 16-bit STORAGE of conv outputs and activations
 
 
 class conv_operands:
@@ -137,19 +138,44 @@ class conv_operands:
     bf16 — input and weight in the forward, the upstream gradient too in the data / weight gradients —
     with fp32 accumulation and an fp32 bias: the arithmetic of the engine's MIMO_PREC_BF16 mode (what
     autocast does to a conv in the reference's ``precision="16-mixed"`` runs, scripts/train/train_ndvi.py:71).
-    No reference fixture pins this mode: it is the pinned fp32 restatement with roundings inserted."""
+    No reference fixture pins this mode: it is the pinned fp32 restatement with roundings inserted.
+
+    ``"bf16-mixed"`` / ``"16-mixed"`` (the engine's MIMO_PREC_BF16_MIXED / MIMO_PREC_FP16_MIXED, i.e. Lightning's
+    autocast precisions): operands rounded to bf16 / fp16 in every convolution but the image convolution, and the
+    FORWARD storage roundings of the engine inserted — convolution outputs and activations are stored in that type
+    (BatchNorm statistics come from the unrounded fp32 accumulators; the 1x1 head reads the stored activation and
+    produces fp32 logits).  The backward of this emulation keeps fp32 gradients (the engine also stores those in 16
+    bits): gradients are compared against the fp32 run at mixed-precision tolerance, not against this emulation."""
 
     def __init__(self, kind: str):
-        assert kind in ("fp32", "bf16")
+        assert kind in ("fp32", "bf16", "bf16-mixed", "16-mixed")
         self.kind = kind
 
     def __enter__(self):
-        global _CONV_OPERANDS
-        self.prev, _CONV_OPERANDS = _CONV_OPERANDS, self.kind
+        global _CONV_OPERANDS, _STORE16
+        self.prev = (_CONV_OPERANDS, _STORE16)
+        _CONV_OPERANDS = self.kind
+        _STORE16 = {"bf16-mixed": torch.bfloat16, "16-mixed": torch.float16}.get(self.kind)
 
     def __exit__(self, *exc):
-        global _CONV_OPERANDS
-        _CONV_OPERANDS = self.prev
+        global _CONV_OPERANDS, _STORE16
+        _CONV_OPERANDS, _STORE16 = self.prev
+
+
+class _StoreRound(torch.autograd.Function):
+    """Round to the 16-bit storage type in the forward, identity in the backward."""
+
+    @staticmethod
+    def forward(ctx, t, dtype):
+        return t.to(dtype).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def _stored(t: Tensor) -> Tensor:
+    return t if _STORE16 is None else _StoreRound.apply(t, _STORE16)
 
 
 class _RoundedConv(torch.autograd.Function):
@@ -159,22 +185,29 @@ class _RoundedConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xp, w):
-        r = lambda t: t.bfloat16().float()
+        dt = _STORE16 or torch.bfloat16
+        r = lambda t: t.to(dt).float()
         ctx.save_for_backward(xp, w)
-        return F.conv2d(r(xp), r(w)) if w.shape[1] > 8 else F.conv2d(xp, w)
+        ctx.dt, ctx.mixed = dt, _STORE16 is not None
+        # MIMO_PREC_BF16: 16-bit forward when the padded input has >= 16 channels; mixed storage modes: every layer
+        # but the image convolution (C_in <= 4)
+        low = w.shape[1] > 4 if ctx.mixed else w.shape[1] > 8
+        return F.conv2d(r(xp), r(w)) if low else F.conv2d(xp, w)
 
     @staticmethod
     def backward(ctx, dz):
-        r = lambda t: t.bfloat16().float()
+        r = lambda t: t.to(ctx.dt).float()
         xp, w = ctx.saved_tensors
-        dx = torch.nn.grad.conv2d_input(xp.shape, r(w), r(dz)) if w.shape[0] > 8 else torch.nn.grad.conv2d_input(xp.shape, w, dz)
-        return dx, torch.nn.grad.conv2d_weight(r(xp), w.shape, r(dz))
+        low = ctx.mixed or w.shape[0] > 8
+        dx = torch.nn.grad.conv2d_input(xp.shape, r(w), r(dz)) if low else torch.nn.grad.conv2d_input(xp.shape, w, dz)
+        xin = r(xp) if (not ctx.mixed or w.shape[1] > 4) else xp.to(ctx.dt).float()  # the fp32 image is rounded on load
+        return dx, torch.nn.grad.conv2d_weight(xin, w.shape, r(dz))
 
 
 def conv3x3_reflect(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
     """Conv2d(k=3, padding=1, padding_mode='reflect') — components.py:23,26."""
     xp = F.pad(x, (1, 1, 1, 1), mode="reflect")
-    if _CONV_OPERANDS == "bf16":
+    if _CONV_OPERANDS != "fp32":
         z = _RoundedConv.apply(xp, w)
         return z if b is None else z + b[None, :, None, None]
     return F.conv2d(xp, w, b)
@@ -185,13 +218,29 @@ def conv_bn_relu(x: Tensor, st: Dict[str, Tensor], conv: str, bn: str, training:
     Training mode normalises with biased batch variance and updates the running
     buffers in ``st`` in place (momentum 0.1, unbiased variance)."""
     z = conv3x3_reflect(x, st[conv + ".weight"], st[conv + ".bias"])
-    z = F.batch_norm(
-        z, st[bn + ".running_mean"], st[bn + ".running_var"], st[bn + ".weight"], st[bn + ".bias"],
-        training, BN_MOMENTUM, BN_EPS,
-    )
+    if _STORE16 is not None and x.shape[1] > 4 and not training:
+        # 16-bit storage of the conv output (eval mode: the normalisation constants do not depend on z; in training
+        # mode the engine takes the statistics from the fp32 accumulators and normalises the STORED z — emulated
+        # below by normalising the rounded tensor with the statistics of the unrounded one)
+        z = _stored(z)
+    if _STORE16 is not None and x.shape[1] > 4 and training:
+        mean = z.mean(dim=(0, 2, 3))
+        var = z.var(dim=(0, 2, 3), unbiased=False)
+        n = z.numel() // z.shape[1]
+        with torch.no_grad():
+            st[bn + ".running_mean"] = (1 - BN_MOMENTUM) * st[bn + ".running_mean"] + BN_MOMENTUM * mean
+            st[bn + ".running_var"] = (1 - BN_MOMENTUM) * st[bn + ".running_var"] + BN_MOMENTUM * var * n / max(n - 1, 1)
+        zs = _stored(z)
+        z = (zs - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + BN_EPS)
+        z = z * st[bn + ".weight"][None, :, None, None] + st[bn + ".bias"][None, :, None, None]
+    else:
+        z = F.batch_norm(
+            z, st[bn + ".running_mean"], st[bn + ".running_var"], st[bn + ".weight"], st[bn + ".bias"],
+            training, BN_MOMENTUM, BN_EPS,
+        )
     if training and (bn + ".num_batches_tracked") in st:
         st[bn + ".num_batches_tracked"] += 1
-    return F.relu(z)
+    return _stored(F.relu(z))
 
 
 def channel_dropout(x: Tensor, p: float, active: bool, mask: Optional[Tensor]) -> Tensor:
@@ -219,7 +268,7 @@ def up_cat(low: Tensor, skip: Tensor) -> Tensor:
     dy = skip.shape[2] - up.shape[2]
     dx = skip.shape[3] - up.shape[3]
     up = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
-    return torch.cat([skip, up], dim=1)
+    return torch.cat([skip, _stored(up)], dim=1)
 
 
 # --------------------------------------------------------------------------

@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
     opt = model.configure_optimizers()["optimizer"]
     red = FlatGradientAllReducer(bucket_bytes=1 << 18)
     red.attach(model.model)
-    opt.grad_scale = red.scale
+    opt.reduce_scale = red.scale
     calls = []
     inner = model.model.grad_ready_hook
     model.model.grad_ready_hook = lambda flat, b, e: (calls.append((b, e)), inner(flat, b, e))
