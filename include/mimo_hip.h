@@ -216,6 +216,18 @@ int mimo_adam_step_amp(float* params, const float* grads, float* exp_avg, float*
 int mimo_uncertainties(const float* p1, const float* p2, int32_t n, int32_t s, int32_t c, int64_t hw,
                        int32_t loss_kind, float* mean, float* aleatoric, float* epistemic, mimo_stream stream);
 
+/* ---- evidential regression head + loss: replaces the tail of EvidentialUnetModel.forward (mimo/models/
+ * evidential_unet.py:90-96: mu, softplus(logv), softplus(logalpha) + 1, softplus(logbeta)) and EvidentialLoss.forward
+ * (mimo/losses.py:202-247, coeff-free form the reference evaluates) and their autograd backward.
+ * logits [N,4,HW] (the S = 1 backbone output), label [N,HW] or NULL, mask [N,HW] or NULL.
+ * forward : ev [N,4,HW] = (gamma, v, alpha, beta); loss_map [N,HW] = per-pixel loss (x mask), or NULL.
+ * backward: dlogits [N,4,HW] = d_loss [N,HW] (NULL = 0) through the loss  +  d_ev [N,4,HW] (NULL = 0) through the
+ *           softplus heads. */
+int mimo_evidential_forward(const float* logits, const float* label, const float* mask, int32_t n, int64_t hw, float* ev,
+                            float* loss_map, mimo_stream stream);
+int mimo_evidential_backward(const float* logits, const float* label, const float* mask, const float* d_ev,
+                             const float* d_loss, int32_t n, int64_t hw, float* dlogits, mimo_stream stream);
+
 /* ---- validation epilogue: replaces, after the forward, the tail of MimoUnetModel.validation_step
  * (mimo_unet.py:153-183): compute_uncertainties, sqrt of the variances, calculate_dist_param(log=True) +
  * the combined NLL on the ensemble mean, the error map, compute_regression_metrics (metrics.py:22-34:

@@ -306,6 +306,130 @@ extern "C" int mimo_validation_epilogue(const float* out, const float* label, co
   return MIMO_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Evidential regression head + loss (mimo/models/evidential_unet.py:74-96, mimo/losses.py:202-247):
+//   (mu, v, alpha, beta) = (l0, softplus(l1), softplus(l2) + 1, softplus(l3))
+//   loss = G(alpha) / (v sqrt(beta)) * (2 beta (1 + v) + (2 alpha - 1) v (y - mu)^2) + (y - mu)^2 (2 alpha + v),
+//   G(alpha) = Gamma(alpha - 1/2) / (4 Gamma(alpha))
+// One pass for the four NIG parameters + the per-pixel loss, one pass for the gradient w.r.t. the logits (analytic:
+// dG/dalpha = G (psi(alpha - 1/2) - psi(alpha))) instead of ~40 element-wise tensor operations and their autograd
+// nodes.  G is evaluated as exp(lgamma(alpha - 1/2) - lgamma(alpha)) / 4 — the reference exponentiates the two
+// lgammas separately, which overflows fp32 (inf / inf = nan) for alpha > 35; this form stays finite there.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // torch: threshold 20
+__device__ __forceinline__ float sigmoid_f(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float digamma_f(float x) {  // x > 0.5 here (alpha > 1)
+  float r = 0.f;
+  while (x < 6.f) {
+    r -= 1.f / x;
+    x += 1.f;
+  }
+  const float i = 1.f / x, i2 = i * i;
+  return r + logf(x) - 0.5f * i - i2 * (1.f / 12.f - i2 * (1.f / 120.f - i2 * (1.f / 252.f)));
+}
+
+struct NigPoint {
+  float mu, v, alpha, beta, c, T, d;  // c = G / (v sqrt(beta)), T = the bracket, d = y - mu
+};
+__device__ __forceinline__ NigPoint nig_point(float l0, float l1, float l2, float l3, float y) {
+  NigPoint q;
+  q.mu = l0;
+  q.v = softplus_f(l1);
+  q.alpha = softplus_f(l2) + 1.f;
+  q.beta = softplus_f(l3);
+  q.d = y - q.mu;
+  const float G = 0.25f * expf(lgammaf(q.alpha - 0.5f) - lgammaf(q.alpha));
+  q.c = G / (q.v * sqrtf(q.beta));
+  q.T = 2.f * q.beta * (1.f + q.v) + (2.f * q.alpha - 1.f) * q.v * q.d * q.d;
+  return q;
+}
+
+__global__ void evidential_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ label,
+                                      const float* __restrict__ mask, int64_t total, int64_t hw, float* __restrict__ ev,
+                                      float* __restrict__ loss) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / hw, r = i - n * hw;
+    const float* l = logits + n * 4 * hw + r;
+    const NigPoint q = nig_point(l[0], l[hw], l[2 * hw], l[3 * hw], label ? label[i] : 0.f);
+    float* e = ev + n * 4 * hw + r;
+    e[0] = q.mu;
+    e[hw] = q.v;
+    e[2 * hw] = q.alpha;
+    e[3 * hw] = q.beta;
+    if (loss && label) {
+      const float sq = q.d * q.d;
+      float v = q.c * q.T + sq * (2.f * q.alpha + q.v);
+      if (mask) v *= mask[i];
+      loss[i] = v;
+    }
+  }
+}
+
+// dlogits = d_loss * dloss/dlogits (+ d_ev * dev/dlogits): both upstream gradients optional
+__global__ void evidential_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ label,
+                                      const float* __restrict__ mask, const float* __restrict__ d_ev,
+                                      const float* __restrict__ d_loss, int64_t total, int64_t hw, float* __restrict__ dlogits) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / hw, r = i - n * hw;
+    const float* l = logits + n * 4 * hw + r;
+    const float l1 = l[hw], l2 = l[2 * hw], l3 = l[3 * hw];
+    float g_mu = 0.f, g_v = 0.f, g_a = 0.f, g_b = 0.f;
+    if (d_loss && label) {
+      const NigPoint q = nig_point(l[0], l1, l2, l3, label[i]);
+      const float up = d_loss[i] * (mask ? mask[i] : 1.f);
+      const float sq = q.d * q.d, two_a1 = 2.f * q.alpha - 1.f;
+      g_mu = up * (-2.f * q.d) * (q.c * two_a1 * q.v + 2.f * q.alpha + q.v);
+      g_v = up * (-q.c * q.T / q.v + q.c * (2.f * q.beta + two_a1 * sq) + sq);
+      g_a = up * (q.c * (digamma_f(q.alpha - 0.5f) - digamma_f(q.alpha)) * q.T + q.c * 2.f * q.v * sq + 2.f * sq);
+      g_b = up * (-q.c * q.T / (2.f * q.beta) + 2.f * q.c * (1.f + q.v));
+    }
+    if (d_ev) {
+      const float* e = d_ev + n * 4 * hw + r;
+      g_mu += e[0];
+      g_v += e[hw];
+      g_a += e[2 * hw];
+      g_b += e[3 * hw];
+    }
+    float* o = dlogits + n * 4 * hw + r;
+    o[0] = g_mu;
+    o[hw] = g_v * sigmoid_f(l1);
+    o[2 * hw] = g_a * sigmoid_f(l2);
+    o[3 * hw] = g_b * sigmoid_f(l3);
+  }
+}
+
+extern "C" int mimo_evidential_forward(const float* logits, const float* label, const float* mask, int32_t n, int64_t hw,
+                                       float* ev, float* loss_map, mimo_stream stream) {
+  using namespace mimo;
+  if (!logits || !ev || n < 0 || hw < 0 || (loss_map && !label)) {
+    set_error("mimo_evidential_forward: invalid argument");
+    return MIMO_ERR_INVALID;
+  }
+  const int64_t total = (int64_t)n * hw;
+  if (total == 0) return MIMO_OK;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 4096);
+  hipLaunchKernelGGL(evidential_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, label, mask, total, hw, ev,
+                     loss_map);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_evidential_backward(const float* logits, const float* label, const float* mask, const float* d_ev,
+                                        const float* d_loss, int32_t n, int64_t hw, float* dlogits, mimo_stream stream) {
+  using namespace mimo;
+  if (!logits || !dlogits || n < 0 || hw < 0 || (d_loss && !label)) {
+    set_error("mimo_evidential_backward: invalid argument");
+    return MIMO_ERR_INVALID;
+  }
+  const int64_t total = (int64_t)n * hw;
+  if (total == 0) return MIMO_OK;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 4096);
+  hipLaunchKernelGGL(evidential_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, label, mask, d_ev, d_loss,
+                     total, hw, dlogits);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
 extern "C" int mimo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
                               mimo_stream stream) {

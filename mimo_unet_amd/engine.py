@@ -217,6 +217,49 @@ def uncertainties(p1: torch.Tensor, p2: torch.Tensor, loss: str = "laplace_nll")
     return tuple(outs)
 
 
+class _EvidentialHeadLoss(torch.autograd.Function):
+    """(ev, loss_map) = evidential head + loss of the backbone logits [B,4,H,W] in one kernel; the backward is one
+    kernel too (include/mimo_hip.h mimo_evidential_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, logits, label, mask):
+        lib = L.load()
+        logits = logits.contiguous().float()
+        b, four, h, w = logits.shape
+        assert four == 4 and logits.is_cuda
+        label_c = None if label is None else label.reshape(b, h * w).contiguous().float()
+        mask_c = None if mask is None else mask.reshape(b, h * w).contiguous().float()
+        ev = torch.empty_like(logits)
+        loss = torch.empty(b, h, w, device=logits.device, dtype=torch.float32) if label is not None else None
+        L.check(lib.mimo_evidential_forward(logits.data_ptr(), L.ptr(label_c) or None, L.ptr(mask_c) or None, b, h * w,
+                                            ev.data_ptr(), L.ptr(loss) or None, L.current_stream()), "mimo_evidential_forward")
+        ctx.save_for_backward(logits, label_c, mask_c)
+        if loss is None:
+            loss = torch.zeros(0, device=logits.device)
+            ctx.mark_non_differentiable(loss)
+        return ev, loss
+
+    @staticmethod
+    def backward(ctx, d_ev, d_loss):
+        lib = L.load()
+        logits, label_c, mask_c = ctx.saved_tensors
+        b, _, h, w = logits.shape
+        d_ev = None if d_ev is None else d_ev.contiguous().float()
+        d_loss = None if (d_loss is None or label_c is None) else d_loss.contiguous().float()
+        out = torch.empty_like(logits)
+        L.check(lib.mimo_evidential_backward(logits.data_ptr(), L.ptr(label_c) or None, L.ptr(mask_c) or None,
+                                             L.ptr(d_ev) or None, L.ptr(d_loss) or None, b, h * w, out.data_ptr(),
+                                             L.current_stream()), "mimo_evidential_backward")
+        return out, None, None
+
+
+def evidential_head_loss(logits: torch.Tensor, label: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None):
+    """Backbone logits [B,4,H,W] (+ label [B,1,H,W], mask [B,H,W]) -> (ev [B,4,H,W] = (gamma, v, alpha, beta),
+    per-pixel loss [B,H,W] or None), differentiable w.r.t. the logits."""
+    ev, loss = _EvidentialHeadLoss.apply(logits, label, mask)
+    return ev, (loss if label is not None else None)
+
+
 VAL_SCALARS = ("nll_combined", "mae", "mse", "rmse", "r2", "aleatoric_std_mean", "epistemic_std_mean", "count")
 
 

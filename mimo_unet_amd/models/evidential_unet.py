@@ -2,7 +2,7 @@
 (``mimo/models/evidential_unet.py:13-209``): a single-subnetwork MIMO U-Net backbone with four output
 channels turned into Normal-Inverse-Gamma parameters (softplus heads) and trained with the evidential
 loss.  The backbone is the HIP engine (`MimoUNet`, S = 1, through its generic autograd bridge); the
-softplus heads and the loss are element-wise tensor arithmetic on the [B,4,H,W] logits."""
+softplus heads and the loss are one fused HIP kernel over the [B,4,H,W] logits (one more for their gradient)."""
 from __future__ import annotations
 
 from argparse import ArgumentParser
@@ -11,6 +11,7 @@ from typing import Any, Dict, Literal
 import torch
 import torch.nn.functional as F
 
+from ..engine import evidential_head_loss
 from ..lightning_compat import LightningModule
 from ..losses import EvidentialLoss
 from ..metrics import compute_regression_metrics
@@ -50,15 +51,25 @@ class EvidentialUnetModel(LightningModule):
         """x [B, C_in, H, W] -> [B, 4, H, W] = (gamma, v, alpha, beta)."""
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise ValueError("channel dimension must match in_channels")
-        out = self.model(x.unsqueeze(1)).squeeze(1)
-        mu, logv, logalpha, logbeta = torch.unbind(out, dim=1)
-        return torch.stack([mu, F.softplus(logv), F.softplus(logalpha) + 1, F.softplus(logbeta)], dim=1)
+        return evidential_head_loss(self._logits(x))[0]  # the four heads in one kernel (and one in the backward)
+
+    def _logits(self, x: torch.Tensor) -> torch.Tensor:
+        return self.model(x.unsqueeze(1)).squeeze(1)
+
+    def _forward_with_loss(self, image: torch.Tensor, label: torch.Tensor, mask):
+        """(NIG parameters [B,4,H,W], per-pixel loss [B,H,W]): heads + EvidentialLoss.forward fused into one pass over
+        the logits (mimo_evidential_forward); other loss settings fall back to the loss class on the parameters."""
+        b, _, h, w = image.shape
+        # (a [B,1,H,W] mask would broadcast the reference's [B,H,W] loss map to [B,B,H,W]: left to the loss class)
+        if tuple(label.shape) == (b, 1, h, w) and (mask is None or tuple(mask.shape) == (b, h, w)):
+            return evidential_head_loss(self._logits(image), label, mask)
+        out = self(image)
+        return out, self.loss_fn(out, label, mask=mask)
 
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int) -> Dict[str, torch.Tensor]:
         image, label = batch["image"], batch["label"]
         mask = batch["mask"] if "mask" in batch else None
-        out = self(image)
-        loss = self.loss_fn(out, label, mask=mask)
+        out, loss = self._forward_with_loss(image, label, mask)
         y_pred = self.loss_fn.mode(out).unsqueeze(dim=1)
         aleatoric_std = self.loss_fn.aleatoric_var(out).unsqueeze(dim=1) ** 0.5
         self._log_metrics(y_pred=y_pred, y_true=label, stage="train")
@@ -69,8 +80,7 @@ class EvidentialUnetModel(LightningModule):
         image, label = batch["image"], batch["label"]
         mask = batch["mask"] if "mask" in batch else None
         with torch.no_grad():
-            out = self(image)
-            loss = self.loss_fn.forward(out, label, mask=mask, reduce_mean=False)
+            out, loss = self._forward_with_loss(image, label, mask)
             y_pred = self.loss_fn.mode(out).unsqueeze(dim=1)
             aleatoric_std = self.loss_fn.aleatoric_var(out).unsqueeze(dim=1) ** 0.5
             epistemic_std = self.loss_fn.epistemic_var(out).unsqueeze(dim=1) ** 0.5
