@@ -80,6 +80,8 @@ typedef struct mimo_config {
   int32_t inference_only;    /* != 0: no buffers for a backward (pre-activations, activation gradients, dz /
                               * weight-gradient scratch, data-gradient weights); mimo_forward then requires
                               * training = 0 and no_grad = 1.  What torch.no_grad() + eval() means for memory. */
+  float center_dropout_rate, final_dropout_rate; /* element-wise nn.Dropout (model.py:213, :277-281): the rates the
+                              * in-engine generator uses for those sites (mimo_forward_args.rng_sites) */
 } mimo_config;
 
 const char* mimo_last_error(void);
@@ -133,11 +135,24 @@ typedef struct mimo_forward_args {
    *     the packed weight copies and BatchNorm scale/shift of the previous call. */
   int32_t no_grad;
   int64_t param_version;
+  /* In-engine dropout (replaces the Bernoulli draws inside nn.Dropout2d / nn.Dropout, components.py:29,
+   * model.py:213,277-281, incl. the MC-dropout passes of ensemble.py:54-66).  rng_sites: host array
+   * [num_double_convs + 1 + S] or NULL; a non-zero entry makes the engine draw that site's multipliers itself
+   * (Dropout2d sites in DoubleConv order with the config's encoder / core / decoder rates, then center_dropout, then
+   * final_dropouts[s]) from a Philox4x32-10 stream keyed by (rng_seed, rng_offset) — take both from the caller's
+   * generator and advance its offset.  The backward regenerates the element-wise multipliers from the same pair.
+   * Sites given through drop_masks / elem_masks keep their recorded multipliers (parity tests). */
+  const uint8_t* rng_sites;
+  uint64_t rng_seed, rng_offset;
   /* batch rows of the x tensor (= of the label / mask tensors later given to mimo_loss_forward); 0 = the plan's
    * batch.  With perm the gather may repeat rows (batch_repetitions, utils.py:27-31), so x can hold fewer rows than
    * the plan's batch; the staged (hipGraph) paths copy exactly this many. */
   int64_t x_rows;
 } mimo_forward_args;
+/* The dropout multipliers of one site as the last mimo_forward used them (tests, and recording a run for bit-level
+ * replay through drop_masks / elem_masks): site < num_double_convs -> [N][Cout]; num_double_convs + j -> the
+ * element-wise site j (0 = center, 1 + s = final s) in the reference's layout [N][C][H'][W']. */
+int mimo_plan_dropout_mask(mimo_plan* plan, int site, float* dst, mimo_stream stream);
 int mimo_plan_num_double_convs(const mimo_plan* plan);
 int mimo_plan_double_conv_channels(const mimo_plan* plan, int index); /* Cout of DoubleConv #index */
 int mimo_forward(mimo_plan* plan, const mimo_forward_args* args, mimo_stream stream);

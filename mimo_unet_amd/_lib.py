@@ -28,7 +28,7 @@ class MimoConfig(C.Structure):
         ("encoder_dropout_rate", C.c_float), ("core_dropout_rate", C.c_float), ("decoder_dropout_rate", C.c_float),
         ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("loss_kind", C.c_int32),
         ("eps_min", C.c_float), ("eps_max", C.c_float), ("device", C.c_int32), ("precision", C.c_int32),
-        ("inference_only", C.c_int32),
+        ("inference_only", C.c_int32), ("center_dropout_rate", C.c_float), ("final_dropout_rate", C.c_float),
     ]
 
 
@@ -37,6 +37,7 @@ class ForwardArgs(C.Structure):
         ("x", C.c_void_p), ("stride_n", C.c_int64), ("stride_s", C.c_int64), ("perm", C.c_void_p),
         ("training", C.c_int32), ("drop_masks", C.POINTER(C.c_void_p)), ("out", C.c_void_p),
         ("elem_masks", C.POINTER(C.c_void_p)), ("no_grad", C.c_int32), ("param_version", C.c_int64),
+        ("rng_sites", C.POINTER(C.c_uint8)), ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64),
         ("x_rows", C.c_int64),
     ]
 
@@ -60,6 +61,7 @@ _SIGNATURES = {
     "mimo_plan_param_floats": (_L, [_P]),
     "mimo_plan_buffer_floats": (_L, [_P]),
     "mimo_plan_bind": (C.c_int, [_P, _P, _P, _P]),
+    "mimo_plan_dropout_mask": (C.c_int, [_P, C.c_int, _P, _P]),
     "mimo_plan_num_double_convs": (C.c_int, [_P]),
     "mimo_plan_double_conv_channels": (C.c_int, [_P, C.c_int]),
     "mimo_forward": (C.c_int, [_P, C.POINTER(ForwardArgs), _P]),

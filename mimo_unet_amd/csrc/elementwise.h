@@ -81,7 +81,25 @@ int up_bwd_launch(const void* dxpad, int dt, int ldp, int choff, void* da, int l
                   int Cp, int accumulate, hipStream_t st);
 
 // a[N,HW] (ld) *= mask, mask in the reference's NCHW layout [N][C][HW] (nn.Dropout multipliers)
-int elem_mask_mul_launch(void* a, int dt, int ld, const float* mask, int N, int C, int Cp, int HW, hipStream_t st);
+// mask == nullptr: multipliers from the Philox stream `rng` (same values in forward and backward)
+struct ElemRng {
+  uint64_t seed, offset;
+  int site;  // distinguishes the streams of the sites sharing one (seed, offset)
+  float p;   // drop probability
+};
+int elem_mask_mul_launch(void* a, int dt, int ld, const float* mask, int N, int C, int Cp, int HW, hipStream_t st,
+                         const ElemRng* rng = nullptr);
+// the same multipliers written out in the reference's layout [N][C][HW]
+int elem_dropout_mask_launch(float* mask, int N, int C, int Cp, int HW, int site, uint64_t seed, uint64_t offset, float p,
+                             hipStream_t st);
+// Dropout2d (one Bernoulli per (sample, channel), components.py:29): multipliers of all active sites in one launch
+struct Dropout2dSite {
+  float* dst;  // [count] = [N][C]
+  int count;
+  float p;
+};
+int dropout2d_masks_launch(const Dropout2dSite* sites_dev, int nsites, int max_count, uint64_t active, uint64_t seed,
+                           uint64_t offset, hipStream_t st);
 
 // ---- BatchNorm + ReLU backward ------------------------------------------------------------
 // dy = da * mask * [z*scale+shift > 0] is evaluated on the fly by both passes (never stored).

@@ -856,13 +856,88 @@ int fold_slice_launch(const void* dxpad, int dt, int ldp, int choff, void* da, i
   return MIMO_OK;
 }
 
+// ---- in-engine dropout masks: Philox4x32-10 (Salmon et al., the counter-based generator torch's CUDA / HIP dropout
+// uses), keyed by a (seed, offset) pair the caller takes from its generator.  A multiplier depends only on (seed,
+// offset, site, element index), so the backward regenerates exactly what the forward used and nothing is stored for
+// the element-wise sites.  Statistically equivalent to the reference's Bernoulli draws (keep with probability 1 - p,
+// scale by 1 / (1 - p)); bit-level parity with recorded masks stays available through the mask arguments.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+  constexpr unsigned int M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned int hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+    const unsigned int hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += W0;
+    key.y += W1;
+  }
+  return ctr;
+}
+__device__ __forceinline__ float4 philox_keep4(unsigned int i0, unsigned int i1, unsigned int site, uint64_t seed, uint64_t offset,
+                                               float p, float inv_keep) {
+  const uint4 r = philox4x32_10(make_uint4(i0, i1, (unsigned int)offset ^ (site << 24), (unsigned int)(offset >> 32)),
+                                make_uint2((unsigned int)seed, (unsigned int)(seed >> 32)));
+  constexpr float k = 1.f / 16777216.f;  // 24 uniform bits
+  return make_float4((r.x >> 8) * k >= p ? inv_keep : 0.f, (r.y >> 8) * k >= p ? inv_keep : 0.f,
+                     (r.z >> 8) * k >= p ? inv_keep : 0.f, (r.w >> 8) * k >= p ? inv_keep : 0.f);
+}
+
+// Dropout2d multipliers [N][C] of every active site in one launch (blockIdx.y = site, bit `site` of `active`)
+__global__ void dropout2d_masks_kernel(const Dropout2dSite* __restrict__ sites, uint64_t active, uint64_t seed, uint64_t offset) {
+  const int site = blockIdx.y;
+  if (!((active >> site) & 1)) return;
+  const Dropout2dSite t = sites[site];
+  const float inv_keep = 1.f / (1.f - t.p);
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; 4 * q < t.count; q += gridDim.x * blockDim.x) {
+    const float4 m = philox_keep4((unsigned int)q, 0u, (unsigned int)site, seed, offset, t.p, inv_keep);
+    const float mv[4] = {m.x, m.y, m.z, m.w};
+    for (int j = 0; j < 4 && 4 * q + j < t.count; ++j) t.dst[4 * q + j] = mv[j];
+  }
+}
+
+int dropout2d_masks_launch(const Dropout2dSite* sites_dev, int nsites, int max_count, uint64_t active, uint64_t seed,
+                           uint64_t offset, hipStream_t st) {
+  if (!active || nsites <= 0) return MIMO_OK;
+  const int gx = std::max(1, std::min(ceil_div(ceil_div(max_count, 4), 256), 64));
+  hipLaunchKernelGGL(dropout2d_masks_kernel, dim3(gx, nsites), dim3(256), 0, st, sites_dev, active, seed, offset);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// the element-wise multipliers of one site in the reference's NCHW layout [N][C][HW] (tests / recorded-mask parity)
+__global__ void elem_dropout_mask_kernel(float* __restrict__ mask, int N, int C, int Cv, int HW, unsigned int site, uint64_t seed,
+                                         uint64_t offset, float p) {
+  const float inv_keep = 1.f / (1.f - p);
+  const int64_t total = (int64_t)N * Cv * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i % HW);
+    const int nq = (int)(i / HW);
+    const int n = nq / Cv, q = nq - n * Cv;
+    const float4 m = philox_keep4((unsigned int)r, (unsigned int)nq, site, seed, offset, p, inv_keep);
+    const float mv[4] = {m.x, m.y, m.z, m.w};
+    for (int j = 0; j < 4 && 4 * q + j < C; ++j) mask[((size_t)n * C + 4 * q + j) * HW + r] = mv[j];
+  }
+}
+
+int elem_dropout_mask_launch(float* mask, int N, int C, int Cp, int HW, int site, uint64_t seed, uint64_t offset, float p,
+                             hipStream_t st) {
+  const int64_t total = (int64_t)N * (Cp / 4) * HW;
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(elem_dropout_mask_kernel, dim3(blocks), dim3(256), 0, st, mask, N, C, Cp / 4, HW, (unsigned int)site, seed,
+                     offset, p);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
 // ---- element-wise dropout (nn.Dropout after down4 and in front of each 1x1 head) -------------
 // a[n,p,c] *= mask[n,c,p]: the multipliers arrive in the reference's NCHW layout, so one thread owns a
 // pixel (coalesced mask reads per channel plane) and walks its own contiguous channel row of `a`.
+// mask == nullptr: the multipliers come from the Philox stream (rng), regenerated identically by the backward
 template <typename T>
 __global__ void elem_mask_mul_kernel(T* __restrict__ a, int ld, const float* __restrict__ mask, int N, int C, int Cv,
-                                     int HW) {
+                                     int HW, ElemRng rng) {
   const int64_t P = (int64_t)N * HW;
+  const float inv_keep = 1.f / (1.f - rng.p);
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(p / HW);
     const int r = (int)(p - (int64_t)n * HW);
@@ -871,19 +946,34 @@ __global__ void elem_mask_mul_kernel(T* __restrict__ a, int ld, const float* __r
     for (int q = 0; q < Cv; ++q) {
       float4 v = ld4(row + 4 * q);
       const int c = 4 * q;
-      v.x *= c + 0 < C ? m[(size_t)(c + 0) * HW] : 1.f;
-      v.y *= c + 1 < C ? m[(size_t)(c + 1) * HW] : 1.f;
-      v.z *= c + 2 < C ? m[(size_t)(c + 2) * HW] : 1.f;
-      v.w *= c + 3 < C ? m[(size_t)(c + 3) * HW] : 1.f;
+      if (mask) {
+        v.x *= c + 0 < C ? m[(size_t)(c + 0) * HW] : 1.f;
+        v.y *= c + 1 < C ? m[(size_t)(c + 1) * HW] : 1.f;
+        v.z *= c + 2 < C ? m[(size_t)(c + 2) * HW] : 1.f;
+        v.w *= c + 3 < C ? m[(size_t)(c + 3) * HW] : 1.f;
+      } else {
+        const float4 k = philox_keep4((unsigned int)r, (unsigned int)(n * Cv + q), (unsigned int)rng.site, rng.seed, rng.offset,
+                                      rng.p, inv_keep);
+        v.x *= k.x;
+        v.y *= k.y;
+        v.z *= k.z;
+        v.w *= k.w;
+      }
       st4(row + 4 * q, v);
     }
   }
 }
 
-int elem_mask_mul_launch(void* a, int dt, int ld, const float* mask, int N, int C, int Cp, int HW, hipStream_t st) {
+int elem_mask_mul_launch(void* a, int dt, int ld, const float* mask, int N, int C, int Cp, int HW, hipStream_t st,
+                         const ElemRng* rng) {
   const int64_t P = (int64_t)N * HW;
   const int blocks = (int)std::min<int64_t>((P + 255) / 256, 4096);
-  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(elem_mask_mul_kernel<T>, dim3(blocks), dim3(256), 0, st, (T*)a, ld, mask, N, C, Cp / 4, HW));
+  if (!mask && !rng) {
+    set_error("elem_mask_mul: neither a mask nor a generator state");
+    return MIMO_ERR_INVALID;
+  }
+  const ElemRng g = rng ? *rng : ElemRng{0, 0, 0, 0.f};
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(elem_mask_mul_kernel<T>, dim3(blocks), dim3(256), 0, st, (T*)a, ld, mask, N, C, Cp / 4, HW, g));
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

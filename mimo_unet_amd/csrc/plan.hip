@@ -267,6 +267,16 @@ struct mimo_plan {
   int64_t* g_perm = nullptr;
   std::vector<float*> g_masks;
   std::vector<const float*> g_mask_ptrs;
+  // in-engine dropout (mimo_forward_args.rng_sites): Dropout2d multipliers are drawn into g_masks by one Philox
+  // launch per forward; the element-wise sites (center / final nn.Dropout) regenerate theirs on the fly in the
+  // forward and in the backward from the (seed, offset) of the last forward
+  Dropout2dSite* d_sites = nullptr;
+  int max_site_count = 0;
+  uint64_t rng_seed = 0, rng_offset = 0;
+  std::vector<char> elem_rng_on;  // [1 + S]
+  std::vector<const float*> eff_masks;
+  float elem_rate(int j) const { return j == 0 ? cfg.center_dropout_rate : cfg.final_dropout_rate; }
+  ElemRng elem_rng(int j) const { return ElemRng{rng_seed, rng_offset, (int)dcs.size() + j, elem_rate(j)}; }
 
   // MIMO_SUBNET_STREAMS=1 (opt-in, forward only): the S private encoder / decoder chains are independent until
   // the concat / after the core, so they are issued on S streams — one chain's bandwidth-bound BatchNorm /
@@ -759,6 +769,21 @@ struct mimo_plan {
     g_masks.resize(dcs.size());
     g_mask_ptrs.assign(dcs.size(), nullptr);
     for (size_t i = 0; i < dcs.size(); ++i) MIMO_TRY(dalloc(&g_masks[i], (size_t)N * dcs[i]->c2.Cout));
+    {
+      if (dcs.size() + 1 + S > 56) {
+        set_error("too many dropout sites (%d) for the in-engine generator", (int)dcs.size() + 1 + S);
+        return MIMO_ERR_INVALID;
+      }
+      std::vector<Dropout2dSite> sites(dcs.size());
+      for (size_t i = 0; i < dcs.size(); ++i) {
+        sites[i] = Dropout2dSite{g_masks[i], N * dcs[i]->c2.Cout, dcs[i]->drop_p};
+        max_site_count = std::max(max_site_count, sites[i].count);
+      }
+      MIMO_TRY(dalloc(&d_sites, sites.size()));
+      MIMO_HIP_CHECK(hipMemcpy(d_sites, sites.data(), sites.size() * sizeof(Dropout2dSite), hipMemcpyHostToDevice));
+      elem_rng_on.assign(1 + S, 0);
+      eff_masks.assign(dcs.size(), nullptr);
+    }
     MIMO_HIP_CHECK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     return MIMO_OK;
   }
@@ -868,6 +893,37 @@ struct mimo_plan {
       set_error("mimo_forward: inference-only plan (mimo_config.inference_only) needs training = 0 and no_grad = 1");
       return MIMO_ERR_STATE;
     }
+    // ---- in-engine dropout: draw the Dropout2d multipliers of the flagged sites, note the element-wise ones ----
+    mimo_forward_args a2 = *args;
+    {
+      const int ndc = (int)dcs.size();
+      uint64_t active = 0;
+      bool any_mask = false;
+      for (int i = 0; i < ndc; ++i) {
+        eff_masks[i] = args->drop_masks ? args->drop_masks[i] : nullptr;
+        if (args->rng_sites && args->rng_sites[i] && dcs[i]->drop_p > 0.f) {
+          active |= 1ull << i;
+          eff_masks[i] = g_masks[i];
+        }
+        any_mask |= eff_masks[i] != nullptr;
+      }
+      rng_seed = args->rng_seed;
+      rng_offset = args->rng_offset;
+      bool any_elem = false;
+      for (int j = 0; j <= S; ++j) {
+        elem_rng_on[j] = args->rng_sites && args->rng_sites[ndc + j] && elem_rate(j) > 0.f &&
+                         !(args->elem_masks && args->elem_masks[j]);
+        any_elem |= elem_rng_on[j] != 0;
+      }
+      MIMO_TRY(dropout2d_masks_launch(d_sites, ndc, max_site_count, active, rng_seed, rng_offset, (hipStream_t)st));
+      a2.drop_masks = any_mask ? eff_masks.data() : nullptr;
+      a2.rng_sites = nullptr;
+      if (any_elem && !a2.elem_masks) {  // keeps the call off the hipGraph paths (the generator state changes per call)
+        static const float* const kNoElemMasks[64] = {};
+        a2.elem_masks = kNoElemMasks;
+      }
+      args = &a2;
+    }
     // what has to be (re)derived from the parameters in this call, and whether anything is kept for a backward
     const bool training_call = args->training != 0;
     fwd_no_grad = !training_call && args->no_grad != 0;
@@ -894,7 +950,7 @@ struct mimo_plan {
     for (size_t i = 0; i < dcs.size(); ++i) {
       const bool on = args->drop_masks && args->drop_masks[i];
       g_mask_ptrs[i] = on ? g_masks[i] : nullptr;
-      if (on)
+      if (on && args->drop_masks[i] != g_masks[i])  // (an in-engine site was drawn straight into the staging buffer)
         MIMO_HIP_CHECK(hipMemcpyAsync(g_masks[i], args->drop_masks[i], (size_t)N * dcs[i]->c2.Cout * sizeof(float),
                                       hipMemcpyDeviceToDevice, st));
     }
@@ -1007,8 +1063,11 @@ struct mimo_plan {
     MIMO_TRY(dc_forward(down4, training, st));
     // center_dropout: in place on down4's output, whose only reader is up1's upsample (the BN/ReLU
     // backward recomputes its mask from z, not from a)
-    if (elem_masks[0]) MIMO_TRY(elem_mask_mul_launch(down4->out.a, this->st, down4->out.ld, elem_masks[0], N, down4->out.C,
-                                                     down4->out.Cp, down4->out.H * down4->out.W, st));
+    if (elem_masks[0] || elem_rng_on[0]) {
+      const ElemRng g = elem_rng(0);
+      MIMO_TRY(elem_mask_mul_launch(down4->out.a, this->st, down4->out.ld, elem_masks[0], N, down4->out.C, down4->out.Cp,
+                                    down4->out.H * down4->out.W, st, elem_masks[0] ? nullptr : &g));
+    }
     MIMO_TRY(dc_forward(up1, training, st));
     MIMO_TRY(dc_forward(up2, training, st));
     MIMO_TRY(dc_forward(up3, training, st));
@@ -1019,7 +1078,11 @@ struct mimo_plan {
       MIMO_TRY(dc_forward(up4[s], training, st));
       const Act& o = up4[s]->out;
       // final_dropouts[s]: in place, the head (forward and weight gradient) is the only reader
-      if (elem_masks[1 + s]) MIMO_TRY(elem_mask_mul_launch(o.a, this->st, o.ld, elem_masks[1 + s], N, o.C, o.Cp, H * W, st));
+      if (elem_masks[1 + s] || elem_rng_on[1 + s]) {
+        const ElemRng g = elem_rng(1 + s);
+        MIMO_TRY(elem_mask_mul_launch(o.a, this->st, o.ld, elem_masks[1 + s], N, o.C, o.Cp, H * W, st,
+                                      elem_masks[1 + s] ? nullptr : &g));
+      }
       const int blk = prof_begin(kProfTierBase, st);
       const int pr = prof_begin(MIMO_PROF_HEAD_FWD, st);
       MIMO_TRY(head_fwd_launch(o.a, this->st, o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co, N, S, s, H * W,
@@ -1323,8 +1386,14 @@ struct mimo_plan {
                                    st));
           prof_end(pr, 0.0, 4.0 * (double)N * H * W * (2.0 * fp + Co + Co / 2), st);
           MIMO_TRY(head_bwd_stats_launch(s_partial, rows, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, colsum(), st));
-          if (!elem_masks.empty() && elem_masks[1 + s])
-            MIMO_TRY(elem_mask_mul_launch(dc->out.da, this->st, dc->out.ldda, elem_masks[1 + s], N, dc->out.C, dc->out.Cp, H * W, st));
+          {
+            const float* em = elem_masks.empty() ? nullptr : elem_masks[1 + s];
+            if (em || elem_rng_on[1 + s]) {
+              const ElemRng g = elem_rng(1 + s);
+              MIMO_TRY(elem_mask_mul_launch(dc->out.da, this->st, dc->out.ldda, em, N, dc->out.C, dc->out.Cp, H * W, st,
+                                            em ? nullptr : &g));
+            }
+          }
           prof_end(blk, 0.0, 0.0, st);
           MIMO_TRY(dc_backward(dc, true, st));
         }
@@ -1334,9 +1403,14 @@ struct mimo_plan {
       case 2: return dc_backward(up2, true, st);
       case 3: return dc_backward(up1, true, st);
       case 4:
-        if (!elem_masks.empty() && elem_masks[0])
-          MIMO_TRY(elem_mask_mul_launch(down4->out.da, this->st, down4->out.ldda, elem_masks[0], N, down4->out.C, down4->out.Cp,
-                                        down4->out.H * down4->out.W, st));
+        {
+          const float* em = elem_masks.empty() ? nullptr : elem_masks[0];
+          if (em || elem_rng_on[0]) {
+            const ElemRng g = elem_rng(0);
+            MIMO_TRY(elem_mask_mul_launch(down4->out.da, this->st, down4->out.ldda, em, N, down4->out.C, down4->out.Cp,
+                                          down4->out.H * down4->out.W, st, em ? nullptr : &g));
+          }
+        }
         return dc_backward(down4, true, st);
       case 5: return dc_backward(down3, true, st);
       case 6: return dc_backward(down2, true, st);
@@ -1419,6 +1493,32 @@ int mimo_plan_bind(mimo_plan* plan, float* params, float* grads, float* bn_buffe
   plan->grads = grads;
   plan->bnbuf = bn_buffers;
   return MIMO_OK;
+}
+
+int mimo_plan_dropout_mask(mimo_plan* plan, int site, float* dst, mimo_stream stream) {
+  if (!plan || !dst || site < 0 || site >= (int)plan->dcs.size() + 1 + plan->S) {
+    set_error("mimo_plan_dropout_mask: bad argument");
+    return MIMO_ERR_INVALID;
+  }
+  const int ndc = (int)plan->dcs.size();
+  if (site < ndc) {  // Dropout2d: the multipliers the last forward used (drawn in the engine or staged from the caller)
+    const float* src = plan->dcs[site]->mask;
+    const size_t n = (size_t)plan->N * plan->dcs[site]->c2.Cout;
+    if (!src) {
+      set_error("mimo_plan_dropout_mask: site %d had no mask in the last forward", site);
+      return MIMO_ERR_STATE;
+    }
+    MIMO_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MIMO_OK;
+  }
+  const int j = site - ndc;
+  if (!plan->elem_rng_on[j]) {
+    set_error("mimo_plan_dropout_mask: element-wise site %d was not drawn by the engine in the last forward", j);
+    return MIMO_ERR_STATE;
+  }
+  const Act& o = j == 0 ? plan->down4->out : plan->up4[j - 1]->out;
+  const ElemRng g = plan->elem_rng(j);
+  return elem_dropout_mask_launch(dst, plan->N, o.C, o.Cp, o.H * o.W, g.site, g.seed, g.offset, g.p, (hipStream_t)stream);
 }
 
 int mimo_plan_profile(mimo_plan* plan, int enable) {

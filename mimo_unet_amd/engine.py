@@ -36,6 +36,8 @@ class NetGeometry:
     encoder_dropout_rate: float = 0.0
     core_dropout_rate: float = 0.0
     decoder_dropout_rate: float = 0.0
+    center_dropout_rate: float = 0.0
+    final_dropout_rate: float = 0.0
     loss: str = "laplace_nll"
     # arithmetic / storage: "fp32" | "split16" | "bf16" | "bf16-mixed" | "16-mixed" (include/mimo_hip.h mimo_precision)
     precision: str = "split16"
@@ -54,7 +56,7 @@ class Plan:
             geom.in_channels, geom.out_channels, geom.num_subnetworks, geom.filter_base_count, batch, height, width,
             geom.encoder_dropout_rate, geom.core_dropout_rate, geom.decoder_dropout_rate,
             1e-5, 0.1, L.LOSS_KINDS[geom.loss], 1e-5, 1e3, device.index or 0, L.PRECISIONS[geom.precision],
-            int(bool(inference_only)))
+            int(bool(inference_only)), geom.center_dropout_rate, geom.final_dropout_rate)
         self.inference_only = bool(inference_only)
         handle = C.c_void_p()
         with torch.cuda.device(device):
@@ -111,13 +113,16 @@ class Plan:
     def forward(self, x: torch.Tensor, out: torch.Tensor, *, training: bool, perm: Optional[torch.Tensor] = None,
                 masks: Optional[Sequence[Optional[torch.Tensor]]] = None, broadcast_subnetworks: bool = False,
                 elem_masks: Optional[Sequence[Optional[torch.Tensor]]] = None, no_grad: bool = False,
-                param_version: int = 0) -> None:
+                param_version: int = 0, rng: Optional[Tuple[Sequence[bool], int, int]] = None) -> None:
         """x: [N,S,Ci,H,W] (or [N,Ci,H,W] with perm / broadcast) contiguous fp32 on the plan's device.
         masks: per DoubleConv [N,C] Dropout2d multipliers; elem_masks: [center, final_0 .. final_{S-1}]
         full-shape nn.Dropout multipliers (NCHW, fp32, contiguous) or None entries.
         no_grad (eval mode only): no backward follows — BatchNorm/ReLU run in the conv epilogue.
         param_version: changes whenever parameters / BN buffers may have changed (0 = unknown); equal
-        versions let eval-mode calls reuse the packed weights of the previous call."""
+        versions let eval-mode calls reuse the packed weights of the previous call.
+        rng: (sites, seed, offset) — sites[i] truthy makes the engine draw the dropout multipliers of site i itself
+        (DoubleConv Dropout2d sites in order, then center_dropout, then final_dropouts[s]) from a Philox stream keyed
+        by (seed, offset)."""
         g = self.geom
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         if x.dim() == 5:
@@ -135,11 +140,32 @@ class Plan:
             for m in elem_masks:
                 assert m is None or (m.is_cuda and m.dtype == torch.float32 and m.is_contiguous())
             elem_arr = (C.c_void_p * len(elem_masks))(*[L.ptr(m) or None for m in elem_masks])
+        rng_arr, rng_seed, rng_offset = None, 0, 0
+        if rng is not None and any(rng[0]):
+            assert len(rng[0]) == self.num_double_convs + 1 + g.num_subnetworks
+            rng_arr = (C.c_uint8 * len(rng[0]))(*[1 if f else 0 for f in rng[0]])
+            rng_seed, rng_offset = int(rng[1]) & (2 ** 64 - 1), int(rng[2]) & (2 ** 64 - 1)
         args = L.ForwardArgs(x.data_ptr(), stride_n, stride_s, L.ptr(perm) or None, int(training),
                              C.cast(mask_arr, C.POINTER(C.c_void_p)) if mask_arr is not None else None, out.data_ptr(),
                              C.cast(elem_arr, C.POINTER(C.c_void_p)) if elem_arr is not None else None,
-                             int(bool(no_grad) and not training), int(param_version), int(x.shape[0]))
+                             int(bool(no_grad) and not training), int(param_version), rng_arr, rng_seed, rng_offset,
+                             int(x.shape[0]))
         L.check(self.lib.mimo_forward(self.handle, C.byref(args), L.current_stream()), "mimo_forward")
+
+    def dropout_mask(self, site: int) -> torch.Tensor:
+        """Dropout multipliers of the last forward: site < num_double_convs -> [N, C]; num_double_convs + j -> the
+        element-wise site j (0 center, 1 + s final s) as [N, C, H', W'] (only when the engine drew it)."""
+        g = self.geom
+        S, f, n = g.num_subnetworks, g.filter_base_count, self.batch
+        if site < self.num_double_convs:
+            shape = (n, self.double_conv_channels[site])
+        elif site == self.num_double_convs:
+            shape = (n, 8 * f * S, self.height // 16, self.width // 16)
+        else:
+            shape = (n, f, self.height, self.width)
+        out = torch.empty(shape, device=self.device, dtype=torch.float32)
+        L.check(self.lib.mimo_plan_dropout_mask(self.handle, site, out.data_ptr(), L.current_stream()), "mimo_plan_dropout_mask")
+        return out
 
     def loss_forward(self, label: torch.Tensor, mask: Optional[torch.Tensor], perm: Optional[torch.Tensor],
                      loss_out: torch.Tensor) -> None:

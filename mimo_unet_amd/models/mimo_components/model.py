@@ -107,14 +107,14 @@ class _NetFunction(torch.autograd.Function):
     """out (and optionally the per-subnetwork loss vector) = net(x); gradients through the C ABI."""
 
     @staticmethod
-    def forward(ctx, net: "MimoUNet", x, label, lmask, perm, masks, bn_training, elem_masks, *params):
+    def forward(ctx, net: "MimoUNet", x, label, lmask, perm, masks, bn_training, elem_masks, rng, *params):
         ctx.set_materialize_grads(False)
         plan = net._plan_for(x, perm)
         n = plan.batch
         S, Co = net.num_subnetworks, net.out_channels
         out = torch.empty(n, S, Co, plan.height, plan.width, device=x.device, dtype=torch.float32)
         plan.bind(net._flat_params, net._flat_grads, net._flat_buffers)
-        plan.forward(x, out, training=bn_training, perm=perm, masks=masks, elem_masks=elem_masks)
+        plan.forward(x, out, training=bn_training, perm=perm, masks=masks, elem_masks=elem_masks, rng=rng)
         if label is not None:
             loss = torch.empty(S, device=x.device, dtype=torch.float32)
             plan.loss_forward(label, lmask, perm, loss)
@@ -131,7 +131,7 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dloss):
         net, plan = ctx.net, ctx.plan
-        n_in = 8 + len(net._param_list)
+        n_in = 9 + len(net._param_list)
         if dout is None and (dloss is None or not ctx.has_loss):
             return (None,) * n_in
         if plan.generation != ctx.generation:
@@ -146,7 +146,7 @@ class _NetFunction(torch.autograd.Function):
         dout_c = None if dout is None else dout.contiguous().float()
         dloss_c = None if (dloss is None or not ctx.has_loss) else dloss.contiguous().float()
         net._run_backward(plan, dout_c, dloss_c, dx)
-        return (None, dx, None, None, None, None, None, None) + (None,) * len(net._param_list)
+        return (None, dx, None, None, None, None, None, None, None) + (None,) * len(net._param_list)
 
 
 class MimoUNet(nn.Module):
@@ -174,7 +174,10 @@ class MimoUNet(nn.Module):
         # arithmetic of the 3x3 forward / data-gradient convolutions (include/mimo_hip.h mimo_precision)
         precision = os.environ.get("MIMO_PRECISION", "split16")
         self._geom = NetGeometry(in_channels, out_channels, S, f, encoder_dropout_rate, core_dropout_rate,
-                                 decoder_dropout_rate, loss, precision)
+                                 decoder_dropout_rate, center_dropout_rate, final_dropout_rate, loss, precision)
+        # Dropout masks are drawn inside the engine (Philox stream keyed by torch's CUDA generator: torch.manual_seed
+        # governs them); False: drawn with torch.bernoulli on the device and handed over as tensors
+        self.engine_rng = os.environ.get("MIMO_ENGINE_RNG", "1") != "0"
         # one plan per (batch, H, W, device, inference-only); least recently used plans are dropped beyond
         # MIMO_PLAN_CACHE entries (a plan owns its whole activation workspace: ragged last batches, separate
         # train / val batch sizes and variable image sizes would otherwise pile up multi-GB plans)
@@ -329,6 +332,20 @@ class MimoUNet(nn.Module):
             out.append(m)
         return out if any_mask else None
 
+    def _engine_rng_sites(self, device):
+        """(sites, seed, offset) for the in-engine generator, or None when no dropout module is active / recorded
+        masks are injected.  Advances torch's CUDA generator offset like a torch dropout call would."""
+        if not self.engine_rng or self.mask_override is not None or self.elem_mask_override is not None:
+            return None
+        drops = [dc.dropout for dc in self.double_convs()] + [self.core.center_dropout] + list(self.decoder.final_dropouts)
+        sites = [bool(d.p > 0.0 and d.training) for d in drops]
+        if not any(sites):
+            return None
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        seed, offset = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(offset + 4)  # one Philox counter block per forward: every site / element has its own sub-stream
+        return sites, seed, offset
+
     def _bn_training(self) -> bool:
         return self.encoder.in_convs[0].norm.training
 
@@ -341,8 +358,9 @@ class MimoUNet(nn.Module):
         x = x.contiguous().float()
         n = perm.shape[1] if perm is not None else x.shape[0]
         bn_training = self._bn_training()
-        masks = self._dropout_masks(n, x.device)
-        elem_masks = self._elem_dropout_masks(n, x.shape[-2], x.shape[-1], x.device)
+        rng = self._engine_rng_sites(x.device) if x.is_cuda else None
+        masks = None if rng is not None else self._dropout_masks(n, x.device)
+        elem_masks = None if rng is not None else self._elem_dropout_masks(n, x.shape[-2], x.shape[-1], x.device)
         # make sure the flat storage exists before the parameters are handed to autograd
         inference = not bn_training and not torch.is_grad_enabled()
         plan = self._plan_for(x, perm, inference=inference)
@@ -353,7 +371,7 @@ class MimoUNet(nn.Module):
                               dtype=torch.float32)
             plan.bind(self._flat_params, self._flat_grads, self._flat_buffers)
             plan.forward(x, out, training=False, perm=perm, masks=masks, elem_masks=elem_masks, no_grad=True,
-                         param_version=self._param_version())
+                         param_version=self._param_version(), rng=rng)
             plan.generation += 1
             self._inference_keep = (x, perm, masks, elem_masks)  # the plan still points at the mask tensors
             if label is None:
@@ -361,7 +379,7 @@ class MimoUNet(nn.Module):
             loss = torch.empty(self.num_subnetworks, device=x.device, dtype=torch.float32)
             plan.loss_forward(label, lmask, perm, loss)  # per-subnetwork mean NLL (validation)
             return out, loss
-        out, loss = _NetFunction.apply(self, x, label, lmask, perm, masks, bn_training, elem_masks, *self._param_list)
+        out, loss = _NetFunction.apply(self, x, label, lmask, perm, masks, bn_training, elem_masks, rng, *self._param_list)
         if bn_training:
             self._bump_batch_counters()
             self._param_epoch += 1  # the engine updated the running statistics in place

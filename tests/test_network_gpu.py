@@ -785,3 +785,61 @@ def test_evidential_head_loss_kernel_against_reference_golden_and_torch_autograd
     big = torch.tensor([0.3, 1.0, 60.0, 1.0]).view(1, 4, 1, 1).cuda()
     _, lbig = evidential_head_loss(big, torch.zeros(1, 1, 1, 1).cuda())
     assert torch.isfinite(lbig).all()
+
+
+@pytest.mark.parametrize("kind", ["dropout2d", "elementwise"])
+def test_in_engine_philox_dropout(kind):
+    """Dropout multipliers drawn inside the engine (Philox4x32-10 keyed by torch's CUDA generator) instead of torch.bernoulli
+    tensors: (a) torch.manual_seed reproduces a run and the generator offset advances, (b) the multipliers are 0 or
+    1/(1-p) with the right keep rate, independent across sites / samples / channels, (c) forward AND backward used exactly
+    those multipliers: replaying them through the recorded-mask arguments is bit-identical."""
+    cfg = O.NetConfig(3, 2, 2, 8)
+    st = O.init_state(cfg, 11)
+    p = 0.3
+    dropout, cf = ((p, p, p), (0.0, 0.0)) if kind == "dropout2d" else ((0.0, 0.0, 0.0), (p, p))
+    model = build_model(cfg, st, dropout=dropout, center_final=cf)
+    model.train()
+    net = model.model
+    assert net.engine_rng
+    g = torch.Generator().manual_seed(3)
+    N = 6
+    x = torch.rand(N, 2, 3, 64, 64, generator=g).cuda()
+    y = torch.rand(N, 2, 1, 64, 64, generator=g).cuda()
+
+    def run(xin):
+        model.zero_grad()
+        xg = xin.clone().requires_grad_(True)
+        p1, p2 = model(xg)
+        model.loss_fn.forward(p1, p2, y, reduce_mean=False).mean().backward()
+        return p1.detach().clone(), xg.grad.clone(), net.flat_gradients().clone()
+
+    torch.manual_seed(123)
+    off0 = torch.cuda.default_generators[0].get_offset()
+    a = run(x)
+    assert torch.cuda.default_generators[0].get_offset() == off0 + 4
+    plan = next(iter(net._plans.values()))
+    ndc = plan.num_double_convs
+    sites = range(ndc) if kind == "dropout2d" else range(ndc, ndc + 1 + cfg.num_subnetworks)
+    masks = {s: plan.dropout_mask(s) for s in sites}
+    b = run(x)                      # next offset: different masks
+    assert not torch.equal(a[0], b[0])
+    torch.manual_seed(123)
+    c = run(x)                      # same seed, same offset: identical run
+    assert all(torch.equal(u, v) for u, v in zip(a, c))
+    # (b) statistics
+    allm = torch.cat([m.flatten() for m in masks.values()])
+    vals = torch.unique(allm)
+    assert len(vals) == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / (1 - p)) < 1e-6
+    keep = float((allm > 0).float().mean())
+    sigma = (p * (1 - p) / allm.numel()) ** 0.5
+    assert abs(keep - (1 - p)) < 5 * sigma, (keep, allm.numel())
+    ms = list(masks.values())
+    assert not torch.equal(ms[0][0], ms[0][1]) and (len(ms) < 2 or ms[0].shape != ms[1].shape or not torch.equal(ms[0], ms[1]))
+    # (c) replay through the recorded-mask path
+    if kind == "dropout2d":
+        net.mask_override = {s: m for s, m in masks.items()}
+    else:
+        net.elem_mask_override = {"center": masks[ndc], **{f"final{s}": masks[ndc + 1 + s] for s in range(cfg.num_subnetworks)}}
+    d = run(x)
+    assert all(torch.equal(u, v) for u, v in zip(a, d))
+    report(f"in-engine Philox {kind}: keep rate {keep:.4f} (1 - p = {1 - p}), {allm.numel()} multipliers, replay bit-identical")
