@@ -281,13 +281,13 @@ def main():
     elapsed = time.perf_counter() - t0
     final_loss = float(loss.detach())
     # ---- second pass: HIP events on the launch stream around every kernel class / resolution tier ----
-    prof, tiers, psteps = {}, [], max(0, args.profile_steps)
+    prof, tiers, kind_tiers, psteps = {}, [], {}, max(0, args.profile_steps)
     if psteps:
         plan.profile(True)
         for i in range(psteps):
             step(i, time_adam=True)
         torch.cuda.synchronize()
-        prof, tiers = plan.profile_read(), plan.profile_read_tiers()
+        prof, tiers, kind_tiers = plan.profile_read(), plan.profile_read_tiers(), plan.profile_read_kind_tiers()
         plan.profile(False)
     identical = None
     if dist is not None:
@@ -383,7 +383,11 @@ def main():
             # forward) / summed device time of EVERY kernel launched for that tier's blocks / 8 TB/s
             "tiers": {f"{c['H'] >> t}x{c['W'] >> t}": {
                 "ms_per_step": round(tier_ms[t], 3), "algorithmic_mb_per_image": round(tier_bytes[t] / 1e6, 1),
-                "hbm_frac": round(tier_bytes[t] * B / (tier_ms[t] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if tier_ms[t] > 0 else None}
+                "hbm_frac": round(tier_bytes[t] * B / (tier_ms[t] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if tier_ms[t] > 0 else None,
+                # which kernel classes the tier's time is made of (ms per step); "other" = statistics / reduction /
+                # packing launches that carry no class of their own
+                "kernels_ms": dict({k: round(v[t] / psteps, 3) for k, v in kind_tiers.items() if v[t] > 0},
+                                   other=round(tier_ms[t] - sum(v[t] for v in kind_tiers.values()) / psteps, 3))}
                 for t in range(5)},
             # the bandwidth class, priced against HBM (8000 GB/s): algorithmic bytes / HIP-event time
             "bandwidth_kernels": {"peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -212,6 +212,8 @@ int mimo_plan_profile_read(mimo_plan* plan, int kind, double* total_ms, int64_t*
  * (0 = full resolution H x W ... 4 = H/16 x W/16), forward and backward separately, since the profile was
  * armed: the denominator of the per-tier HBM fraction of SURVEY 8(d). */
 int mimo_plan_profile_read_tier(mimo_plan* plan, int tier, double* forward_ms, double* backward_ms);
+/* device time of one kernel class inside one resolution tier (the per-tier kernel table of bench.py) */
+int mimo_plan_profile_read_kind_tier(mimo_plan* plan, int kind, int tier, double* ms);
 
 /* ---- optimiser: replaces torch.optim.Adam.step (mimo_unet.py:186-190; L2-in-grad) ------ */
 int mimo_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "mimo_plan_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double)]),
     "mimo_plan_profile_read_tier": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mimo_plan_profile_read_kind_tier": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mimo_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "mimo_adam_step_amp": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _F, _P, _P, _P]),
     "mimo_uncertainties": (C.c_int, [_P, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P]),

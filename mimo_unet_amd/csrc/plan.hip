@@ -172,8 +172,10 @@ struct mimo_plan {
   // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
   struct ProfRec {
     hipEvent_t a, b;
-    int kind;
+    int kind, tier;
   };
+  int cur_tier = 0;  // resolution tier of the block being issued (kernel-class records inherit it)
+  double prof_kind_tier_ms[MIMO_PROF_KINDS][5] = {};
   bool prof_on = false;
   std::vector<ProfRec> prof_recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -205,6 +207,8 @@ struct mimo_plan {
       (void)hipEventCreate(&r.b);
     }
     r.kind = kind;
+    if (kind >= kProfTierBase) cur_tier = (kind - kProfTierBase) / 2;
+    r.tier = cur_tier;
     (void)hipEventRecord(r.a, st);
     prof_recs.push_back(r);
     return (int)prof_recs.size() - 1;
@@ -225,8 +229,10 @@ struct mimo_plan {
       MIMO_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
       if (r.kind >= kProfTierBase)
         prof_tier_ms[r.kind - kProfTierBase] += ms;
-      else
+      else {
         prof_ms[r.kind] += ms;
+        prof_kind_tier_ms[r.kind][r.tier] += ms;
+      }
       prof_pool.emplace_back(r.a, r.b);
     }
     prof_recs.clear();
@@ -1534,6 +1540,8 @@ int mimo_plan_profile(mimo_plan* plan, int enable) {
       plan->prof_launches[k] = 0;
     }
     for (double& v : plan->prof_tier_ms) v = 0.0;
+    for (auto& row : plan->prof_kind_tier_ms)
+      for (double& v : row) v = 0.0;
   }
   return MIMO_OK;
 }
@@ -1559,6 +1567,16 @@ int mimo_plan_profile_read_tier(mimo_plan* plan, int tier, double* forward_ms, d
   MIMO_TRY(plan->prof_collect());
   if (forward_ms) *forward_ms = plan->prof_tier_ms[2 * tier];
   if (backward_ms) *backward_ms = plan->prof_tier_ms[2 * tier + 1];
+  return MIMO_OK;
+}
+
+int mimo_plan_profile_read_kind_tier(mimo_plan* plan, int kind, int tier, double* ms) {
+  if (!plan || kind < 0 || kind >= MIMO_PROF_KINDS || tier < 0 || tier >= mimo_plan::kProfTiers || !ms) {
+    set_error("mimo_plan_profile_read_kind_tier: bad argument");
+    return MIMO_ERR_INVALID;
+  }
+  MIMO_TRY(plan->prof_collect());
+  *ms = plan->prof_kind_tier_ms[kind][tier];
   return MIMO_OK;
 }
 

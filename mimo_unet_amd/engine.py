@@ -199,6 +199,18 @@ class Plan:
             res[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
         return res
 
+    def profile_read_kind_tiers(self) -> Dict[str, List[float]]:
+        """{kernel class: [ms per resolution tier]} — which kernels a tier's device time is made of."""
+        res = {}
+        for k, name in enumerate(self.PROF_KINDS):
+            row = []
+            for t in range(self.PROF_TIERS):
+                ms = C.c_double()
+                L.check(self.lib.mimo_plan_profile_read_kind_tier(self.handle, k, t, C.byref(ms)), "mimo_plan_profile_read_kind_tier")
+                row.append(ms.value)
+            res[name] = row
+        return res
+
     def profile_read_tiers(self) -> List[Tuple[float, float]]:
         """[(forward_ms, backward_ms)] per resolution tier: device time of every launch of the tier's blocks."""
         res = []

@@ -6,15 +6,18 @@ cd "$R"
 O=gpurun_out/other_configs.raw
 : > $O
 run() { echo "CMD $*" >> $O; "$@" 2>/dev/null | tail -n 1 >> $O; }
+runp() { P=$1; shift; echo "CMD MIMO_PRECISION=$P $*" >> $O; MIMO_PRECISION=$P "$@" 2>/dev/null | tail -n 1 >> $O; }
 run python scripts/measure_inference_speed.py
 run python scripts/measure_inference_speed.py --batch 8
 run python scripts/measure_inference_speed.py --monte_carlo_steps 0 --dropout 0 --height 128 --width 160
 run python bench.py --config cfg2 --steps 10 --warmup 3 --no-cpu-baseline
 run python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline
-echo "CMD MIMO_PRECISION=bf16 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline" >> $O
-MIMO_PRECISION=bf16 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -n 1 >> $O
-echo "CMD MIMO_PRECISION=bf16 python bench.py --steps 20 --warmup 5 --no-cpu-baseline" >> $O
-MIMO_PRECISION=bf16 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -n 1 >> $O
-echo "CMD MIMO_PRECISION=fp32 python bench.py --steps 10 --warmup 3 --no-cpu-baseline" >> $O
-MIMO_PRECISION=fp32 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -n 1 >> $O
+for P in bf16 bf16-mixed 16-mixed; do
+  runp $P python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline
+  runp $P python bench.py --steps 20 --warmup 5 --no-cpu-baseline
+done
+runp fp32 python bench.py --steps 10 --warmup 3 --no-cpu-baseline
+run python bench.py --batch 4 --steps 30 --warmup 8 --no-cpu-baseline --profile-steps 0
+echo "CMD MIMO_TRAIN_GRAPH=1 python bench.py --batch 4 --steps 30 --warmup 8 --no-cpu-baseline --profile-steps 0" >> $O
+MIMO_TRAIN_GRAPH=1 python bench.py --batch 4 --steps 30 --warmup 8 --no-cpu-baseline --profile-steps 0 2>/dev/null | tail -n 1 >> $O
 cat $O | cut -c1-200
