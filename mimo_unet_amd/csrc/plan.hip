@@ -72,6 +72,8 @@ struct ConvBN {
   bool fwd_split = false, dg_split = false, wg_split = false;
   int *cin_map = nullptr, *fwd_row_map = nullptr, *dg_row_map = nullptr, *dg_col_map = nullptr;
   float* z = nullptr;
+  float* dz_own = nullptr;  // MIMO_WGRAD_STREAM=2: this layer's own dz buffer (its weight gradient may run much later)
+  float* dzs_own = nullptr;  // ... and its own pair-split copy where the weight gradient needs one
   int dtz = ST_F32;  // element type of z: the plan's storage type, fp32 where the fp32 kernel family writes it
   float *mean = nullptr, *invstd = nullptr, *scale = nullptr, *shift = nullptr, *c1 = nullptr, *c2 = nullptr;
   const float* in = nullptr;
@@ -159,6 +161,10 @@ struct mimo_plan {
   // convolution kernels the two streams mostly time-share the CUs (measured +0.7 % images/s), and the
   // per-kernel HIP-event durations the roofline is computed from become overlapped durations.
   bool wg_async = false;
+  // MIMO_WGRAD_STREAM=2 ("deferred"): every layer keeps its own dz buffer, so the weight gradients queue up on the side
+  // stream without back-pressure on the main chain — the chain (BatchNorm backward -> data gradient -> ...) never waits
+  // for a weight gradient, and an MFMA-bound kernel is always available to run beside the bandwidth-bound ones
+  bool wg_deferred = false;
   hipStream_t wg_stream = nullptr;
   hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
   bool wg_pending[2] = {false, false};
@@ -670,7 +676,14 @@ struct mimo_plan {
     MIMO_TRY(alloc_act(&s_dz, cap_act, st));
     {
       const char* we = getenv("MIMO_WGRAD_STREAM");
-      wg_async = we && atoi(we) != 0;
+      wg_async = we && atoi(we) != 0 && !cfg.inference_only;
+      wg_deferred = wg_async && atoi(we) == 2;
+      if (wg_deferred)
+        for (auto& dc : dcs)
+          for (ConvBN* L : {&dc->c1, &dc->c2}) {
+            MIMO_TRY(alloc_act(&L->dz_own, (size_t)L->N * L->H * L->W * L->cout_p, st));
+            if (L->wg_split && !L->dg_split) MIMO_TRY(dalloc(&L->dzs_own, (size_t)L->N * L->H * L->W * L->cout_p));
+          }
       s_dz2[0] = s_dz;
       s_dz2[1] = s_dz;
       if (any_mixed_dz) {
@@ -1152,9 +1165,11 @@ struct mimo_plan {
     prof_end(pr, 0.0, 8.0 * (double)P * L.cout_p, st);
     MIMO_TRY(bn_bwd_stats_launch(s_partial, rows, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
                                  grads + L.off_gamma, grads + L.off_beta, fwd_training ? grads + L.off_b : nullptr, colsum(), st));
+    // (with the profiler armed everything runs on the caller's stream: per-kernel times, not overlapped times)
+    const bool async = wg_async && !prof_on;
     const int b = dz_idx;
-    float* dz = s_dz2[b];
-    if (wg_async) {
+    float* dz = (wg_deferred && L.dz_own) ? L.dz_own : s_dz2[b];
+    if (async && !wg_deferred) {
       dz_idx ^= 1;
       if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
     }
@@ -1167,12 +1182,13 @@ struct mimo_plan {
     // gradient is too); fp32 otherwise, with a split copy for a bf16-pair weight gradient
     const float* dz_wg = dz;
     if (L.wg_split && !L.dg_split) {
-      MIMO_TRY(split_pairs_launch(dz, s_dzs2[b], P, L.cout_p, st));
-      dz_wg = s_dzs2[b];
+      float* dzs = (wg_deferred && L.dzs_own) ? L.dzs_own : s_dzs2[b];
+      MIMO_TRY(split_pairs_launch(dz, dzs, P, L.cout_p, st));
+      dz_wg = dzs;
     }
     // wgrad(L) may start as soon as dz exists, next to dgrad(L) (releasing it only after dgrad(L), i.e. next
     // to the bandwidth-bound kernels of the layer below, measured the same step time)
-    if (wg_async) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
+    if (async) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
     // conv bias gradient: exactly zero in front of a training-mode BatchNorm (written by bn_bwd_stats above);
     // a real column sum of dz only after an eval-mode forward (running statistics: dz = scale * dy)
     if (!fwd_training) MIMO_TRY(colsum_vec_launch(s_partial, rows, L.cout_p, L.Cout, grads + L.off_b, colsum(), st));
@@ -1203,8 +1219,8 @@ struct mimo_plan {
       prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     }
     hipStream_t ws = st;
-    if (wg_async) {
-      MIMO_HIP_CHECK(hipStreamWaitEvent(wg_stream, ev_dz[b], 0));
+    if (async) {
+      MIMO_HIP_CHECK(hipStreamWaitEvent(wg_stream, ev_dz[b], 0));  // (a wait refers to the record made just above)
       ws = wg_stream;
     }
     WgradLaunch wg;
@@ -1230,7 +1246,7 @@ struct mimo_plan {
     else
       MIMO_TRY(wgrad_launch(wg, ws));
     prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), ws);
-    if (wg_async) {
+    if (async) {
       MIMO_HIP_CHECK(hipEventRecord(ev_wg[b], wg_stream));
       wg_pending[b] = true;
     }
