@@ -166,12 +166,15 @@ struct mimo_plan {
   // for a weight gradient, and an MFMA-bound kernel is always available to run beside the bandwidth-bound ones
   bool wg_deferred = false;
   hipStream_t wg_stream = nullptr;
-  hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
-  bool wg_pending[2] = {false, false};
-  float* s_dz2[2] = {nullptr, nullptr};
+  static constexpr int kDzBufs = 4;  // capacity; wg_bufs (MIMO_WGRAD_BUFFERS, default 2) are used
+  int wg_bufs = 2;
+  bool wg_release_after_dgrad = false;  // MIMO_WGRAD_RELEASE=1: a weight gradient starts when its layer's data gradient ends
+  hipEvent_t ev_dz[kDzBufs] = {}, ev_wg[kDzBufs] = {}, ev_join = nullptr;
+  bool wg_pending[kDzBufs] = {};
+  float* s_dz2[kDzBufs] = {};
   // split (bf16 hi|lo) copy of dz for layers whose data gradient runs on the fp32 kernel while the weight
   // gradient runs on the bf16-pair kernel (fewer than 16 output channels); null when no layer needs it
-  float* s_dzs2[2] = {nullptr, nullptr};
+  float* s_dzs2[kDzBufs] = {};
   bool any_mixed_dz = false;
   int dz_idx = 0;
 
@@ -338,8 +341,10 @@ struct mimo_plan {
     for (hipEvent_t e : sub_join)
       if (e) (void)hipEventDestroy(e);
     if (sub_fork) (void)hipEventDestroy(sub_fork);
-    for (hipEvent_t e : {ev_dz[0], ev_dz[1], ev_wg[0], ev_wg[1], ev_join})
-      if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < kDzBufs; ++i)
+      for (hipEvent_t e : {ev_dz[i], ev_wg[i]})
+        if (e) (void)hipEventDestroy(e);
+    if (ev_join) (void)hipEventDestroy(ev_join);
   }
 
   template <typename T>
@@ -684,18 +689,25 @@ struct mimo_plan {
             MIMO_TRY(alloc_act(&L->dz_own, (size_t)L->N * L->H * L->W * L->cout_p, st));
             if (L->wg_split && !L->dg_split) MIMO_TRY(dalloc(&L->dzs_own, (size_t)L->N * L->H * L->W * L->cout_p));
           }
-      s_dz2[0] = s_dz;
-      s_dz2[1] = s_dz;
+      if (wg_async) {
+        const char* be = getenv("MIMO_WGRAD_BUFFERS");
+        wg_bufs = be ? std::max(2, std::min(kDzBufs, atoi(be))) : 2;
+        const char* re = getenv("MIMO_WGRAD_RELEASE");
+        wg_release_after_dgrad = re && atoi(re) != 0;
+      }
+      for (int i = 0; i < kDzBufs; ++i) s_dz2[i] = s_dz;
       if (any_mixed_dz) {
         MIMO_TRY(dalloc(&s_dzs2[0], cap_act));
-        s_dzs2[1] = s_dzs2[0];
-        if (wg_async) MIMO_TRY(dalloc(&s_dzs2[1], cap_act));
+        for (int i = 1; i < kDzBufs; ++i) s_dzs2[i] = s_dzs2[0];
+        if (wg_async)
+          for (int i = 1; i < wg_bufs; ++i) MIMO_TRY(dalloc(&s_dzs2[i], cap_act));
       }
       if (wg_async) {
-        MIMO_TRY(alloc_act(&s_dz2[1], cap_act, st));
+        for (int i = 1; i < wg_bufs; ++i) MIMO_TRY(alloc_act(&s_dz2[i], cap_act, st));
         MIMO_HIP_CHECK(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&ev_dz[0], &ev_dz[1], &ev_wg[0], &ev_wg[1], &ev_join})
-          MIMO_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (int i = 0; i < wg_bufs; ++i)
+          for (hipEvent_t* e : {&ev_dz[i], &ev_wg[i]}) MIMO_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        MIMO_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
       }
     }
     MIMO_TRY(alloc_act(&s_dxpadA, cap_pad, st));
@@ -1170,7 +1182,7 @@ struct mimo_plan {
     const int b = dz_idx;
     float* dz = (wg_deferred && L.dz_own) ? L.dz_own : s_dz2[b];
     if (async && !wg_deferred) {
-      dz_idx ^= 1;
+      dz_idx = (dz_idx + 1) % wg_bufs;
       if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
     }
     pr = prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
@@ -1188,7 +1200,7 @@ struct mimo_plan {
     }
     // wgrad(L) may start as soon as dz exists, next to dgrad(L) (releasing it only after dgrad(L), i.e. next
     // to the bandwidth-bound kernels of the layer below, measured the same step time)
-    if (async) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
+    if (async && !wg_release_after_dgrad) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
     // conv bias gradient: exactly zero in front of a training-mode BatchNorm (written by bn_bwd_stats above);
     // a real column sum of dz only after an eval-mode forward (running statistics: dz = scale * dy)
     if (!fwd_training) MIMO_TRY(colsum_vec_launch(s_partial, rows, L.cout_p, L.Cout, grads + L.off_b, colsum(), st));
@@ -1218,6 +1230,7 @@ struct mimo_plan {
         MIMO_TRY(conv3x3_launch(a, nullptr, st));
       prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     }
+    if (async && wg_release_after_dgrad) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));  // behind this layer's data gradient
     hipStream_t ws = st;
     if (async) {
       MIMO_HIP_CHECK(hipStreamWaitEvent(wg_stream, ev_dz[b], 0));  // (a wait refers to the record made just above)
@@ -1257,10 +1270,12 @@ struct mimo_plan {
 
   // the caller's stream waits for every weight gradient issued so far
   int wg_join(hipStream_t st) {
-    if (!wg_async || !(wg_pending[0] || wg_pending[1])) return MIMO_OK;
+    bool any = false;
+    for (bool p : wg_pending) any |= p;
+    if (!wg_async || !any) return MIMO_OK;
     MIMO_HIP_CHECK(hipEventRecord(ev_join, wg_stream));
     MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
-    wg_pending[0] = wg_pending[1] = false;
+    for (bool& p : wg_pending) p = false;
     return MIMO_OK;
   }
 
