@@ -63,6 +63,35 @@ __global__ void sums_to_stats_kernel(const double* __restrict__ sums, int chunks
   stats[cout + c] = s2;
 }
 
+// fp32 <-> 16-bit storage conversions, so that the fp32 test interface can drive the 16-bit storage kernels
+template <typename T>
+__global__ void to16_kernel(const float* __restrict__ s, T* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (T)s[i];
+}
+template <typename T>
+__global__ void from16_kernel(const T* __restrict__ s, float* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = (float)s[i];
+}
+int to16(const float* s, void* d, int64_t n, bool f16, hipStream_t st) {
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  if (f16)
+    hipLaunchKernelGGL(to16_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, s, (_Float16*)d, n);
+  else
+    hipLaunchKernelGGL(to16_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, s, (__bf16*)d, n);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+int from16(const void* s, float* d, int64_t n, bool f16, hipStream_t st) {
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  if (f16)
+    hipLaunchKernelGGL(from16_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, (const _Float16*)s, d, n);
+  else
+    hipLaunchKernelGGL(from16_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16*)s, d, n);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+bool is_mixed(int precision) { return precision == MIMO_PREC_BF16_MIXED || precision == MIMO_PREC_FP16_MIXED; }
+
 }  // namespace
 
 extern "C" {
@@ -73,8 +102,11 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   hipStream_t st = (hipStream_t)stream;
   Temp t;
   const int cout_pad = conv3x3_cout_pad(cout);
-  const bool split = precision == MIMO_PREC_SPLIT16 || precision == MIMO_PREC_BF16;
-  const bool bf16 = precision == MIMO_PREC_BF16;
+  // 16-bit storage modes: the fp32 tensors of this interface are rounded into 16-bit buffers, the storage-mode kernels
+  // run on those, the result is widened again (exact)
+  const bool mixed = is_mixed(precision), f16s = precision == MIMO_PREC_FP16_MIXED;
+  const bool split = precision == MIMO_PREC_SPLIT16 || precision == MIMO_PREC_BF16 || mixed;
+  const bool bf16 = precision == MIMO_PREC_BF16 || precision == MIMO_PREC_BF16_MIXED;
   float* wf = t.get<float>((size_t)9 * cout_pad * cin_p);
   void* wpk = t.get<uint16_t>((size_t)ceil_div(cin_p, 32) * 9 * cout_pad * 64);
   float* bp = t.get<float>(cout_pad);
@@ -90,9 +122,20 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   MIMO_TRY(pack_weights_launch(w, wf, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
   if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, bf16 ? 0 : 1, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
   if (bias) MIMO_HIP_CHECK(hipMemcpyAsync(bp, bias, cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+  const int64_t nx = (int64_t)n * h * wd * cin_p, nz = (int64_t)n * h * wd * cout_p;
+  uint16_t *x16 = nullptr, *z16 = nullptr;
+  if (mixed) {
+    x16 = t.get<uint16_t>(nx);
+    z16 = t.get<uint16_t>(nz);
+    if (!x16 || !z16) {
+      set_error("mimo_op_conv3x3_forward: allocation failed");
+      return MIMO_ERR_HIP;
+    }
+    MIMO_TRY(to16(x, x16, nx, f16s, st));
+  }
   ConvLaunch a;
-  a.x = x;
-  a.y = z;
+  a.x = mixed ? reinterpret_cast<const float*>(x16) : x;
+  a.y = mixed ? reinterpret_cast<float*>(z16) : z;
   a.w = wf;
   a.bias = bp;
   a.stats = stats ? partial : nullptr;
@@ -108,9 +151,10 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   a.wpk = wpk;
   int rows = 0;
   if (split)
-    MIMO_TRY(conv3x3_bf16x3_launch(a, bf16 ? 2 : 1, &rows, st));
+    MIMO_TRY(conv3x3_bf16x3_launch(a, mixed ? (f16s ? 6 : 4) : (bf16 ? 2 : 1), &rows, st));
   else
     MIMO_TRY(conv3x3_launch(a, &rows, st));
+  if (mixed) MIMO_TRY(from16(z16, z, nz, f16s, st));
   if (stats) {
     int chunks = 0;
     MIMO_TRY(rowsum_launch(partial, rows, 2 * cout_pad, sums, &chunks, st));
@@ -126,7 +170,8 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
   hipStream_t st = (hipStream_t)stream;
   Temp t;
   const int rows_pad = conv3x3_cout_pad(cin_p);
-  const bool split = precision == MIMO_PREC_SPLIT16 || precision == MIMO_PREC_BF16;
+  const bool mixed = is_mixed(precision), f16s = precision == MIMO_PREC_FP16_MIXED;
+  const bool split = precision == MIMO_PREC_SPLIT16 || precision == MIMO_PREC_BF16 || mixed;
   const bool bf16 = precision == MIMO_PREC_BF16;
   float* wdp = t.get<float>((size_t)9 * rows_pad * cout_p);
   void* wpk = t.get<uint16_t>((size_t)ceil_div(cout_p, 32) * 9 * rows_pad * 64);
@@ -138,9 +183,20 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
     return MIMO_ERR_HIP;
   }
   MIMO_TRY(pack_weights_launch(w, wdp, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
-  if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, 0, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
+  if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, f16s ? 1 : 0, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
   const float* dz_in = dz;
-  if (split) {  // the bf16-pair kernel reads dz in split storage (see elementwise.h split_pairs_launch)
+  const int64_t ndz = (int64_t)n * h * wd * cout_p, ndx = (int64_t)n * h * wd * cin_p;
+  uint16_t* dx16 = nullptr;
+  if (mixed) {  // plain 16-bit dz in, 16-bit padded-domain gradient out, folded in 16-bit storage, widened at the end
+    uint16_t* dz16 = t.get<uint16_t>(ndz);
+    dx16 = t.get<uint16_t>(ndx);
+    if (!dz16 || !dx16) {
+      set_error("mimo_op_conv3x3_dgrad: allocation failed");
+      return MIMO_ERR_HIP;
+    }
+    MIMO_TRY(to16(dz, dz16, ndz, f16s, st));
+    dz_in = reinterpret_cast<const float*>(dz16);
+  } else if (split) {  // the bf16-pair kernel reads dz in split storage (see elementwise.h split_pairs_launch)
     float* dzs = t.get<float>((size_t)n * h * wd * cout_p);
     if (!dzs) {
       set_error("mimo_op_conv3x3_dgrad: allocation failed");
@@ -168,10 +224,15 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
   a.off = 2;
   a.wpk = wpk;
   if (split)
-    MIMO_TRY(conv3x3_bf16x3_launch(a, bf16 ? 3 : 0, nullptr, st));
+    MIMO_TRY(conv3x3_bf16x3_launch(a, mixed ? (f16s ? 7 : 5) : (bf16 ? 3 : 0), nullptr, st));
   else
     MIMO_TRY(conv3x3_launch(a, nullptr, st));
-  MIMO_TRY(fold_slice_launch(dxpad, ST_F32, cin_p, 0, dx, cin_p, n, h, wd, cin_p, 0, st));
+  if (mixed) {
+    MIMO_TRY(fold_slice_launch(dxpad, f16s ? ST_F16 : ST_BF16, cin_p, 0, dx16, cin_p, n, h, wd, cin_p, 0, st));
+    MIMO_TRY(from16(dx16, dx, ndx, f16s, st));
+  } else {
+    MIMO_TRY(fold_slice_launch(dxpad, ST_F32, cin_p, 0, dx, cin_p, n, h, wd, cin_p, 0, st));
+  }
   MIMO_HIP_CHECK(hipStreamSynchronize(st));
   return MIMO_OK;
 }
@@ -181,7 +242,8 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
                           mimo_stream stream) {
   hipStream_t st = (hipStream_t)stream;
   Temp t;
-  const bool split = precision == MIMO_PREC_SPLIT16 || precision == MIMO_PREC_BF16;
+  const bool mixed = is_mixed(precision), f16s = precision == MIMO_PREC_FP16_MIXED;
+  const bool split = precision == MIMO_PREC_SPLIT16 || precision == MIMO_PREC_BF16 || mixed;
   const bool bf16 = precision == MIMO_PREC_BF16;
   WgradLaunch a;
   a.x = x;
@@ -210,7 +272,21 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
     set_error("mimo_op_conv3x3_wgrad: allocation failed");
     return MIMO_ERR_HIP;
   }
-  if (split) {  // split storage of dz, as the BatchNorm-backward kernel writes it in the plan
+  if (mixed) {  // activations and dz as plain 16-bit NHWC tensors
+    const int64_t nx = (int64_t)n * h * wd * cin_p, ndz = (int64_t)n * h * wd * cout_p;
+    uint16_t *x16 = t.get<uint16_t>(nx), *dz16 = t.get<uint16_t>(ndz);
+    if (!x16 || !dz16) {
+      set_error("mimo_op_conv3x3_wgrad: allocation failed");
+      return MIMO_ERR_HIP;
+    }
+    MIMO_TRY(to16(x, x16, nx, f16s, st));
+    MIMO_TRY(to16(dz, dz16, ndz, f16s, st));
+    a.x = reinterpret_cast<const float*>(x16);
+    a.dz = reinterpret_cast<const float*>(dz16);
+    a.np = 1;
+    a.store = f16s ? 2 : 1;
+    MIMO_TRY(wgrad_split_launch(a, st));
+  } else if (split) {  // split storage of dz, as the BatchNorm-backward kernel writes it in the plan
     float* dzs = t.get<float>((size_t)n * h * wd * cout_p);
     if (!dzs) {
       set_error("mimo_op_conv3x3_wgrad: allocation failed");

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import logging
 import os
+import weakref
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence
 
@@ -109,7 +110,7 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net: "MimoUNet", x, label, lmask, perm, masks, bn_training, elem_masks, rng, *params):
         ctx.set_materialize_grads(False)
-        plan = net._plan_for(x, perm)
+        plan = net._plan_for(x, perm, for_autograd=True)
         n = plan.batch
         S, Co = net.num_subnetworks, net.out_channels
         out = torch.empty(n, S, Co, plan.height, plan.width, device=x.device, dtype=torch.float32)
@@ -123,6 +124,10 @@ class _NetFunction(torch.autograd.Function):
         plan.generation += 1
         ctx.net, ctx.plan, ctx.generation = net, plan, plan.generation
         ctx.keep = (x, label, lmask, perm, masks, out, elem_masks)  # device memory the plan still points at
+        # the plan holds the saved activations of THIS graph until its backward has run or the graph is dropped; a
+        # forward of the same geometry in between gets another plan (_plan_for), like autograd keeping two graphs alive
+        plan.pending = plan.generation
+        weakref.finalize(ctx, _release_plan, plan, plan.generation)
         ctx.x_shape = x.shape
         ctx.has_loss = label is not None
         ctx.mark_non_differentiable(*[])
@@ -146,7 +151,13 @@ class _NetFunction(torch.autograd.Function):
         dout_c = None if dout is None else dout.contiguous().float()
         dloss_c = None if (dloss is None or not ctx.has_loss) else dloss.contiguous().float()
         net._run_backward(plan, dout_c, dloss_c, dx)
+        _release_plan(plan, ctx.generation)
         return (None, dx, None, None, None, None, None, None, None) + (None,) * len(net._param_list)
+
+
+def _release_plan(plan, generation: int) -> None:
+    if getattr(plan, "pending", None) == generation:
+        plan.pending = None
 
 
 class MimoUNet(nn.Module):
@@ -254,7 +265,8 @@ class MimoUNet(nn.Module):
         self._flat_device = device
         self._versioned = plist + [named_b[sp.name] for sp in plan.specs if sp.kind == 1]
 
-    def _plan_for(self, x: torch.Tensor, perm: Optional[torch.Tensor], inference: bool = False) -> Plan:
+    def _plan_for(self, x: torch.Tensor, perm: Optional[torch.Tensor], inference: bool = False,
+                  for_autograd: bool = False) -> Plan:
         """inference: a plan without the buffers only a backward needs (pre-activation tensors, activation
         gradients, dz / padded-gradient / weight-gradient scratch, data-gradient weight copies) — what eval
         mode under torch.no_grad() uses, e.g. the passes x B samples of an MC-dropout ensemble."""
@@ -264,11 +276,23 @@ class MimoUNet(nn.Module):
         n = perm.shape[1] if perm is not None else x.shape[0]
         key = (n, x.shape[-2], x.shape[-1], x.device.index, bool(inference))
         plan = self._plans.get(key)
+        if for_autograd and plan is not None and getattr(plan, "pending", None) is not None:
+            # an earlier graph of this geometry is still alive and may yet be back-propagated (two forwards, then the
+            # first one's backward — torch's autograd allows it): use further plans of the same geometry (key + slot)
+            slot = 1
+            while True:
+                k2 = key + (slot,)
+                p2 = self._plans.get(k2)
+                if p2 is None or getattr(p2, "pending", None) is None:
+                    key, plan = k2, p2
+                    break
+                slot += 1
         if plan is None:
             while len(self._plans) >= self._plan_cache_size:
                 self._plans.popitem(last=False)  # a pending autograd node keeps its own reference to its plan
             plan = Plan(self._geom, n, x.shape[-2], x.shape[-1], x.device, inference_only=inference)
             plan.generation = 0
+            plan.pending = None
             self._plans[key] = plan
         else:
             self._plans.move_to_end(key)

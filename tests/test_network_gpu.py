@@ -843,3 +843,38 @@ def test_in_engine_philox_dropout(kind):
     d = run(x)
     assert all(torch.equal(u, v) for u, v in zip(a, d))
     report(f"in-engine Philox {kind}: keep rate {keep:.4f} (1 - p = {1 - p}), {allm.numel()} multipliers, replay bit-identical")
+
+
+def test_two_forwards_then_the_first_ones_backward():
+    """torch's autograd keeps every live graph's saved tensors; the engine keeps one set of saved activations per plan,
+    so a second forward of the same geometry while the first graph is still alive runs on a second plan — the first
+    graph's backward then gives exactly the gradient of an undisturbed run (the reference behaviour), and the extra
+    plan is reused, not leaked, afterwards."""
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    model = build_model(cfg, state_from(fx, "init/"))
+    model.eval()  # no running-statistics side effects between the calls
+    g = torch.Generator().manual_seed(8)
+    xa = torch.rand(3, 2, 2, 32, 32, generator=g).cuda()
+    xb = torch.rand(3, 2, 2, 32, 32, generator=g).cuda()
+    ref = []
+    for x in (xa, xb):
+        model.zero_grad()
+        p1, p2 = model(x)
+        (p1.square().mean() + p2.mean()).backward()
+        ref.append(model.model.flat_gradients().clone())
+    n_plans = len(model.model._plans)
+    model.zero_grad()
+    a1, a2 = model(xa)
+    b1, b2 = model(xb)          # same geometry, first graph still alive
+    (a1.square().mean() + a2.mean()).backward()
+    assert torch.equal(model.model.flat_gradients(), ref[0])
+    model.zero_grad()
+    (b1.square().mean() + b2.mean()).backward()
+    assert torch.equal(model.model.flat_gradients(), ref[1])
+    assert len(model.model._plans) == n_plans + 1
+    del a1, a2, b1, b2
+    model.zero_grad()
+    p1, p2 = model(xa)
+    (p1.square().mean() + p2.mean()).backward()
+    assert torch.equal(model.model.flat_gradients(), ref[0]) and len(model.model._plans) == n_plans + 1

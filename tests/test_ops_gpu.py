@@ -261,3 +261,56 @@ def test_bf16_conv_kernels_against_rounded_operand_reference(case):
     errs = (rel_err(from_nhwc(zd, Co), z_ref), rel_err(from_nhwc(dxd, Ci), xr.grad), rel_err(dwd.cpu(), dw_ref))
     report("bf16 exact", case, ["%.2e" % e for e in errs])
     assert max(errs) < 2e-6
+
+
+@pytest.mark.parametrize("mode", ["bf16-mixed", "16-mixed"])
+@pytest.mark.parametrize("case", [(1, 64, 64, 30, 30), (2, 16, 16, 45, 30), (1, 16, 16, 120, 240), (2, 32, 32, 21, 42),
+                                  (1, 6, 7, 16, 33), (1, 50, 70, 8, 60), (2, 2, 2, 24, 8)], ids=lambda c: "x".join(map(str, c)))
+def test_storage_mode_conv_kernels_against_rounded_reference(case, mode):
+    """The 16-bit STORAGE kernels (conv modes 4-7, weight-gradient operand modes 1-2): inputs arrive as bf16 / fp16
+    NHWC tensors, products are exact, accumulation fp32, the output is rounded ONCE to the storage type.  Reference:
+    the same with torch (round inputs, fp32 conv, round the result).  A different fp32 summation order can move a
+    result across a rounding boundary: at most one unit in the last place of the 16-bit type for the forward (and two
+    for the folded data gradient, which is rounded on the padded domain and again after the fold), the weight gradient
+    (fp32 output) to 2e-6; the BatchNorm sums come from the unrounded accumulators."""
+    L = _lib()
+    lib = L.load()
+    prec = L.PRECISIONS[mode]
+    dt = torch.bfloat16 if mode == "bf16-mixed" else torch.float16
+    ulp = 2.0 ** -8 if mode == "bf16-mixed" else 2.0 ** -11
+    N, H, W, Ci, Co = case
+    r = lambda t: t.to(dt).float()
+    g = torch.Generator().manual_seed(sum(case))
+    x = r(torch.randn(N, Ci, H, W, generator=g))
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3.0 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    dz = r(torch.randn(N, Co, H, W, generator=g))
+    xp = F.pad(x, (1, 1, 1, 1), mode="reflect")
+    z32 = F.conv2d(xp, r(w)) + b[None, :, None, None]
+    xr = x.clone().requires_grad_(True)
+    F.pad(xr, (1, 1, 1, 1), mode="reflect").backward(r(torch.nn.grad.conv2d_input(xp.shape, r(w), dz)))
+    dw_ref = torch.nn.grad.conv2d_weight(xp, w.shape, dz)
+    cip, cop, st = pad8(Ci), pad8(Co), L.current_stream()
+    xd, wd_, bd, dzd = to_nhwc(x, cip), w.cuda().contiguous(), b.cuda(), to_nhwc(dz, cop)
+    zd = torch.zeros(N, H, W, cop, device="cuda")
+    stats = torch.zeros(2, Co, dtype=torch.float64, device="cuda")
+    dxd = torch.zeros(N, H, W, cip, device="cuda")
+    dwd, dbd = torch.zeros(Co, Ci, 3, 3, device="cuda"), torch.zeros(Co, device="cuda")
+    L.check(lib.mimo_op_conv3x3_forward(xd.data_ptr(), wd_.data_ptr(), bd.data_ptr(), zd.data_ptr(), stats.data_ptr(), N, H, W,
+                                        Ci, cip, Co, cop, prec, st))
+    L.check(lib.mimo_op_conv3x3_dgrad(dzd.data_ptr(), wd_.data_ptr(), dxd.data_ptr(), N, H, W, Ci, cip, Co, cop, prec, st))
+    L.check(lib.mimo_op_conv3x3_wgrad(xd.data_ptr(), dzd.data_ptr(), dwd.data_ptr(), dbd.data_ptr(), N, H, W, Ci, cip, Co, cop,
+                                      prec, st))
+    torch.cuda.synchronize()
+    z, dx = from_nhwc(zd, Co), from_nhwc(dxd, Ci)
+    assert torch.equal(r(z), z) and torch.equal(r(dx), dx)  # representable in the storage type
+    # element-wise: within one (two) unit(s) in the last place of the reference value
+    ez = ((z - r(z32)).abs() / z32.abs().clamp_min(1e-3)).max().item()
+    edx = ((dx - r(xr.grad)).abs() / xr.grad.abs().clamp_min(1e-3 * float(xr.grad.abs().max()))).max().item()
+    same = (z == r(z32)).float().mean().item()
+    e_dw = rel_err(dwd.cpu(), dw_ref)
+    e_s1 = rel_err(stats[0].cpu(), z32.double().sum(dim=(0, 2, 3)))
+    e_s2 = rel_err(stats[1].cpu(), (z32.double() ** 2).sum(dim=(0, 2, 3)))
+    report(f"{mode} storage kernels", case, f"z {ez / ulp:.2f} ulp ({100 * same:.2f} % identical), dx {edx / ulp:.2f} ulp, dW {e_dw:.1e}, "
+           f"sums {e_s1:.1e} / {e_s2:.1e}")
+    assert ez <= 1.01 * ulp and same > 0.98 and edx <= 3.0 * ulp and e_dw < 2e-6 and e_s1 < 1e-5 and e_s2 < 1e-5
