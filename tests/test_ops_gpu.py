@@ -306,11 +306,16 @@ def test_storage_mode_conv_kernels_against_rounded_reference(case, mode):
     assert torch.equal(r(z), z) and torch.equal(r(dx), dx)  # representable in the storage type
     # element-wise: within one (two) unit(s) in the last place of the reference value
     ez = ((z - r(z32)).abs() / z32.abs().clamp_min(1e-3)).max().item()
-    edx = ((dx - r(xr.grad)).abs() / xr.grad.abs().clamp_min(1e-3 * float(xr.grad.abs().max()))).max().item()
+    # data gradient: interior pixels are one rounded value (<= 1 ulp element-wise); the two border rows / columns are
+    # sums of up to four rounded padded-domain values, which may cancel: bounded relative to the tensor's scale
+    gref, gmax = r(xr.grad), float(xr.grad.abs().max())
+    rel = (dx - gref).abs() / xr.grad.abs().clamp_min(1e-3 * gmax)
+    e_int = rel[:, :, 2:-2, 2:-2].max().item() if H > 4 and W > 4 else 0.0
+    edx = max(e_int, float((dx - gref).abs().max()) / gmax / 2)
     same = (z == r(z32)).float().mean().item()
     e_dw = rel_err(dwd.cpu(), dw_ref)
     e_s1 = rel_err(stats[0].cpu(), z32.double().sum(dim=(0, 2, 3)))
     e_s2 = rel_err(stats[1].cpu(), (z32.double() ** 2).sum(dim=(0, 2, 3)))
     report(f"{mode} storage kernels", case, f"z {ez / ulp:.2f} ulp ({100 * same:.2f} % identical), dx {edx / ulp:.2f} ulp, dW {e_dw:.1e}, "
            f"sums {e_s1:.1e} / {e_s2:.1e}")
-    assert ez <= 1.01 * ulp and same > 0.98 and edx <= 2.02 * ulp and e_dw < 5e-6 and e_s1 < 1e-5 and e_s2 < 1e-5
+    assert ez <= 1.01 * ulp and same > 0.98 and edx <= 1.01 * ulp and e_dw < 5e-6 and e_s1 < 1e-5 and e_s2 < 1e-5
