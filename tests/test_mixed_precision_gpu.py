@@ -92,6 +92,7 @@ def test_cfg4_geometry_bf16_mixed_vs_oracle_and_memory():
         o32 = O.mimo_unet_forward(cfg, st, x, training=False)
     hip = torch.cat([p1, p2], dim=2).detach().cpu()
     e16, e32 = rel_err(hip, o16), rel_err(hip, o32)
+    del p1, p2  # drop the eval-mode autograd graph: its plan is free again (else the training step gets a second plan)
     model.train()
     lb_w = torch.tensor([0.7, 0.9, 1.1, 1.3])
     model.loss_buffer.get_weights = lambda: lb_w
