@@ -902,6 +902,25 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
   const int nfr = a.cout_pad / 16;
   int nf = 4;
   while (nfr % nf != 0) --nf;
+  if (conv_ws_enabled() && a.Ho * a.Wo >= 256) {
+    // Channel-tile width of the persistent kernel by cost, not just "the widest that divides": a launch with fewer
+    // (pixel tile, channel tile) pairs than CUs (the 16x16 .. 64x64 layers at a few images per GPU — the per-GPU
+    // batch of a strong-scaling run) finishes sooner with narrow channel tiles on many CUs than with wide ones on a
+    // few: time ~ (tiles per workgroup) x (per-phase fixed cost + NF x MFMA time), fixed cost ~ one NF unit.
+    static const bool adapt = !(getenv("MIMO_CONV_ADAPTIVE_NF") && atoi(getenv("MIMO_CONV_ADAPTIVE_NF")) == 0);
+    if (adapt) {
+      int TR, TC;
+      pick_tile_n(a.Ho, a.Wo, WsTile<4>::NPIX, WsTile<4>::MAXPIX, &TR, &TC);
+      const int numTiles = a.N * ceil_div(a.Ho, TR) * ceil_div(a.Wo, TC);
+      long best = -1;
+      for (int c = 4; c >= 1; --c) {
+        if (nfr % c) continue;
+        const int gx = max(1, min(numTiles, 256 / (nfr / c)));
+        const long cost = (long)ceil_div(numTiles, gx) * (1 + c);
+        if (best < 0 || cost < best) best = cost, nf = c;
+      }
+    }
+  }
   // NF <= 2: little MFMA work per tile -> 256-pixel tiles so that two workgroups share a CU and
   // one's loads / stores overlap the other's MFMAs (MIMO_CONV_BIGTILE_NF2=1 restores 512-pixel tiles)
   static const bool big_nf2 = getenv("MIMO_CONV_BIGTILE_NF2") && atoi(getenv("MIMO_CONV_BIGTILE_NF2")) != 0;
@@ -994,51 +1013,59 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
   const float* w = params + j.w_off;
   if (blockIdx.x == 0 && j.bias_n > 0)
     for (int i = threadIdx.x; i < j.bias_n; i += blockDim.x) j.bias_dst[i] = params[j.bias_off + i];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j.total; i += gridDim.x * blockDim.x) {
-    int row, col, tap, k = 0, chunk = 0;
+  // One thread per (row, column) = one (output channel, input channel) pair: its nine taps are 36 contiguous bytes
+  // of the OIHW tensor, so a wave reads one contiguous span (the tap-major order of round 1 read 4 of every 36
+  // bytes per pass: 113 us per step for 60 MB of weights); the nine stores per thread are coalesced across the wave
+  // (consecutive columns of one tap).
+  const int per_tap = j.total / 9;  // elements of one tap: kind 0: rows_pad * cols; else chunks * rows_pad * 32
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_tap; i += gridDim.x * blockDim.x) {
+    int row, col, k = 0, chunk = 0;
     if (j.kind == 0) {
       col = i % j.cols;
-      const int rest = i / j.cols;
-      row = rest % j.rows_pad;
-      tap = rest / j.rows_pad;
+      row = i / j.cols;
     } else {
       k = i & 31;
-      int rest = i >> 5;
+      const int rest = i >> 5;
       row = rest % j.rows_pad;
-      rest /= j.rows_pad;
-      tap = rest % 9;
-      chunk = rest / 9;
+      chunk = rest / j.rows_pad;
       col = chunk * 32 + k;
     }
-    float v = 0.f;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = 0.f;
     if (col < j.cols) {
       const int rm = j.row_map[row], cm = j.col_map[col];
       if (rm >= 0 && cm >= 0) {
         const int co = j.transposed ? cm : rm, ci = j.transposed ? rm : cm;
-        const int kh = j.transposed ? 2 - tap / 3 : tap / 3, kw = j.transposed ? 2 - tap % 3 : tap % 3;
-        v = w[(((size_t)co * j.cin + ci) * 3 + kh) * 3 + kw];
+        const float* src = w + ((size_t)co * j.cin + ci) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = src[j.transposed ? 8 - t : t];  // transposed: taps flipped (kh, kw -> 2-kh, 2-kw)
       }
     }
-    if (j.kind == 0) {
-      reinterpret_cast<float*>(j.dst)[i] = v;
-    } else if (j.kind == 1) {
-      v *= kF16WeightScale;
-      const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
-      _Float16* d = reinterpret_cast<_Float16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 64;
-      d[k] = hi;
-      d[32 + k] = lo;
-    } else {
-      const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-      __bf16* d = reinterpret_cast<__bf16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 64;
-      d[k] = hi;
-      d[32 + k] = lo;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float x = v[tap];
+      if (j.kind == 0) {
+        reinterpret_cast<float*>(j.dst)[((size_t)tap * j.rows_pad + row) * j.cols + col] = x;
+      } else if (j.kind == 1) {
+        const float xs = x * kF16WeightScale;
+        const _Float16 hi = (_Float16)xs, lo = (_Float16)(xs - (float)hi);
+        _Float16* d = reinterpret_cast<_Float16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 64;
+        d[k] = hi;
+        d[32 + k] = lo;
+      } else {
+        const __bf16 hi = (__bf16)x, lo = (__bf16)(x - (float)hi);
+        __bf16* d = reinterpret_cast<__bf16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 64;
+        d[k] = hi;
+        d[32 + k] = lo;
+      }
     }
   }
 }
 
 int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream) {
   if (njobs <= 0) return MIMO_OK;
-  const int gx = max(1, min(ceil_div(max_total, 256 * 8), 256));
+  const int gx = max(1, min(ceil_div(max_total / 9, 256 * 2), 512));
   hipLaunchKernelGGL(pack_jobs_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev, params);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;

@@ -31,10 +31,12 @@ struct PQ {
 // xcd_bands: workgroups are dealt round-robin to the 8 XCDs (each with a private L2); give every XCD one
 // contiguous band of the pixels in flight, so that gathers which re-read neighbouring rows (bilinear
 // backward: every gradient row feeds two input rows) find them in their own L2.
+// T = threads per workgroup (256 everywhere but the BatchNorm-backward reduction, which runs 1024)
+template <int T = 256>
 __device__ __forceinline__ PQ pixquad(int Cv, bool xcd_bands = false) {
   PQ r;
-  r.QB = Cv < 256 ? Cv : 256;
-  r.PPI = 256 / r.QB;
+  r.QB = Cv < T ? Cv : T;
+  r.PPI = T / r.QB;
   r.ql = threadIdx.x % r.QB;
   r.pl = threadIdx.x / r.QB;
   r.q = blockIdx.y * r.QB + r.ql;
@@ -52,9 +54,12 @@ __device__ __forceinline__ PQ pixquad(int Cv, bool xcd_bands = false) {
 // partial round), BatchNorm + ReLU forward with 6 per CU, the 16-tap bilinear backward with many short
 // workgroups (4096 -> 16384: 0.67 -> 0.55 ms), the rest at 4096-8192.
 constexpr int kBlocksBnRelu = 1536, kBlocksBnBwd = 1792, kBlocksUpBwd = 16384, kBlocksPoolBwd = 8192;
-static dim3 pq_grid(int Cv, int64_t P, int max_blocks = kEwMaxBlocks) {
-  const int QB = Cv < 256 ? Cv : 256;
-  const int PPI = 256 / QB;
+// The BatchNorm-backward REDUCTION runs the same 7168 waves as 448 workgroups of 1024 threads: a quarter of the partial
+// rows for the column-sum launch that follows (12.6 -> ~5 us, 24 times per step, at every batch size)
+constexpr int kBnReduceThreads = 1024, kBlocksBnReduce = kBlocksBnBwd / 4;
+static dim3 pq_grid(int Cv, int64_t P, int max_blocks = kEwMaxBlocks, int T = 256) {
+  const int QB = Cv < T ? Cv : T;
+  const int PPI = T / QB;
   int64_t gx = ceil_div64(P, PPI);
   if (gx > max_blocks) gx = max_blocks;
   if (gx < 1) gx = 1;
@@ -128,14 +133,27 @@ __device__ __forceinline__ float4 f4max(float4 a, float4 b) {
   return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
 
-// sum the accumulators of the threads that share a channel quad; result valid for pl == 0
+// sum the accumulators of the threads that share a channel quad; result valid for pl == 0 (red: one float4 per thread).
+// Fixed summation order (deterministic); two levels when many threads share a quad (the 1024-thread reduction).
 __device__ __forceinline__ float4 quad_block_sum(float4 v, const PQ& t, float4* red) {
   __syncthreads();
   red[threadIdx.x] = t.active ? v : f4zero();
   __syncthreads();
   float4 s = f4zero();
+  if (t.PPI <= 32) {
+    if (t.pl == 0)
+      for (int j = 0; j < t.PPI; ++j) s = f4add(s, red[j * t.QB + t.ql]);
+    return s;
+  }
+  const bool lead = t.pl < 16 && t.pl < t.PPI;
+  if (lead)
+    for (int j = t.pl; j < t.PPI; j += 16) s = f4add(s, red[j * t.QB + t.ql]);
+  __syncthreads();
+  if (lead) red[threadIdx.x] = s;
+  __syncthreads();
+  s = f4zero();
   if (t.pl == 0)
-    for (int j = 0; j < t.PPI; ++j) s = f4add(s, red[j * t.QB + t.ql]);
+    for (int j = 0; j < 16 && j < t.PPI; ++j) s = f4add(s, red[j * t.QB + t.ql]);
   return s;
 }
 
@@ -1079,13 +1097,13 @@ __device__ __forceinline__ float4 relu_grad4(const TA* da, int ldda, const TA* d
 }
 
 template <typename TZ, typename TA>
-__global__ void bnrelu_bwd_reduce_kernel(const TA* __restrict__ da, int ldda, const TA* __restrict__ dxpad,
-                                         int ldp, const TZ* __restrict__ z, int ldz, const float* __restrict__ scale,
-                                         const float* __restrict__ shift, const float* __restrict__ mean,
-                                         const float* __restrict__ invstd, const float* __restrict__ mask, int C, int Cv,
-                                         int N, int H, int W, float* __restrict__ partial) {
-  __shared__ float4 red[256];
-  const PQ t = pixquad(Cv);
+__global__ __launch_bounds__(kBnReduceThreads) void bnrelu_bwd_reduce_kernel(
+    const TA* __restrict__ da, int ldda, const TA* __restrict__ dxpad, int ldp, const TZ* __restrict__ z, int ldz,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ mask, int C, int Cv, int N, int H, int W,
+    float* __restrict__ partial) {
+  __shared__ float4 red[kBnReduceThreads];
+  const PQ t = pixquad<kBnReduceThreads>(Cv);
   const int Cp = 4 * Cv;
   float4 a1 = f4zero(), a2 = f4zero();
   if (t.active) {
@@ -1116,10 +1134,10 @@ int bnrelu_bwd_reduce_launch(const void* da, int dta, int ldda, const void* dxpa
                              const float* mask, int C, int Cp, int N, int H, int W, float* partial, int* rows,
                              hipStream_t st) {
   const int Cv = Cp / 4;
-  const dim3 grid = pq_grid(Cv, (int64_t)N * H * W, kBlocksBnBwd);
+  const dim3 grid = pq_grid(Cv, (int64_t)N * H * W, kBlocksBnReduce, kBnReduceThreads);
   *rows = grid.x;
   MIMO_ST_DISPATCH2(dtz, dta, TZ, TA,
-                    hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<TZ, TA>), grid, dim3(256), 0, st, (const TA*)da, ldda,
+                    hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<TZ, TA>), grid, dim3(kBnReduceThreads), 0, st, (const TA*)da, ldda,
                                        (const TA*)dxpad, ldp, (const TZ*)z, ldz, scale, shift, mean, invstd, mask, C, Cv, N, H, W,
                                        partial))
   MIMO_KERNEL_CHECK();
