@@ -649,7 +649,8 @@ def test_flat_adam_checkpoint_resume_on_device(tmp_path):
     resumed = build_model(cfg, state_from(fx, "init/"))
     resumed.load_state_dict(ck["state_dict"])
     resumed.train()
-    resumed.loss_buffer.buffer.copy_(ck["loss_buffer"][0])
+    # (on the device, where the uninterrupted run keeps it: a CPU softmax of the same ring differs in the last bit)
+    resumed.loss_buffer.buffer = ck["loss_buffer"][0].cuda()
     resumed.loss_buffer.index = ck["loss_buffer"][1]
     opt2 = resumed.configure_optimizers()["optimizer"]
     opt2.load_state_dict(ck["optimizer"])
