@@ -123,7 +123,10 @@ class _NetFunction(torch.autograd.Function):
             loss = torch.zeros(0, device=x.device, dtype=torch.float32)
         plan.generation += 1
         ctx.net, ctx.plan, ctx.generation = net, plan, plan.generation
-        ctx.keep = (x, label, lmask, perm, masks, out, elem_masks)  # device memory the plan still points at
+        # device memory the plan still points at; the output goes through save_for_backward (keeping it in a plain
+        # attribute would tie ctx -> out -> grad_fn -> ctx into a cycle that only the garbage collector breaks)
+        ctx.keep = (x, label, lmask, perm, masks, elem_masks)
+        ctx.save_for_backward(out)
         # the plan holds the saved activations of THIS graph until its backward has run or the graph is dropped; a
         # forward of the same geometry in between gets another plan (_plan_for), like autograd keeping two graphs alive
         plan.pending = plan.generation

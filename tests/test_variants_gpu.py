@@ -14,7 +14,8 @@ VARIANTS = {
     "conv_ws_swizzle": {"MIMO_CONV_WS_SWIZZLE": "1"},   # XOR-swizzled 128-byte LDS rows
     "wgrad_ws_off": {"MIMO_WGRAD_WS": "0"},             # 4-wave weight gradient for 64x64 tiles too
     "wgrad_split_mode0": {"MIMO_WGRAD_SPLIT_MODE": "0"},
-    "side_stream": {"MIMO_WGRAD_STREAM": "1"},
+    "side_stream_off": {"MIMO_WGRAD_STREAM": "0"},      # weight gradients on the caller's stream (the default is the side stream)
+    "side_stream_3_buffers": {"MIMO_WGRAD_STREAM": "1", "MIMO_WGRAD_BUFFERS": "3"},
     "side_stream_deferred": {"MIMO_WGRAD_STREAM": "2"},  # per-layer dz buffers: weight gradients queue without back-pressure
     "no_graph": {"MIMO_HIP_GRAPH": "0"},
     "subnet_streams": {"MIMO_SUBNET_STREAMS": "1"},     # encoder / decoder chains of the S subnetworks on S streams
