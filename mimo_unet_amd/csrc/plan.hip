@@ -686,7 +686,7 @@ struct mimo_plan {
       // training-step hipGraph (MIMO_TRAIN_GRAPH=1) turns it off.
       const char* tg = getenv("MIMO_TRAIN_GRAPH");
       wg_async = !(we && atoi(we) == 0) && !cfg.inference_only && !(tg && atoi(tg) != 0);
-      wg_deferred = wg_async && atoi(we) == 2;
+      wg_deferred = wg_async && we && atoi(we) == 2;
       if (wg_deferred)
         for (auto& dc : dcs)
           for (ConvBN* L : {&dc->c1, &dc->c2}) {
