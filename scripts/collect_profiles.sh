@@ -9,6 +9,14 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+# default run first (weight gradients on the side stream: kernel durations in this trace are OVERLAPPED durations)
+rocprofv3 --kernel-trace --stats -d "$OUT/trace_default" -o cfg3 --output-format csv -- python3 "$R/bench.py" --steps 5 --warmup 2 --profile-steps 0 --no-cpu-baseline > "$OUT/bench_under_rocprof_default.json" 2> "$OUT/trace_default.err"
+cp "$OUT/trace_default/cfg3_kernel_stats.csv" "$OUT/kernel_stats_default_overlapped.csv"
+python3 "$R/scripts/trace_overlap.py" "$OUT/trace_default" 0 0 > "$OUT/overlap_default.txt" 2>&1
+rm -rf "$OUT/trace_default"
+# per-kernel evidence: the same command with the streams serialised (MIMO_WGRAD_STREAM=0), which is also how
+# bench.py's own HIP-event pass measures the kernels (the plan serialises while its profiler is armed)
+export MIMO_WGRAD_STREAM=0
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o cfg3 --output-format csv -- python3 "$R/bench.py" --steps 5 --warmup 2 --profile-steps 0 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 cp "$OUT/trace/cfg3_kernel_stats.csv" "$OUT/kernel_stats.csv"
 python3 "$R/scripts/trace_step.py" "$OUT/trace" > "$OUT/step_timeline.txt" 2>&1
@@ -23,5 +31,6 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" \
 done
 rm -rf "$OUT/trace"
 python3 "$R/scripts/pmc_traffic.py" "$OUT" 3 > /dev/null 2>&1
+unset MIMO_WGRAD_STREAM
 cd "$R" && python3 bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"
