@@ -327,7 +327,10 @@ def main():
                    "parallelism": f"dp{world}" + ("" if dist is None else f" ({backend}: bucketed all-reduce started inside the backward)"),
                    "rccl_ranks": None if dist is None else dist.get_world_size(),
                    "params_bit_identical_across_ranks": identical,
-                   "optimizer": "adam(lr=1e-3) fused", "final_loss": round(final_loss, 5)},
+                   "optimizer": "adam(lr=1e-3) fused", "final_loss": round(final_loss, 5),
+                   "streams": ("weight gradients on the caller's stream" if os.environ.get("MIMO_WGRAD_STREAM") == "0" else
+                               "weight gradients on a side stream beside the BatchNorm-backward kernels of the layer below "
+                               "(MIMO_WGRAD_STREAM=1, default); the second pass that times the kernel classes serialises them")},
         # whole step against HBM: SURVEY 8(d) algorithmic bytes (activations + 3 x weights) / wall time / 8 TB/s
         "hbm_frac_step": round(step_bytes / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
     }
