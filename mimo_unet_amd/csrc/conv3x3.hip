@@ -413,7 +413,7 @@ int wgrad_launch(const WgradLaunch& a, hipStream_t stream) {
 //   A (only when splits > kReduceFan): slab group sums, element-wise, grid over (elements, groups)
 //   B: per (32 ci x 32 co) tile, sum <= kReduceFan slabs with co-contiguous reads, transpose the
 //      [9][32][32] tile through LDS and write torch's layout as 288-float contiguous runs per co
-constexpr int kReduceFan = 16;
+constexpr int kReduceFan = kWgReduceFan;
 
 __global__ void wgrad_group_sum_kernel(const float* __restrict__ partial, int splits, size_t slab, float* __restrict__ out) {
   const int grp = blockIdx.y;
@@ -432,9 +432,9 @@ __global__ void wgrad_group_sum_kernel(const float* __restrict__ partial, int sp
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int cin_pad,
-                                                           int cout_pad, const int* __restrict__ cin_map, int cin_p,
-                                                           int cin, int cout, float* __restrict__ dw) {
+__device__ __forceinline__ void wgrad_reduce_tile(const float* __restrict__ partial, int splits, int cin_pad, int cout_pad,
+                                                  const int* __restrict__ cin_map, int cin_p, int cin, int cout,
+                                                  float* __restrict__ dw, int block) {
   // 8 output channels per pass: a 9 KB LDS tile, so the kernel fits next to the 145-159 KB workgroups of
   // the persistent convolution kernels it runs beside (side stream) instead of waiting for their CUs
   constexpr int PITCH = 289;  // 32*9 + 1
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   // one (32 ci x 8 co) sub-tile per workgroup: the four sequential passes of a 32 x 32 tile were four exposed
   // load -> LDS -> store round trips (13 us even for a 36 KB slab)
   const int coTiles = (cout_pad + COB - 1) / COB;  // cin_pad / cout_pad are multiples of 16
-  const int ciT = blockIdx.x / coTiles, coT = blockIdx.x - ciT * coTiles;
+  const int ciT = block / coTiles, coT = block - ciT * coTiles;
   const int ci0 = ciT * 32;
   const size_t slab4 = (size_t)9 * cin_pad * cout_pad / 4;
   {
@@ -498,6 +498,56 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       dw[((size_t)(co0 + co) * cin + ci) * 9 + tap] = tile[co * PITCH + j];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int cin_pad,
+                                                           int cout_pad, const int* __restrict__ cin_map, int cin_p,
+                                                           int cin, int cout, float* __restrict__ dw) {
+  wgrad_reduce_tile(partial, splits, cin_pad, cout_pad, cin_map, cin_p, cin, cout, dw, (int)blockIdx.x);
+}
+
+// ---- the same two passes for several layers per launch (job tables, common.h) ----
+__global__ void wgrad_group_jobs_kernel(const WgGroupJob* __restrict__ jobs) {
+  const WgGroupJob j = jobs[blockIdx.y];
+  const float4* src = reinterpret_cast<const float4*>(j.src);
+  float4* dst = reinterpret_cast<float4*>(j.dst);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j.slab4; i += gridDim.x * blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < j.count; ++s) {
+      const float4 v = src[(size_t)s * j.slab4 + i];
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+    dst[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgReduceJob* __restrict__ jobs, int njobs,
+                                                                float* __restrict__ grads) {
+  int k = 0;
+  while (k + 1 < njobs && (int)blockIdx.x >= jobs[k + 1].block_begin) ++k;
+  const WgReduceJob j = jobs[k];
+  wgrad_reduce_tile(j.src, j.n, j.cin_pad, j.cout_pad, j.cin_map, j.cin_p, j.cin, j.cout, grads + j.w_off,
+                    (int)blockIdx.x - j.block_begin);
+}
+
+int wgrad_reduce_blocks(int cin_pad, int cout_pad) { return ceil_div(cin_pad, 32) * ceil_div(cout_pad, 8); }
+
+int wgrad_group_jobs_launch(const WgGroupJob* jobs_dev, int njobs, int max_slab4, hipStream_t stream) {
+  if (njobs <= 0) return MIMO_OK;
+  const int bx = std::max(1, std::min(ceil_div(max_slab4, 256), 256));
+  hipLaunchKernelGGL(wgrad_group_jobs_kernel, dim3(bx, njobs), dim3(256), 0, stream, jobs_dev);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+int wgrad_reduce_jobs_launch(const WgReduceJob* jobs_dev, int njobs, int total_blocks, float* grads, hipStream_t stream) {
+  if (njobs <= 0 || total_blocks <= 0) return MIMO_OK;
+  hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3(total_blocks), dim3(256), 0, stream, jobs_dev, njobs, grads);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
 }
 
 // scratch (floats) the reduction needs behind the `splits` slabs of the wgrad kernels
