@@ -152,10 +152,12 @@ struct mimo_plan {
         *s_partial = nullptr, *s_losspart = nullptr;
   double* s_sums = nullptr;
   int* s_tickets = nullptr;  // colsum tickets of the scratch set in use (zero between launches)
-  // Batched weight-gradient reduction (MIMO_WGRAD_BATCHED_REDUCE, default 1): every layer keeps its own slabs and the
+  // Batched weight-gradient reduction (MIMO_WGRAD_BATCHED_REDUCE=1, opt-in): every layer keeps its own slabs and the
   // reductions of all layers of a backward stage run as one launch per group-sum level + one final launch, instead of
-  // 1-3 small launches per layer (57 per step: 0.47 ms of fixed cost, 8 % of the step at 4 images per GPU).
-  bool wg_batched = true;
+  // 1-3 small launches per layer (57 per step, 0.47 ms of kernel time).  Bit-identical.  Measured no faster (5.71 vs
+  // 5.67 ms at 4 images per GPU, 29.1 vs 29.0 ms at 32) once the weight gradients run on the side stream: the
+  // per-layer reductions already hide there, the batched ones sit at the stage boundary the caller's stream waits on.
+  bool wg_batched = false;
   struct StageReduce {
     std::vector<WgGroupJob*> group_jobs;  // device tables, one per level
     std::vector<int> group_count, group_max_slab4;
@@ -799,7 +801,7 @@ struct mimo_plan {
     // ---- batched weight-gradient reduction: per-layer slabs and per-stage job tables ----
     {
       const char* be = getenv("MIMO_WGRAD_BATCHED_REDUCE");
-      wg_batched = !(be && atoi(be) == 0) && !cfg.inference_only;
+      wg_batched = be && atoi(be) != 0 && !cfg.inference_only;
       if (wg_batched) {
         std::vector<std::vector<ConvBN*>> stage_layers(kBwdStagesDecl);
         auto add = [&](int stage, DoubleConv* dc) {

@@ -478,9 +478,9 @@ def test_side_stream_weight_gradients_match(name, monkeypatch):
     cfg = cfg_from_meta(fx["meta"])
     image, label, perms = (torch.from_numpy(fx[f"s0/{k}"]).cuda() for k in ("image", "label", "perms"))
     grads = []
-    for mode in ("0", "1", "1-staged", "2", "2-staged", "0-perlayer"):  # 2 = deferred: per-layer dz buffers, no back-pressure
+    for mode in ("0", "1", "1-staged", "2", "2-staged", "0-batched", "1-batched"):  # 2 = deferred: per-layer dz buffers
         monkeypatch.setenv("MIMO_WGRAD_STREAM", mode[0])
-        monkeypatch.setenv("MIMO_WGRAD_BATCHED_REDUCE", "0" if mode.endswith("perlayer") else "1")
+        monkeypatch.setenv("MIMO_WGRAD_BATCHED_REDUCE", "1" if mode.endswith("batched") else "0")
         model = build_model(cfg, state_from(fx, "init/"))  # the variable is read when the plan is created
         model.train()
         if mode.endswith("staged"):

@@ -18,7 +18,7 @@ VARIANTS = {
     "side_stream_3_buffers": {"MIMO_WGRAD_STREAM": "1", "MIMO_WGRAD_BUFFERS": "3"},
     "side_stream_deferred": {"MIMO_WGRAD_STREAM": "2"},  # per-layer dz buffers: weight gradients queue without back-pressure
     "no_graph": {"MIMO_HIP_GRAPH": "0"},
-    "wgrad_reduce_per_layer": {"MIMO_WGRAD_BATCHED_REDUCE": "0"},  # 1-3 reduction launches per layer instead of per stage
+    "wgrad_reduce_batched": {"MIMO_WGRAD_BATCHED_REDUCE": "1"},  # one reduction launch sequence per backward stage
     "subnet_streams": {"MIMO_SUBNET_STREAMS": "1"},     # encoder / decoder chains of the S subnetworks on S streams
     "skip_copy": {"MIMO_SKIP_IN_PLACE": "0"},           # skip tensors copied into the concat buffers
     "skip_grad_copy": {"MIMO_SKIP_GRAD_IN_PLACE": "0"},  # skip-connection gradients copied out by fold_slice
