@@ -340,3 +340,77 @@ def test_bench_algorithmic_byte_model_matches_survey_table():
     flops = 3 * sum(2 * ci * co * k * k * h * w for _, ci, co, h, w, k in bench.conv_layers(bench.CONFIGS["cfg3"]))
     assert round(flops / 1e9, 1) == 194.8
     assert round(bench.algorithmic_bytes_per_image(bench.CONFIGS["cfg2"])[1] / 1e6, 1) == 605.0
+
+
+def test_flat_adam_follows_the_grad_scaler_protocol_for_fused_optimizers(monkeypatch):
+    """torch.amp.GradScaler hands a fused optimiser (`_step_supports_amp_scaling`) two tensor attributes around step():
+    `grad_scale` (divide the gradients by it) and `found_inf` (skip the step when non-zero) and deletes them afterwards.
+    FlatAdam forwards them to the device-side kernel, keeps its own multiplier under another name (`reduce_scale`) and
+    counts steps on the device so that a skipped step does not advance the bias correction."""
+    from mimo_unet_amd import optim as OP
+    calls = []
+
+    def fake_amp(p, g, m, v, *, lr, betas, eps, weight_decay, step_dev, reduce_scale, amp_scale, found_inf):
+        calls.append((None if amp_scale is None else float(amp_scale), None if found_inf is None else float(found_inf)))
+        if found_inf is not None and float(found_inf) != 0:
+            return
+        step_dev += 1
+        gs = g * reduce_scale / (1.0 if amp_scale is None else float(amp_scale))
+        _torch_adam_step(p, gs, m, v, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, step=int(step_dev.item()), grad_scale=1.0)
+
+    monkeypatch.setattr(OP, "adam_step", _torch_adam_step)
+    monkeypatch.setattr(OP, "adam_step_amp", fake_amp)
+    net, ref = _FakeFlatNet(), _FakeFlatNet()
+    opt, ropt = OP.FlatAdam(net, lr=1e-2), OP.FlatAdam(ref, lr=1e-2)
+    assert opt._step_supports_amp_scaling and opt.reduce_scale == 1.0 and not hasattr(opt, "grad_scale")
+    g = torch.Generator().manual_seed(1)
+    grads = [torch.randn(10, generator=g) for _ in range(3)]
+    # scaled step, overflow step (skipped), scaled step  ==  two plain steps on the unscaled gradients
+    for i, (gr, inf) in enumerate(((grads[0], 0.0), (grads[1], 1.0), (grads[2], 0.0))):
+        net.grads.copy_(gr * 1024.0)
+        opt.grad_scale, opt.found_inf = torch.tensor(1024.0), torch.tensor(inf)   # what GradScaler.step() sets ...
+        opt.step()
+        del opt.grad_scale, opt.found_inf                                          # ... and removes
+    for gr in (grads[0], grads[2]):
+        ref.grads.copy_(gr)
+        ropt.step()
+    assert opt.step_count == 2 and calls == [(1024.0, 0.0), (1024.0, 1.0), (1024.0, 0.0)]
+    torch.testing.assert_close(net.flat, ref.flat, rtol=1e-6, atol=1e-7)
+    # once the device counter exists, a plain step keeps using it
+    net.grads.copy_(grads[1])
+    opt.step()
+    assert opt.step_count == 3 and calls[-1] == (None, None)
+    assert opt.state_dict()["flat"]["step"] == 3
+
+
+def test_oracle_mixed_precision_emulation_inserts_the_storage_roundings():
+    """O.conv_operands("bf16-mixed" | "16-mixed"): operands and stored tensors rounded like the engine's 16-bit storage
+    modes — eval forward deviates from fp32 at the level of the type (and fp16 less than bf16), a training step runs,
+    updates the running statistics from the UNROUNDED conv output and stays within mixed-precision distance of fp32."""
+    from oracle import mimo_oracle as O
+    cfg = O.NetConfig(3, 2, 2, 4)
+    st = O.init_state(cfg, 0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 2, 3, 32, 32, generator=g)
+    with torch.no_grad():
+        ref = O.mimo_unet_forward(cfg, st, x, training=False)
+        errs = {}
+        for kind in ("bf16", "bf16-mixed", "16-mixed"):
+            with O.conv_operands(kind):
+                out = O.mimo_unet_forward(cfg, st, x, training=False)
+            errs[kind] = float((out - ref).abs().max() / ref.abs().max())
+    assert 1e-6 < errs["16-mixed"] < errs["bf16-mixed"] < 2e-2 and errs["16-mixed"] < 2e-3
+    img, lab = torch.rand(2, 3, 32, 32, generator=g), torch.rand(2, 1, 32, 32, generator=g)
+    perms = O.draw_perms(2, 2, generator=g)
+    res = {}
+    for kind in ("fp32", "16-mixed"):
+        ts = O.TrainState(cfg=cfg, st={k: v.clone() for k, v in st.items()}, loss_buffer=O.LossBuffer(2, 0.3, 10))
+        with O.conv_operands(kind):
+            r = O.train_step(ts, img, lab, None, perms, apply_optimizer=False)
+        res[kind] = (float(r["total"]), ts.st["core.down2.conv.double_conv.1.running_mean"].clone(),
+                     torch.cat([v.flatten() for k, v in sorted(r["grads"].items())]))
+    assert abs(res["16-mixed"][0] - res["fp32"][0]) < 5e-3 * abs(res["fp32"][0])
+    torch.testing.assert_close(res["16-mixed"][1], res["fp32"][1], rtol=5e-3, atol=5e-4)
+    cos = torch.nn.functional.cosine_similarity(res["16-mixed"][2], res["fp32"][2], dim=0).item()
+    assert cos > 0.97
+    assert O._STORE16 is None and O._CONV_OPERANDS == "fp32"  # context managers restored the defaults
