@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmimo_hip.so")
+# MIMO_HIP_LIB: another build of the same library (A/B runs of two builds on one GPU box)
+LIB_PATH = os.environ.get("MIMO_HIP_LIB") or os.path.join(_HERE, "libmimo_hip.so")
 
 
 class MimoHipError(RuntimeError):

@@ -1297,37 +1297,49 @@ int bn_bwd_apply_launch(const void* da, int dta, int ldda, const void* dxpad, in
 // channel row — a wave reads 64 consecutive float4, fully coalesced — multiplies it with its slice of the
 // 1x1 weights, and a butterfly of G-lane shuffles completes the Co dot products.  (One thread per pixel
 // reading its own 128-byte row touched 64 cache lines per load instruction and ran at 1 TB/s.)
-template <int G, typename T>
+template <int G, int CO, typename T>
 __global__ void head_fwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
                                 const float* __restrict__ bias, int C, int Cp, int Co, int N, int S, int s, int HW,
                                 float* __restrict__ out) {
+  // CO = compile-time bound of Co (2: one target, 4: the evidential head, 8: the rest); UN pixels per thread and
+  // iteration, their loads issued together (one 16-byte load in flight per thread ran at 3.4 TB/s)
   const int g = threadIdx.x % G, pl = threadIdx.x / G;
-  constexpr int PPB = 256 / G;
-  float wq[kMaxHeadOut][4], bs[kMaxHeadOut];
+  constexpr int PPB = 256 / G, UN = 4;
+  float wq[CO][4], bs[CO];
 #pragma unroll
-  for (int co = 0; co < kMaxHeadOut; ++co) {
+  for (int co = 0; co < CO; ++co) {
     bs[co] = co < Co ? bias[co] : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) wq[co][j] = (co < Co && 4 * g + j < C) ? w[co * C + 4 * g + j] : 0.f;
   }
   const bool has = 4 * g < Cp;
-  const int64_t P = (int64_t)N * HW;
-  for (int64_t p = (int64_t)blockIdx.x * PPB + pl; p < P; p += (int64_t)gridDim.x * PPB) {
-    const float4 v = has ? ld4(a + p * lda + 4 * g) : f4zero();
-    float acc[kMaxHeadOut];
+  const int64_t P = (int64_t)N * HW, stride = (int64_t)gridDim.x * PPB;
+  for (int64_t p0 = (int64_t)blockIdx.x * PPB + pl; p0 < P; p0 += stride * UN) {
+    float4 v[UN];
 #pragma unroll
-    for (int co = 0; co < kMaxHeadOut; ++co)
-      acc[co] = fmaf(v.x, wq[co][0], fmaf(v.y, wq[co][1], fmaf(v.z, wq[co][2], v.w * wq[co][3])));
+    for (int u = 0; u < UN; ++u) {
+      const int64_t p = p0 + u * stride;
+      v[u] = (has && p < P) ? ld4(a + p * lda + 4 * g) : f4zero();
+    }
 #pragma unroll
-    for (int off = 1; off < G; off <<= 1)
+    for (int u = 0; u < UN; ++u) {
+      const int64_t p = p0 + u * stride;
+      float acc[CO];
 #pragma unroll
-      for (int co = 0; co < kMaxHeadOut; ++co)
-        if (co < Co) acc[co] += __shfl_xor(acc[co], off);
-    const int n = (int)(p / HW);
-    const int yx = (int)(p - (int64_t)n * HW);
+      for (int co = 0; co < CO; ++co)
+        acc[co] = fmaf(v[u].x, wq[co][0], fmaf(v[u].y, wq[co][1], fmaf(v[u].z, wq[co][2], v[u].w * wq[co][3])));
 #pragma unroll
-    for (int co = 0; co < kMaxHeadOut; ++co)
-      if (co < Co && co % G == g) out[(((int64_t)n * S + s) * Co + co) * HW + yx] = acc[co] + bs[co];
+      for (int off = 1; off < G; off <<= 1)
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] += __shfl_xor(acc[co], off);
+      if (p < P) {
+        const int n = (int)(p / HW);
+        const int yx = (int)(p - (int64_t)n * HW);
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+          if (co < Co && co % G == g) out[(((int64_t)n * S + s) * Co + co) * HW + yx] = acc[co] + bs[co];
+      }
+    }
   }
 }
 
@@ -1341,10 +1353,18 @@ int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float*
   int G = 2;
   while (G < Cv) G <<= 1;
   const int64_t P = (int64_t)N * HW;
-  const int blocks = (int)std::min<int64_t>(ceil_div64(P, 256 / G), 4096);
-#define HEAD_LAUNCH(GG)                                                                                              \
-  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL((head_fwd_kernel<GG, T>), dim3(blocks), dim3(256), 0, st, (const T*)a, lda, w, bias, C, \
-                                             Cp, Co, N, S, s, HW, out))
+  const int blocks = (int)std::min<int64_t>(ceil_div64(P, (256 / G) * 4), 4096);
+#define HEAD_LAUNCH2(GG, CC)                                                                                         \
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL((head_fwd_kernel<GG, CC, T>), dim3(blocks), dim3(256), 0, st, (const T*)a, lda, w, bias, \
+                                             C, Cp, Co, N, S, s, HW, out))
+#define HEAD_LAUNCH(GG)             \
+  if (Co <= 2) {                    \
+    HEAD_LAUNCH2(GG, 2);            \
+  } else if (Co <= 4) {             \
+    HEAD_LAUNCH2(GG, 4);            \
+  } else {                          \
+    HEAD_LAUNCH2(GG, kMaxHeadOut);  \
+  }
   switch (G) {
     case 2: HEAD_LAUNCH(2); break;
     case 4: HEAD_LAUNCH(4); break;
@@ -1354,6 +1374,7 @@ int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float*
     default: HEAD_LAUNCH(64); break;
   }
 #undef HEAD_LAUNCH
+#undef HEAD_LAUNCH2
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1439,7 +1460,9 @@ int loss_finalize_launch(const float* partial, int S, int blocks, double count, 
   return MIMO_OK;
 }
 
-template <typename T>
+// CO = compile-time bound of Co (as in head_fwd_kernel); UN pixels per thread and iteration, loads issued together (the
+// grid is capped at kEwMaxBlocks partial rows = 16 waves per CU: one pixel at a time left 16 KB in flight per CU)
+template <int CO, typename T>
 __global__ void head_bwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w, int C, int Cv, int Co,
                                 int N, int S, int s, int HW, const float* __restrict__ out,
                                 const float* __restrict__ dout, const float* __restrict__ dloss,
@@ -1447,12 +1470,13 @@ __global__ void head_bwd_kernel(const T* __restrict__ a, int lda, const float* _
                                 const int64_t* __restrict__ perm, int kind, float eps_min, float eps_max, float inv_count,
                                 T* __restrict__ da, float* __restrict__ partial) {
   __shared__ float4 red[256];
+  constexpr int UN = 4;
   const PQ t = pixquad(Cv);
   const int Cp = 4 * Cv, Ct = Co / 2;
-  float4 wq[kMaxHeadOut], dwacc[kMaxHeadOut];
-  float dbacc[kMaxHeadOut];
+  float4 wq[CO], dwacc[CO];
+  float dbacc[CO];
 #pragma unroll
-  for (int co = 0; co < kMaxHeadOut; ++co) {
+  for (int co = 0; co < CO; ++co) {
     wq[co] = f4zero();
     dwacc[co] = f4zero();
     dbacc[co] = 0.f;
@@ -1467,43 +1491,64 @@ __global__ void head_bwd_kernel(const T* __restrict__ a, int lda, const float* _
   const float coef = dloss ? dloss[s] * inv_count : 0.f;
   if (t.active) {
     const int P = N * HW;
-    for (int p = t.p; p < P; p += t.pstep) {
-      const int n = p / HW;
-      const int yx = p - n * HW;
-      const int64_t obase = (((int64_t)n * S + s) * Co) * HW + yx;
-      float dl[kMaxHeadOut];
+    for (int p0 = t.p; p0 < P; p0 += UN * t.pstep) {
+      float dl[UN][CO], mu[UN][CO / 2], lp[UN][CO / 2], y[UN][CO / 2], mk[UN];
+      float4 av[UN];
 #pragma unroll
-      for (int co = 0; co < kMaxHeadOut; ++co) dl[co] = (dout && co < Co) ? dout[obase + (int64_t)co * HW] : 0.f;
-      if (dloss) {
-        const int64_t src = perm ? perm[(int64_t)s * N + n] : n;
-        const float mk = mask ? mask[src * HW + yx] : 1.f;
+      for (int u = 0; u < UN; ++u) {
+        const int p = min(p0 + u * t.pstep, P - 1);  // past the end: a valid pixel, results discarded
+        const int n = p / HW;
+        const int yx = p - n * HW;
+        const int64_t obase = (((int64_t)n * S + s) * Co) * HW + yx;
 #pragma unroll
-        for (int tc = 0; tc < kMaxHeadOut / 2; ++tc)
-          if (tc < Ct) {
-            const float mu = out[obase + (int64_t)tc * HW], lp = out[obase + (int64_t)(Ct + tc) * HW];
-            const float y = label[(src * Ct + tc) * HW + yx];
-            float gm, gl;
-            nll_grad(kind, mu - y, lp, eps_min, eps_max, &gm, &gl);
-            dl[tc] += coef * mk * gm;
-            dl[Ct + tc] += coef * mk * gl;  // Ct + tc < kMaxHeadOut
-          }
-      }
-      const float4 av = ld4(a + (size_t)p * lda + 4 * t.q);
-      float4 g = f4zero();
+        for (int co = 0; co < CO; ++co) dl[u][co] = (dout && co < Co) ? dout[obase + (int64_t)co * HW] : 0.f;
+        mk[u] = 1.f;
+        if (dloss) {
+          const int64_t src = perm ? perm[(int64_t)s * N + n] : n;
+          if (mask) mk[u] = mask[src * HW + yx];
 #pragma unroll
-      for (int co = 0; co < kMaxHeadOut; ++co)
-        if (co < Co) {
-          g.x = fmaf(dl[co], wq[co].x, g.x);
-          g.y = fmaf(dl[co], wq[co].y, g.y);
-          g.z = fmaf(dl[co], wq[co].z, g.z);
-          g.w = fmaf(dl[co], wq[co].w, g.w);
-          dwacc[co].x = fmaf(dl[co], av.x, dwacc[co].x);
-          dwacc[co].y = fmaf(dl[co], av.y, dwacc[co].y);
-          dwacc[co].z = fmaf(dl[co], av.z, dwacc[co].z);
-          dwacc[co].w = fmaf(dl[co], av.w, dwacc[co].w);
-          dbacc[co] += dl[co];
+          for (int tc = 0; tc < CO / 2; ++tc)
+            if (tc < Ct) {
+              mu[u][tc] = out[obase + (int64_t)tc * HW];
+              lp[u][tc] = out[obase + (int64_t)(Ct + tc) * HW];
+              y[u][tc] = label[(src * Ct + tc) * HW + yx];
+            }
         }
-      st4(da + (size_t)p * Cp + 4 * t.q, g);
+        av[u] = ld4(a + (size_t)p * lda + 4 * t.q);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int p = p0 + u * t.pstep;
+        if (p >= P) break;
+        if (dloss) {
+#pragma unroll
+          for (int tc = 0; tc < CO / 2; ++tc)
+            if (tc < Ct) {
+              float gm, gl;
+              nll_grad(kind, mu[u][tc] - y[u][tc], lp[u][tc], eps_min, eps_max, &gm, &gl);
+#pragma unroll
+              for (int co = 0; co < CO; ++co) {  // dl[tc] and dl[Ct + tc], with compile-time register indices
+                if (co == tc) dl[u][co] += coef * mk[u] * gm;
+                if (co == Ct + tc) dl[u][co] += coef * mk[u] * gl;
+              }
+            }
+        }
+        float4 g = f4zero();
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+          if (co < Co) {
+            g.x = fmaf(dl[u][co], wq[co].x, g.x);
+            g.y = fmaf(dl[u][co], wq[co].y, g.y);
+            g.z = fmaf(dl[u][co], wq[co].z, g.z);
+            g.w = fmaf(dl[u][co], wq[co].w, g.w);
+            dwacc[co].x = fmaf(dl[u][co], av[u].x, dwacc[co].x);
+            dwacc[co].y = fmaf(dl[u][co], av[u].y, dwacc[co].y);
+            dwacc[co].z = fmaf(dl[u][co], av[u].z, dwacc[co].z);
+            dwacc[co].w = fmaf(dl[u][co], av[u].w, dwacc[co].w);
+            dbacc[co] += dl[u][co];
+          }
+        st4(da + (size_t)p * Cp + 4 * t.q, g);
+      }
     }
   }
   // partial row: [Co][Cp] weight gradient followed by [Co] bias gradient (from quad 0 threads)
@@ -1512,7 +1557,7 @@ __global__ void head_bwd_kernel(const T* __restrict__ a, int lda, const float* _
     float4 v = f4zero();
     float b = 0.f;
 #pragma unroll
-    for (int k = 0; k < kMaxHeadOut; ++k)
+    for (int k = 0; k < CO; ++k)
       if (k == co) {
         v = dwacc[k];
         b = dbacc[k];
@@ -1537,8 +1582,18 @@ int head_bwd_launch(const void* a, int dt, int lda, const float* w, int C, int C
   grid.y = 1;  // Cv <= 64 for the head (filter_base_count <= 256)
   *rows = grid.x;
   const float inv_count = 1.f / (float)((double)N * (Co / 2) * HW);
-  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(head_bwd_kernel<T>, grid, dim3(256), 0, st, (const T*)a, lda, w, C, Cv, Co, N, S, s, HW,
-                                             out, dout, dloss, label, mask, perm, kind, eps_min, eps_max, inv_count, (T*)da, partial));
+#define HEAD_BWD_LAUNCH(CC)                                                                                              \
+  MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL((head_bwd_kernel<CC, T>), grid, dim3(256), 0, st, (const T*)a, lda, w, C, Cv, Co, N, S, s, \
+                                             HW, out, dout, dloss, label, mask, perm, kind, eps_min, eps_max, inv_count, (T*)da,  \
+                                             partial))
+  if (Co <= 2) {
+    HEAD_BWD_LAUNCH(2);
+  } else if (Co <= 4) {
+    HEAD_BWD_LAUNCH(4);
+  } else {
+    HEAD_BWD_LAUNCH(kMaxHeadOut);
+  }
+#undef HEAD_BWD_LAUNCH
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
