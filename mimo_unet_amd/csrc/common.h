@@ -71,6 +71,7 @@ struct ConvLaunch {
   const float* ep_shift = nullptr;
   const float* ep_mask = nullptr;
   int ep_mask_ld = 0;
+  int pair = 0;  // split kernel: a.wpk holds the tap-paired image of the last chunk (conv3x3_pair_tail)
 };
 // returns number of partial-stat rows (spatial blocks) through *rows when stats != nullptr
 int conv3x3_launch(const ConvLaunch& a, int* rows, hipStream_t stream);
@@ -79,7 +80,10 @@ int conv3x3_launch(const ConvLaunch& a, int* rows, hipStream_t stream);
 // 2: bf16 forward (one MFMA per product); 3: bf16 data gradient
 int conv3x3_bf16x3_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t stream);
 int pack_weights_bf16x3_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
-                               const int* row_map, const int* col_map, int transposed, hipStream_t stream);
+                               const int* row_map, const int* col_map, int transposed, hipStream_t stream, int pair = 0);
+// 1 when conv3x3_bf16x3_launch(mode) runs a layer with cin_p input channels and Ho x Wo outputs on the tap-paired
+// instance (last chunk <= 16 channels: two taps per MFMA); the weights must then be packed with pair = 1
+int conv3x3_pair_tail(int mode, int cin_p, int Ho, int Wo);
 int conv3x3_pick_nfrag(int cout);            // fragments (of 16 output channels) per workgroup
 int conv3x3_cout_pad(int cout);              // packed weight rows for that choice
 int conv3x3_stat_rows(int N, int Ho, int Wo);  // spatial workgroups == partial-stat rows
@@ -146,6 +150,7 @@ struct PackJob {
   float* bias_dst;
   const int *row_map, *col_map;
   int kind, cout, cin, rows_pad, cols, transposed, total, bias_n;
+  int pair;  // kind 1 / 2: tap-paired image of the last chunk (conv3x3_pair_tail)
 };
 int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream);
 

@@ -403,12 +403,22 @@ struct WsTile {
 };
 constexpr int kWsMaxMF = 4;
 
-template <int NF, int MODE, bool SWZ, int MF_>
+// PAIR (split16 modes, padded rows): the LAST 32-channel chunk of the input holds <= 16 channels.  Its taps are then
+// multiplied two per MFMA in TWO phases of three steps instead of three: step kw of the first phase carries channels
+// 0-15 of tap (0, kw) in K lanes 0-15 and of tap (1, kw) in K lanes 16-31, step kw of the second tap (2, kw) in K
+// lanes 0-15 (weights of lanes 16-31 zero); the chunk's third phase is a bare barrier (the producers stage as
+// before).  45 input channels: 15 K steps per tile instead of 18.  The weight image of the chunk is packed accordingly
+// (conv3x3_pair_tail, pack kernels below); the input tile in LDS is unchanged: the lanes of K groups 2-3 read the
+// pixel one tile row further down at slots 0-1 — a per-lane constant, so the fragment addresses keep the form
+// (lane base) + (scalar of the phase) + (immediate of the step), and phases keep their three steps, so the
+// alternation of the two B register sets is the same compile-time pattern as without pairing.
+template <int NF, int MODE, bool SWZ, int MF_, bool PAIR = false>
 __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC,
                                                                                           int tilesY, int tilesX,
                                                                                           int numTiles, int xcd_order,
                                                                                           int gx, int coTiles) {
   MIMO_CONV_MODE_CONSTANTS
+  static_assert(!PAIR || (!SWZ && NP == 3 && !IN16), "tap pairing: split16 modes on the padded LDS rows");
   typedef typename Elem<F16>::T ET;
   typedef typename Elem<F16>::V8 bf16x8;
   typedef typename Elem<F16>::V4 bf16x4;
@@ -622,6 +632,9 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   }
   // weight rows: row & 7 == lr & 7 (row = tap * NB + nf * 16 + lr), so the swizzle is a per-lane constant;
   // the lo half is slot + 4, i.e. the hi address with bit 6 flipped
+  // phases of a paired chunk (see the kernel comment); second phase: K groups 2-3 meet zero weights and re-read slots
+  // 0-1 of their own row (any finite data)
+  const int pair_d = g >= 2 ? TCP * PITCH - 32 : 0, pair_d2 = g >= 2 ? -32 : 0;
   const int wbase = SWZ ? lr * PITCH + ((g ^ (lr & 7)) << 4) : lr * PITCH + g * 16;
   const int wlo = SWZ ? ((wbase ^ 64) - wbase) : 64;
   // Accumulators are kept TRANSPOSED (MFMA called with the weight fragment as A and the pixel fragment as B):
@@ -669,15 +682,17 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     bh[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * PITCH);              \
     if (NP == 3) bl[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * PITCH + wlo); \
   }
-#define C_READ_A(AS, KW, M)                                                                          \
+  // ro_: tile row of the phase's taps (r_; phases of a paired chunk: 0 and 2); pd_: the per-lane constant of a paired
+  // chunk's phases (first: K groups 2-3 read one tile row down, slots 0-1), else 0
+#define C_READ_A(AS, KW, M)                                                                     \
   {                                                                                                  \
     if (SWZ) {                                                                                       \
-      const int row_ = pbase[M] + r_ * TCP + (KW);                                                   \
+      const int row_ = pbase[M] + ro_ * TCP + (KW);                                                   \
       const int o_ = row_ * PITCH + ((g ^ (row_ & 7)) << 4);                                         \
       ah[AS] = *reinterpret_cast<const bf16x8*>(xb_ + o_);                                           \
       if (NP == 3) al[AS] = *reinterpret_cast<const bf16x8*>(xb_ + (o_ ^ 64));                       \
     } else {                                                                                         \
-      const unsigned char* p_ = xb_ + pbase[M] + (r_ * TCP + (KW)) * PITCH;                          \
+      const unsigned char* p_ = xb_ + pbase[M] + pd_ + (ro_ * TCP + (KW)) * PITCH;                                            \
       ah[AS] = *reinterpret_cast<const bf16x8*>(p_);                                                 \
       if (NP == 3) al[AS] = *reinterpret_cast<const bf16x8*>(p_ + 64);                               \
     }                                                                                                \
@@ -778,6 +793,9 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     const int j_ = ph / 3, r_ = ph - 3 * j_;                                                         \
     const unsigned char* xb_ = xs + (j_ & 1) * XBYTES;                                               \
     const unsigned char* wb_ = ws + (ph & 1) * WROWB + wbase;                                        \
+    const bool pc_ = PAIR && (j_ + 1) % nchunks == 0; /* phase of a paired chunk (r_ = 0, 1) */       \
+    const int ro_ = pc_ ? 2 * r_ : r_;                                                               \
+    const int pd_ = pc_ ? (r_ == 0 ? pair_d : pair_d2) : 0;                                          \
     __syncthreads(); /* this phase is staged; the buffers of the previous one are released */        \
     C_READ_B((P) ^ 1, 0)                                                                             \
     C_READ_A(0, 0, 0)                                                                                \
@@ -792,14 +810,21 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     C_TAP(0, (P) ^ 1, false)                                                                         \
     C_TAP(1, P, false)                                                                               \
     C_TAP(2, (P) ^ 1, true)                                                                          \
-    tile_done = r_ == 2 && (j_ + 1) % nchunks == 0;                                                  \
+    tile_done = r_ == (PAIR ? 1 : 2) && (j_ + 1) % nchunks == 0;                                     \
     ++ph;                                                                                            \
+    if (PAIR) { /* third phase of a paired chunk: nothing to multiply */                             \
+      if (ph < nphases && ph % 3 == 2 && (ph / 3 + 1) % nchunks == 0) {                              \
+        __syncthreads();                                                                             \
+        ++ph;                                                                                        \
+      }                                                                                              \
+    }                                                                                                \
   }
 
   int ph = 0, ti = 0;
   bool tile_done = false;
+  // (PAIR: ph also counts the bare-barrier phases, which C_PHASE consumes behind the phase in front of them)
   C_PHASE(1, true)  // leaves B set 0 pending
-  while (ph + 1 < nphases) {
+  while (ph + (PAIR ? 2 : 1) < nphases) {  // at least two phases to go (PAIR: the very last one is a bare barrier)
     C_PHASE(0, false)
     C_PHASE(1, false)
   }
@@ -854,6 +879,16 @@ static bool conv_ws_enabled() {
 
 int conv3x3_ws_stat_rows(int, int, int) { return 512 * 4; }  // <= 512 persistent workgroups x 4 consumer waves
 
+// Tap pairing of a <= 16-channel last chunk (see conv3x3_ws_kernel): decided per layer from what the dispatch below
+// will launch — the packer lays the chunk's weights out for it, the launch selects the PAIR instance (ConvLaunch::pair).
+int conv3x3_pair_tail(int mode, int cin_p, int Ho, int Wo) {
+  static const bool on = !(getenv("MIMO_CONV_PAIR_TAIL") && atoi(getenv("MIMO_CONV_PAIR_TAIL")) == 0);
+  static const bool swz = getenv("MIMO_CONV_WS_SWIZZLE") && atoi(getenv("MIMO_CONV_WS_SWIZZLE")) != 0;
+  if (!on || swz || mode < 0 || mode > 1 || !conv_ws_enabled() || Ho * Wo < 256) return 0;
+  const int tail = cin_p - 32 * (ceil_div(cin_p, 32) - 1);
+  return tail <= 16 ? 1 : 0;
+}
+
 template <int NF, int MODE, int MF>
 static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   int TR, TC;
@@ -874,7 +909,18 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   // forward / data gradient per step): the LDS array is not what the consumers wait for.  Opt-in.
   static const bool swz = getenv("MIMO_CONV_WS_SWIZZLE") && atoi(getenv("MIMO_CONV_WS_SWIZZLE")) != 0;
   static const int xcd = !(getenv("MIMO_CONV_XCD_ORDER") && atoi(getenv("MIMO_CONV_XCD_ORDER")) == 0);
-  if (swz)
+  if (a.pair) {
+    if constexpr (MODE <= 1) {
+      if (swz || a.pair != conv3x3_pair_tail(MODE, a.cin_p, a.Ho, a.Wo)) {
+        set_error("conv3x3 split: weights packed for tap pairing, launch is not");
+        return MIMO_ERR_INVALID;
+      }
+      hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false, MF, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
+    } else {
+      set_error("conv3x3 split: tap pairing exists for the split16 modes only");
+      return MIMO_ERR_INVALID;
+    }
+  } else if (swz)
     hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, true, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
   else
     hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
@@ -936,6 +982,10 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
       default: return mf2 ? launch_ws<1, MODE, 2>(a, rows, stream) : launch_ws<1, MODE, 4>(a, rows, stream);
     }
   }
+  if (a.pair) {
+    set_error("conv3x3 split: weights packed for tap pairing, launch is not");
+    return MIMO_ERR_INVALID;
+  }
   if (use_big_tile(a.Ho, a.Wo) && (nf >= 3 || big_nf2)) {
     switch (nf) {
       case 4: return launch_bf16x3<4, 4, MODE>(a, rows, stream);
@@ -975,10 +1025,19 @@ int conv3x3_bf16x3_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t 
 // weight packing for the split kernel: torch OIHW -> [chunk][tap][row][hi 32 | lo 32] bf16
 // (row/col maps and the transposed flag as in pack_weights_kernel, conv3x3.hip)
 // ---------------------------------------------------------------------------------------
+// paired last chunk (conv3x3_pair_tail): tap (row, kw) of channel k < 16 -> of the chunk's nine weight slots, slot kw
+// for rows 0 (K lane k) and 1 (K lane 16 + k), slot 3 + kw for row 2 (K lane k).  K lanes 16-31 of slots 3-5 and
+// slots 6-8 are never written: they keep the zeros of the allocation.
+__device__ __forceinline__ void pair_slot(int tap, int k, int* slot, int* kk) {
+  const int row = tap / 3, kw = tap - 3 * row;
+  *slot = row == 2 ? 3 + kw : kw;
+  *kk = k + (row == 1 ? 16 : 0);
+}
+
 template <bool F16>
 __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, typename Elem<F16>::T* __restrict__ dst, int cout,
                                            int cin, int rows_pad, int cols, int nchunks, const int* __restrict__ row_map,
-                                           const int* __restrict__ col_map, int transposed) {
+                                           const int* __restrict__ col_map, int transposed, int pair) {
   typedef typename Elem<F16>::T ET;
   const int total = nchunks * 9 * rows_pad * 32;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -1000,9 +1059,14 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, typename
     if (F16) v *= kF16WeightScale;
     const ET hi = (ET)v;
     const ET lo = (ET)(v - (float)hi);
-    ET* d = dst + (((size_t)chunk * 9 + tap) * rows_pad + row) * 64;
-    d[k] = hi;
-    d[32 + k] = lo;
+    int slot = tap, kk = k;
+    if (pair && chunk == nchunks - 1) {
+      if (k >= 16) continue;  // K lanes 16-31 of the paired image belong to the odd taps of channels 0-15
+      pair_slot(tap, k, &slot, &kk);
+    }
+    ET* d = dst + (((size_t)chunk * 9 + slot) * rows_pad + row) * 64;
+    d[kk] = hi;
+    d[32 + kk] = lo;
   }
 }
 
@@ -1042,22 +1106,26 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
         for (int t = 0; t < 9; ++t) v[t] = src[j.transposed ? 8 - t : t];  // transposed: taps flipped (kh, kw -> 2-kh, 2-kw)
       }
     }
+    const bool paired = j.kind != 0 && j.pair && chunk == (j.cols + 31) / 32 - 1;
+    if (paired && k >= 16) continue;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const float x = v[tap];
+      int slot = tap, kk = k;
+      if (paired) pair_slot(tap, k, &slot, &kk);
       if (j.kind == 0) {
         reinterpret_cast<float*>(j.dst)[((size_t)tap * j.rows_pad + row) * j.cols + col] = x;
       } else if (j.kind == 1) {
         const float xs = x * kF16WeightScale;
         const _Float16 hi = (_Float16)xs, lo = (_Float16)(xs - (float)hi);
-        _Float16* d = reinterpret_cast<_Float16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 64;
-        d[k] = hi;
-        d[32 + k] = lo;
+        _Float16* d = reinterpret_cast<_Float16*>(j.dst) + (((size_t)chunk * 9 + slot) * j.rows_pad + row) * 64;
+        d[kk] = hi;
+        d[32 + kk] = lo;
       } else {
         const __bf16 hi = (__bf16)x, lo = (__bf16)(x - (float)hi);
-        __bf16* d = reinterpret_cast<__bf16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 64;
-        d[k] = hi;
-        d[32 + k] = lo;
+        __bf16* d = reinterpret_cast<__bf16*>(j.dst) + (((size_t)chunk * 9 + slot) * j.rows_pad + row) * 64;
+        d[kk] = hi;
+        d[32 + kk] = lo;
       }
     }
   }
@@ -1072,16 +1140,16 @@ int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const fl
 }
 
 int pack_weights_bf16x3_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
-                               const int* row_map, const int* col_map, int transposed, hipStream_t stream) {
+                               const int* row_map, const int* col_map, int transposed, hipStream_t stream, int pair) {
   const int nchunks = ceil_div(cols, 32);
   const int total = nchunks * 9 * rows_pad * 32;
   const int blocks = min(ceil_div(total, 256), 4096);
   if (f16)
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel<true>, dim3(blocks), dim3(256), 0, stream, w,
-                       reinterpret_cast<_Float16*>(dst), cout, cin, rows_pad, cols, nchunks, row_map, col_map, transposed);
+                       reinterpret_cast<_Float16*>(dst), cout, cin, rows_pad, cols, nchunks, row_map, col_map, transposed, pair);
   else
     hipLaunchKernelGGL(pack_weights_bf16x3_kernel<false>, dim3(blocks), dim3(256), 0, stream, w,
-                       reinterpret_cast<__bf16*>(dst), cout, cin, rows_pad, cols, nchunks, row_map, col_map, transposed);
+                       reinterpret_cast<__bf16*>(dst), cout, cin, rows_pad, cols, nchunks, row_map, col_map, transposed, pair);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

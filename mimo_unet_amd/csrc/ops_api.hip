@@ -120,7 +120,9 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
     return MIMO_ERR_HIP;
   }
   MIMO_TRY(pack_weights_launch(w, wf, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
-  if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, bf16 ? 0 : 1, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
+  const int fmode = mixed ? (f16s ? 6 : 4) : (bf16 ? 2 : 1);
+  const int pair = split ? conv3x3_pair_tail(fmode, cin_p, h, wd) : 0;
+  if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, bf16 ? 0 : 1, cout, cin, cout_pad, cin_p, rm, cm, 0, st, pair));
   if (bias) MIMO_HIP_CHECK(hipMemcpyAsync(bp, bias, cout * sizeof(float), hipMemcpyDeviceToDevice, st));
   const int64_t nx = (int64_t)n * h * wd * cin_p, nz = (int64_t)n * h * wd * cout_p;
   uint16_t *x16 = nullptr, *z16 = nullptr;
@@ -149,9 +151,10 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   a.cout_store = cout_p;
   a.off = 1;
   a.wpk = wpk;
+  a.pair = pair;
   int rows = 0;
   if (split)
-    MIMO_TRY(conv3x3_bf16x3_launch(a, mixed ? (f16s ? 6 : 4) : (bf16 ? 2 : 1), &rows, st));
+    MIMO_TRY(conv3x3_bf16x3_launch(a, fmode, &rows, st));
   else
     MIMO_TRY(conv3x3_launch(a, &rows, st));
   if (mixed) MIMO_TRY(from16(z16, z, nz, f16s, st));
@@ -183,7 +186,9 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
     return MIMO_ERR_HIP;
   }
   MIMO_TRY(pack_weights_launch(w, wdp, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
-  if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, f16s ? 1 : 0, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
+  const int dmode = mixed ? (f16s ? 7 : 5) : (bf16 ? 3 : 0);
+  const int pair = split ? conv3x3_pair_tail(dmode, cout_p, h + 2, wd + 2) : 0;
+  if (split) MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, f16s ? 1 : 0, cout, cin, rows_pad, cout_p, rm, cm, 1, st, pair));
   const float* dz_in = dz;
   const int64_t ndz = (int64_t)n * h * wd * cout_p, ndx = (int64_t)n * h * wd * cin_p;
   uint16_t* dx16 = nullptr;
@@ -223,8 +228,9 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
   a.cout_store = cin_p;
   a.off = 2;
   a.wpk = wpk;
+  a.pair = pair;
   if (split)
-    MIMO_TRY(conv3x3_bf16x3_launch(a, mixed ? (f16s ? 7 : 5) : (bf16 ? 3 : 0), nullptr, st));
+    MIMO_TRY(conv3x3_bf16x3_launch(a, dmode, nullptr, st));
   else
     MIMO_TRY(conv3x3_launch(a, nullptr, st));
   if (mixed) {

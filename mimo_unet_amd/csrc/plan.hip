@@ -775,6 +775,7 @@ struct mimo_plan {
           j.kind = L->fwd_split ? ((cfg.precision == MIMO_PREC_BF16 || cfg.precision == MIMO_PREC_BF16_MIXED) ? 2 : 1) : 0;
           j.dst = L->fwd_split ? L->wf16 : (void*)L->wf;
           j.total = L->fwd_split ? ceil_div(j.cols, 32) * 9 * j.rows_pad * 32 : 9 * j.rows_pad * j.cols;
+          j.pair = L->fwd_split ? conv3x3_pair_tail(fwd_mode(), L->cin_p, L->H, L->W) : 0;
           jobs.push_back(j);
           PackJob d{};
           d.w_off = L->off_w;
@@ -789,6 +790,7 @@ struct mimo_plan {
           d.kind = L->dg_split ? (f16 ? 1 : 2) : 0;
           d.dst = L->dg_split ? L->wd16 : (void*)L->wd;
           d.total = L->dg_split ? ceil_div(d.cols, 32) * 9 * d.rows_pad * 32 : 9 * d.rows_pad * d.cols;
+          d.pair = L->dg_split ? conv3x3_pair_tail(dgrad_mode(), L->cout_p, L->H + 2, L->W + 2) : 0;
           dg.push_back(d);
         }
       n_fwd_jobs = (int)jobs.size();
@@ -943,6 +945,7 @@ struct mimo_plan {
     int rows = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
     a.wpk = L.wf16;
+    a.pair = L.fwd_split ? conv3x3_pair_tail(fwd_mode(), L.cin_p, L.H, L.W) : 0;
     int pr = prof_begin(MIMO_PROF_CONV_FWD, st);
     if (L.fwd_split)
       MIMO_TRY(conv3x3_bf16x3_launch(a, fwd_mode(), &rows, st));
@@ -1309,6 +1312,7 @@ struct mimo_plan {
       a.cout_store = L.cin_p;
       a.off = 2;
       a.wpk = L.wd16;
+      a.pair = L.dg_split ? conv3x3_pair_tail(dgrad_mode(), L.cout_p, L.H + 2, L.W + 2) : 0;
       pr = prof_begin(MIMO_PROF_CONV_DGRAD, st);
       if (L.dg_split)
         MIMO_TRY(conv3x3_bf16x3_launch(a, dgrad_mode(), nullptr, st));
