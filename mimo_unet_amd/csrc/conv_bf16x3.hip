@@ -412,7 +412,13 @@ constexpr int kWsMaxMF = 4;
 // pixel one tile row further down at slots 0-1 — a per-lane constant, so the fragment addresses keep the form
 // (lane base) + (scalar of the phase) + (immediate of the step), and phases keep their three steps, so the
 // alternation of the two B register sets is the same compile-time pattern as without pairing.
-template <int NF, int MODE, bool SWZ, int MF_, bool PAIR = false>
+//
+// WDMA: the weights of a phase go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write) into
+// the buffer the consumers released at the last barrier, one phase ahead; the producers wait for them with a counted
+// vmcnt that leaves their own (younger) input-tile loads in flight, then pass a raw s_barrier.  A DMA instruction
+// writes 64 x 16 contiguous bytes, so the weight rows are unpadded 128-byte rows with the slot index XORed by
+// (row & 7) (conflict-free ds_read_b128, as SWZ); the XOR is applied to the per-lane SOURCE address.
+template <int NF, int MODE, bool SWZ, int MF_, bool PAIR = false, bool WDMA = !SWZ>
 __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC,
                                                                                           int tilesY, int tilesX,
                                                                                           int numTiles, int xcd_order,
@@ -439,7 +445,9 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   // read group hit 16 distinct (row parity, slot) pairs = all 64 banks); else 144-byte padded rows, which
   // are 2-way conflicting on that read (~46 % of the LDS cycles, profiles/r01/final/pmc_SQ_INSTS_LDS.csv).
   constexpr int PITCH = SWZ ? 128 : kPitchB;
-  constexpr int XBYTES = kWsMaxPix * PITCH, WROWB = 3 * NB * PITCH;
+  constexpr bool WSWZ = SWZ || WDMA;               // weight rows: swizzled 128-byte rows
+  constexpr int WPITCH = WSWZ ? 128 : kPitchB;
+  constexpr int XBYTES = kWsMaxPix * PITCH, WROWB = 3 * NB * WPITCH;
   __shared__ __attribute__((aligned(128))) unsigned char xs[2 * XBYTES];
   __shared__ __attribute__((aligned(128))) unsigned char ws[2 * WROWB];
 
@@ -453,6 +461,14 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   // coTiles workgroups that read the SAME input tiles sit on one XCD and fetch them from HBM once (measured
   // before: 11 x re-read of the input on the 480-channel layers, one per channel tile), and an XCD owns
   // gx / 8 CONSECUTIVE columns — vertically adjacent tile rows, whose halo rows they share.
+#ifdef MIMO_CONV_ABLATE
+  // timing-only builds (-DMIMO_CONV_ABLATE=bits, results are wrong; WDMA instances only): 1 = producers skip the
+  // input-tile loads, 2 = the input-tile LDS stores, 4 = the weight staging; 8 = consumers skip the MFMAs, 16 = the
+  // fragment reads
+  constexpr int abl = MIMO_CONV_ABLATE;
+#else
+  constexpr int abl = 0;
+#endif
   const int v_ = xcd_order ? xcd_virtual_index((int)blockIdx.x, gx * coTiles) : (int)blockIdx.x;
   const int vbx = v_ / coTiles;
   const int co0 = (v_ - vbx * coTiles) * NB;
@@ -463,7 +479,14 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     // =============================== producers ===============================
     const int ptid = tid - 256;
     f32x4 xreg[XU];
-    u32x4 wreg[3][WU];
+    u32x4 wreg[WDMA ? 1 : 3][WDMA ? 1 : WU];
+    // WDMA: 16-byte unit (u & 7) ^ (row & 7) of weight row u >> 3 of the phase lands at LDS unit u = ptid + 256 k
+    int wsrc[WU];
+#pragma unroll
+    for (int k = 0; k < WU; ++k) {
+      const int u = min(ptid + k * 256, WUNITS - 1), row = u >> 3;
+      wsrc[k] = ((row / NB) * a.cout_pad + row % NB) * 8 + ((u & 7) ^ (row & 7));
+    }
     // halo-tile coordinates of this thread's units (tile-shape constants): (row << 16) | column, and the byte
     // offset of the unit from the tile's first halo pixel for tiles whose halo lies inside the image
     int u_rc[XU], u_off[XU];
@@ -574,18 +597,44 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
       const int t_ = u_ / (NB * 8);                                                                  \
       const int rem_ = u_ - t_ * (NB * 8);                                                           \
       const int wrow_ = t_ * NB + (rem_ >> 3);                                                       \
-      *reinterpret_cast<u32x4*>(ws + (BUF) * WROWB + wrow_ * PITCH + (((rem_ & 7) ^ (SWZ ? (wrow_ & 7) : 0)) << 4)) = wreg[SLOT][k_]; \
+      *reinterpret_cast<u32x4*>(ws + (BUF) * WROWB + wrow_ * WPITCH + (((rem_ & 7) ^ (WSWZ ? (wrow_ & 7) : 0)) << 4)) = wreg[SLOT][k_]; \
     }                                                                                                \
   }
+    // WDMA: weights of phase PH straight into weight buffer BUF (wave-uniform LDS base + lane * 16)
+#define WS_DMA_W(BUF, PH)                                                                            \
+  {                                                                                                  \
+    const int phw_ = (PH);                                                                           \
+    const int ck_ = (phw_ / 3) % nchunks, r_ = phw_ % 3;                                             \
+    const u32x4* src_ = wpk + ((size_t)(ck_ * 9 + r_ * 3) * a.cout_pad + co0) * 8;                   \
+    _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                              \
+      if (ptid + k_ * 256 < WUNITS) { /* a multiple of 128 units: whole waves */                     \
+        __builtin_amdgcn_global_load_lds(                                                            \
+            (const __attribute__((address_space(1))) void*)(src_ + wsrc[k_]),                        \
+            (__attribute__((address_space(3))) void*)(ws + (BUF) * WROWB + (k_ * 256 + (ptid & ~63)) * 16), 16, 0, 0); \
+      }                                                                                              \
+    }                                                                                                \
+  }
+    // all vector-memory operations but the N youngest (this phase's input loads) are done: the DMA'd weights are in LDS
+#define WS_DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
     const int nphases = 3 * nstages;
     WS_LOAD_X(0, XU, 0)  // nstages >= 1: the grid never exceeds the tile count
-    WS_LOAD_W(0, 0)
-    WS_LOAD_W(1, 1)
-    WS_LOAD_W(2, 2)
+    if (WDMA) {
+      WS_DMA_W(0, 0)
+    } else {
+      WS_LOAD_W(0, 0)
+      WS_LOAD_W(1, 1)
+      WS_LOAD_W(2, 2)
+    }
     WS_STORE_X(0, XU, 0)
-    WS_STORE_W(0, 0)
+    if (!WDMA) {
+      WS_STORE_W(0, 0)
+    }
     WS_LOAD_X(0, XU, min(1, nstages - 1))
-    __syncthreads();  // phase 0 is staged
+    if (WDMA) {
+      WS_DMA_WAIT(XU)
+    } else {
+      __syncthreads();  // phase 0 is staged
+    }
     // during phase (j, r): store W(phase + 1) and part r of input stage j + 1 into the buffers the
     // consumers released at the last barrier; then refill those registers two / three phases ahead
     for (int j = 0; j < nstages; ++j) {
@@ -596,11 +645,26 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
        buffers nobody reads any more -- straight-line code lets the compiler keep exact vmcnt counts \
        (a conditional load forces a full drain at the join and collapses the prefetch depth) */      \
     const int ph_ = 3 * j + (R);                                                                     \
-    WS_STORE_W(((R) + 1) % 3, (ph_ + 1) & 1)                                                         \
-    WS_LOAD_W((R), min(ph_ + 3, nphases - 1))                                                        \
-    WS_STORE_X((R) * XP, ((R) + 1) * XP, xb)                                                         \
-    WS_LOAD_X((R) * XP, ((R) + 1) * XP, min(j + 2, nstages - 1))                                     \
-    __syncthreads();                                                                                 \
+    if (WDMA) {                                                                                      \
+      if (!(abl & 2)) {                                                                              \
+        WS_STORE_X((R) * XP, ((R) + 1) * XP, xb)                                                     \
+      }                                                                                              \
+      if (!(abl & 4)) {                                                                              \
+        WS_DMA_W((ph_ + 1) & 1, min(ph_ + 1, nphases - 1))                                           \
+      }                                                                                              \
+      if (!(abl & 1)) {                                                                              \
+        WS_LOAD_X((R) * XP, ((R) + 1) * XP, min(j + 2, nstages - 1))                                 \
+        WS_DMA_WAIT(XP)                                                                              \
+      } else {                                                                                       \
+        WS_DMA_WAIT(0)                                                                               \
+      }                                                                                              \
+    } else {                                                                                         \
+      WS_STORE_W(((R) + 1) % 3, (ph_ + 1) & 1)                                                       \
+      WS_LOAD_W((R), min(ph_ + 3, nphases - 1))                                                      \
+      WS_STORE_X((R) * XP, ((R) + 1) * XP, xb)                                                       \
+      WS_LOAD_X((R) * XP, ((R) + 1) * XP, min(j + 2, nstages - 1))                                   \
+      __syncthreads();                                                                               \
+    }                                                                                                \
   }
       WS_PHASE(0)
       WS_PHASE(1)
@@ -611,6 +675,8 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #undef WS_STORE_X
 #undef WS_LOAD_W
 #undef WS_STORE_W
+#undef WS_DMA_W
+#undef WS_DMA_WAIT
     if (FWD && a.stats) __syncthreads();  // the consumers combine their BatchNorm sums through LDS (see the end)
     return;
   }
@@ -635,8 +701,8 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   // phases of a paired chunk (see the kernel comment); second phase: K groups 2-3 meet zero weights and re-read slots
   // 0-1 of their own row (any finite data)
   const int pair_d = g >= 2 ? TCP * PITCH - 32 : 0, pair_d2 = g >= 2 ? -32 : 0;
-  const int wbase = SWZ ? lr * PITCH + ((g ^ (lr & 7)) << 4) : lr * PITCH + g * 16;
-  const int wlo = SWZ ? ((wbase ^ 64) - wbase) : 64;
+  const int wbase = WSWZ ? lr * WPITCH + ((g ^ (lr & 7)) << 4) : lr * WPITCH + g * 16;
+  const int wlo = WSWZ ? ((wbase ^ 64) - wbase) : 64;
   // Accumulators are kept TRANSPOSED (MFMA called with the weight fragment as A and the pixel fragment as B):
   // lane (lr, g) of fragment (m, nf) holds pixel lr of the fragment and output channels nf*16 + g*4 .. +3, so the
   // epilogue issues one 16-byte store per fragment and one pixel-address computation per m — the
@@ -678,14 +744,14 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   bf16x8 ah[2], al[2], bh[2][NF], bl[2][NF];
 
 #define C_READ_B(BS, KW)                                                                             \
-  _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
-    bh[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * PITCH);              \
-    if (NP == 3) bl[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * PITCH + wlo); \
+  if (!(abl & 16)) _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
+    bh[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * WPITCH);             \
+    if (NP == 3) bl[BS][nf] = *reinterpret_cast<const bf16x8*>(wb_ + ((KW) * NB + nf * 16) * WPITCH + wlo); \
   }
   // ro_: tile row of the phase's taps (r_; phases of a paired chunk: 0 and 2); pd_: the per-lane constant of a paired
   // chunk's phases (first: K groups 2-3 read one tile row down, slots 0-1), else 0
 #define C_READ_A(AS, KW, M)                                                                     \
-  {                                                                                                  \
+  if (!(abl & 16)) {                                                                                                  \
     if (SWZ) {                                                                                       \
       const int row_ = pbase[M] + ro_ * TCP + (KW);                                                   \
       const int o_ = row_ * PITCH + ((g ^ (row_ & 7)) << 4);                                         \
@@ -698,7 +764,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     }                                                                                                \
   }
 #define C_MFMA(AS, BS, M)                                                                            \
-  _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
+  if (!(abl & 8)) _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
     if (NP == 3) {                                                                                   \
       acc[M][nf] = mfma16(bh[BS][nf], al[AS], acc[M][nf]);                                           \
       acc[M][nf] = mfma16(bl[BS][nf], ah[AS], acc[M][nf]);                                           \
@@ -908,7 +974,10 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   // conflict-free swizzled rows measured the same step time as the padded rows (6.97 / 7.20 vs 6.89 / 7.20 ms
   // forward / data gradient per step): the LDS array is not what the consumers wait for.  Opt-in.
   static const bool swz = getenv("MIMO_CONV_WS_SWIZZLE") && atoi(getenv("MIMO_CONV_WS_SWIZZLE")) != 0;
-  static const int xcd = !(getenv("MIMO_CONV_XCD_ORDER") && atoi(getenv("MIMO_CONV_XCD_ORDER")) == 0);
+  static const int xcd_ = !(getenv("MIMO_CONV_XCD_ORDER") && atoi(getenv("MIMO_CONV_XCD_ORDER")) == 0);
+  // MIMO_CONV_WDMA=0: weights staged through registers (ds_write) as before
+  static const bool wdma = !(getenv("MIMO_CONV_WDMA") && atoi(getenv("MIMO_CONV_WDMA")) == 0);
+  const int xcd = xcd_;
   if (a.pair) {
     if constexpr (MODE <= 1) {
       if (swz || a.pair != conv3x3_pair_tail(MODE, a.cin_p, a.Ho, a.Wo)) {
@@ -922,8 +991,10 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
     }
   } else if (swz)
     hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, true, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
-  else
+  else if (wdma)
     hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
+  else
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false, MF, false, false>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
