@@ -10,7 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 export MIMO_WGRAD_STREAM=0
 for V in "$A" "$B"; do
   export $VAR=$V
-  rocprofv3 --kernel-trace -d "$OUT/trace_$V" -o t --output-format csv -- python3 "$R/bench.py" --steps 3 --warmup 2 --profile-steps 0 --no-cpu-baseline > "$OUT/bench_$V.json" 2> "$OUT/trace_$V.err"
-  python3 "$R/scripts/trace_convs.py" "$OUT/trace_$V" > "$OUT/conv_layers_$V.txt" 2>&1
-  rm -rf "$OUT/trace_$V"
+  L=$(basename "$V" .so)  # label of the setting in the file names (values may be paths: MIMO_HIP_LIB)
+  rocprofv3 --kernel-trace -d "$OUT/trace_$L" -o t --output-format csv -- python3 "$R/bench.py" --steps 3 --warmup 2 --profile-steps 0 --no-cpu-baseline > "$OUT/bench_$L.json" 2> "$OUT/trace_$L.err"
+  python3 "$R/scripts/trace_convs.py" "$OUT/trace_$L" > "$OUT/conv_layers_$L.txt" 2>&1
+  rm -rf "$OUT/trace_$L"
 done
