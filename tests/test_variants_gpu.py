@@ -24,6 +24,8 @@ VARIANTS = {
     "skip_grad_copy": {"MIMO_SKIP_GRAD_IN_PLACE": "0"},  # skip-connection gradients copied out by fold_slice
     "pool_fused_off": {"MIMO_POOL_FUSED": "0"},         # separate MaxPool2d pass after BatchNorm + ReLU
     "conv_ws_mf2_off": {"MIMO_CONV_WS_MF2": "0"},       # thin forward layers on 256-pixel tiles, one workgroup per CU
+    "conv_wdma_off": {"MIMO_CONV_WDMA": "0"},           # convolution weights staged through registers, not by LDS-DMA
+    "conv_pair_tail_off": {"MIMO_CONV_PAIR_TAIL": "0"},  # short last K chunks with one tap per MFMA
 }
 
 
