@@ -153,6 +153,19 @@ typedef struct mimo_forward_args {
  * replay through drop_masks / elem_masks): site < num_double_convs -> [N][Cout]; num_double_convs + j -> the
  * element-wise site j (0 = center, 1 + s = final s) in the reference's layout [N][C][H'][W']. */
 int mimo_plan_dropout_mask(mimo_plan* plan, int site, float* dst, mimo_stream stream);
+
+/* Numerics status of the plan's kernels since the last clear — the reference has no counterpart (torch raises
+ * nothing either; a diverged or out-of-range run shows as NaN losses): the default split16 forward carries
+ * activations as fp16 (hi, lo) pairs and weights as fp16 pairs x 2^8, so |activation| >= 65520 or |weight| >= 256
+ * overflows where the reference's fp32 path (mimo/models/mimo_components/components.py:23-29) does not.
+ * Bits of *flags: MIMO_STATUS_FWD_STATS — a BatchNorm batch statistic of a training forward was not finite;
+ * MIMO_STATUS_BWD_STATS — a BatchNorm-backward sum was not finite; MIMO_STATUS_LOGITS — a logit was not finite.
+ * The kernels record them for free (one test per finalized channel sum / logit); this call copies the word to the
+ * host and is the one plan call that synchronises `stream`.  clear != 0 resets the word. */
+#define MIMO_STATUS_FWD_STATS 1
+#define MIMO_STATUS_BWD_STATS 2
+#define MIMO_STATUS_LOGITS 4
+int mimo_plan_status(mimo_plan* plan, int32_t* flags, int32_t clear, mimo_stream stream);
 int mimo_plan_num_double_convs(const mimo_plan* plan);
 int mimo_plan_double_conv_channels(const mimo_plan* plan, int index); /* Cout of DoubleConv #index */
 int mimo_forward(mimo_plan* plan, const mimo_forward_args* args, mimo_stream stream);

@@ -71,6 +71,7 @@ struct ConvLaunch {
   const float* ep_shift = nullptr;
   const float* ep_mask = nullptr;
   int ep_mask_ld = 0;
+  int* status = nullptr;  // with ep_scale: bit 0 is OR-ed in when a convolution output is not finite (the ReLU would drop a NaN)
   int pair = 0;  // split kernel: a.wpk holds the tap-paired image of the last chunk (conv3x3_pair_tail)
 };
 // returns number of partial-stat rows (spatial blocks) through *rows when stats != nullptr

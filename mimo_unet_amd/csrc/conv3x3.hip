@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvLaunch a, int TR,
 #pragma unroll
         for (int nf = 0; nf < NFRAG; ++nf) {
           float v = acc[m][nf][r4] + bv[nf];
-          if (a.ep_scale) v = fmaxf(fmaf(v, esc[nf], esh[nf]), 0.f) * emk[nf];
+          if (a.ep_scale) {
+            if (a.status && !isfinite(v)) atomicOr(a.status, 1);  // the ReLU below would drop a NaN
+            v = fmaxf(fmaf(v, esc[nf], esh[nf]), 0.f) * emk[nf];
+          }
           if (co0 + nf * 16 + lr < a.cout_store) yp[nf * 16] = v;
           s1[nf] += v;
           s2[nf] += v * v;

@@ -337,7 +337,10 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
           float v = acc[m][nf][r4] * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];
-          if (a.ep_scale) v = fmaxf(fmaf(v, esc[nf], esh[nf]), 0.f) * emk[nf];
+          if (a.ep_scale) {
+            if (a.status && !isfinite(v)) atomicOr(a.status, 1);  // the ReLU below would drop a NaN
+            v = fmaxf(fmaf(v, esc[nf], esh[nf]), 0.f) * emk[nf];
+          }
           if (co0 + nf * 16 + lr < a.cout_store) yp[nf * 16] = (OT)v;
           s1[nf] += v;
           s2[nf] += v * v;
@@ -829,6 +832,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
           if (FWD) v = v + bv[nf];                                                                   \
           const int c_ = co0 + nf * 16 + g * 4;                                                      \
           if (FWD && a.ep_scale) {                                                                   \
+            if (a.status && !(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]))) atomicOr(a.status, 1); \
             const f32x4 esc_ = *reinterpret_cast<const f32x4*>(a.ep_scale + c_);                     \
             const f32x4 esh_ = *reinterpret_cast<const f32x4*>(a.ep_shift + c_);                     \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                       \

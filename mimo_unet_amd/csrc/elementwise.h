@@ -25,7 +25,10 @@ constexpr int kColsumMaxGroups = 256;
 struct ColsumScratch {
   double* sums;
   int* tickets;
+  int* status = nullptr;  // numerics status word of the plan (mimo_plan_status): OR-ed when a finalized sum is not finite
 };
+// bits of the status word
+constexpr int kStatusFwdStats = 1, kStatusBwdStats = 2, kStatusLogits = 4;
 int colsum_vec_launch(const float* partial, int rows, int cols, int C, float* out, const ColsumScratch& cs, hipStream_t st);
 int bn_fwd_stats_launch(const float* partial, int rows, int cout_pad, int C, int Cp, int64_t count, const float* gamma,
                         const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
@@ -52,12 +55,14 @@ int bn_eval_prepare_launch(int C, int Cp, const float* gamma, const float* beta,
                            const float* running_var, float eps, float* mean, float* invstd, float* scale,
                            float* shift, hipStream_t st);
 // a = relu(z*scale+shift) * mask[n][c]
+// status != nullptr (eval mode): kStatusFwdStats is OR-ed into it when an input element is not finite (fmaxf would drop it)
 int bn_relu_fwd_launch(const void* z, int dtz, int ldz, void* a, int dta, int lda, const float* scale, const float* shift,
-                       const float* mask, int C, int Cp, int64_t P, int HW, hipStream_t st);
+                       const float* mask, int C, int Cp, int64_t P, int HW, hipStream_t st, int* status = nullptr);
 
 // same, for a tensor that feeds MaxPool2d(2): also writes pool[N,H/2,W/2] = maxpool2x2(a) (one pass, 2x2 window per thread)
 int bn_relu_pool_fwd_launch(const void* z, int dtz, int ldz, void* a, int dta, int lda, const float* scale, const float* shift,
-                            const float* mask, int C, int Cp, int N, int H, int W, void* pool, int ldpool, hipStream_t st);
+                            const float* mask, int C, int Cp, int N, int H, int W, void* pool, int ldpool, hipStream_t st,
+                            int* status = nullptr);
 
 // ---- pooling / upsampling ---------------------------------------------------------------
 int maxpool_fwd_launch(const void* a, int dt, int lda, int N, int H, int W, int Cp, void* out, int ldo, hipStream_t st);
@@ -125,8 +130,9 @@ int vec_finalize_launch(const double* sums, int chunks, int cols, int C, float* 
 
 // ---- 1x1 head + loss ------------------------------------------------------------------------
 // out[n][s][co][yx] = bias[co] + sum_c a[n,yx,c] * w[co][c]      (components.py:126)
+// status != nullptr: kStatusLogits is OR-ed into it when a logit is not finite
 int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float* bias, int C, int Co, int N, int S, int s,
-                    int HW, float* out, hipStream_t st);
+                    int HW, float* out, hipStream_t st, int* status = nullptr);
 // per-subnetwork sum of the un-reduced NLL (losses.py:151-160) -> partial [S][blocks]
 int loss_fwd_launch(const float* out, const float* label, const float* mask, const int64_t* perm, int N, int S,
                     int Co, int HW, int kind, float eps_min, float eps_max, float* partial, int* blocks,

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kColsumThreads) void bn_fwd_stats_kernel(
     const float* __restrict__ partial, int rows, int cout_pad, int C, int Cp, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
     float eps, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
-    double* __restrict__ scratch, int scratch_cols, int* __restrict__ tickets) {
+    double* __restrict__ scratch, int scratch_cols, int* __restrict__ tickets, int* __restrict__ status) {
   __shared__ double red[2048];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s1, s2;
@@ -470,6 +470,9 @@ __global__ __launch_bounds__(kColsumThreads) void bn_fwd_stats_kernel(
     shift[c] = 0.f;
     return;
   }
+  // a convolution output that is not finite (an input / weight outside the fp16 range of the split forward, a
+  // diverged run) shows in its channel sums: recorded for mimo_plan_status instead of surfacing only as NaNs downstream
+  if (status && !(isfinite(s1) && isfinite(s2))) atomicOr(status, kStatusFwdStats);
   const double m = s1 / count;
   double var = s2 / count - m * m;
   var = var > 0.0 ? var : 0.0;
@@ -490,7 +493,7 @@ int bn_fwd_stats_launch(const float* partial, int rows, int cout_pad, int C, int
   const int groups = ceil_div(Cp, 64);
   hipLaunchKernelGGL(bn_fwd_stats_kernel, dim3(groups, colsum_chunks(rows)), dim3(kColsumThreads), 0, st, partial, rows,
                      cout_pad, C, Cp, (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
-                     shift, cs.sums, groups * 64, cs.tickets);
+                     shift, cs.sums, groups * 64, cs.tickets, cs.status);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -549,12 +552,15 @@ __device__ __forceinline__ float4 mask4(const float* mask, int n, int C, int c0)
 template <typename TZ, typename TA>
 __global__ void bn_relu_fwd_kernel(const TZ* __restrict__ z, int ldz, TA* __restrict__ a, int lda,
                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                   const float* __restrict__ mask, int C, int Cv, int P, int HW) {
+                                   const float* __restrict__ mask, int C, int Cv, int P, int HW, int* __restrict__ status) {
   const PQ t = pixquad(Cv);
   if (!t.active) return;
   const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q);
   for (int p = t.p; p < P; p += t.pstep) {
     const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
+    // eval mode (status != nullptr; a training forward sees it in the batch statistics): fmaxf drops a NaN, so a
+    // convolution output that is not finite would otherwise vanish here as a silently dead channel
+    if (status && !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w))) atomicOr(status, kStatusFwdStats);
     float4 r;
     r.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
     r.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
@@ -572,11 +578,11 @@ __global__ void bn_relu_fwd_kernel(const TZ* __restrict__ z, int ldz, TA* __rest
 }
 
 int bn_relu_fwd_launch(const void* z, int dtz, int ldz, void* a, int dta, int lda, const float* scale, const float* shift,
-                       const float* mask, int C, int Cp, int64_t P, int HW, hipStream_t st) {
+                       const float* mask, int C, int Cp, int64_t P, int HW, hipStream_t st, int* status) {
   const int Cv = Cp / 4;
   MIMO_ST_DISPATCH2(dtz, dta, TZ, TA,
                     hipLaunchKernelGGL((bn_relu_fwd_kernel<TZ, TA>), pq_grid(Cv, P, kBlocksBnRelu), dim3(256), 0, st,
-                                       (const TZ*)z, ldz, (TA*)a, lda, scale, shift, mask, C, Cv, (int)P, HW))
+                                       (const TZ*)z, ldz, (TA*)a, lda, scale, shift, mask, C, Cv, (int)P, HW, status))
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -588,13 +594,14 @@ template <typename TZ, typename TA>
 __global__ void bn_relu_pool_fwd_kernel(const TZ* __restrict__ z, int ldz, TA* __restrict__ a, int lda,
                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                         const float* __restrict__ mask, int C, int Cv, int N, int H, int W,
-                                        TA* __restrict__ pool, int ldpool) {
+                                        TA* __restrict__ pool, int ldpool, int* __restrict__ status) {
   const PQ t = pixquad(Cv);
   if (!t.active) return;
   const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q);
   const int Hp = H / 2, Wp = W / 2;
   const int P = N * Hp * Wp;
   auto act = [&](float4 v, float4 m) {
+    if (status && !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w))) atomicOr(status, kStatusFwdStats);  // as bn_relu_fwd_kernel
     float4 r;
     r.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f) * m.x;
     r.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f) * m.y;
@@ -631,12 +638,13 @@ __global__ void bn_relu_pool_fwd_kernel(const TZ* __restrict__ z, int ldz, TA* _
 }
 
 int bn_relu_pool_fwd_launch(const void* z, int dtz, int ldz, void* a, int dta, int lda, const float* scale, const float* shift,
-                            const float* mask, int C, int Cp, int N, int H, int W, void* pool, int ldpool, hipStream_t st) {
+                            const float* mask, int C, int Cp, int N, int H, int W, void* pool, int ldpool, hipStream_t st,
+                            int* status) {
   const int Cv = Cp / 4;
   MIMO_ST_DISPATCH2(dtz, dta, TZ, TA,
                     hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<TZ, TA>), pq_grid(Cv, (int64_t)N * (H / 2) * (W / 2), 4096),
                                        dim3(256), 0, st, (const TZ*)z, ldz, (TA*)a, lda, scale, shift, mask, C, Cv, N, H, W,
-                                       (TA*)pool, ldpool))
+                                       (TA*)pool, ldpool, status))
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1167,12 +1175,13 @@ __global__ __launch_bounds__(kColsumThreads) void bn_bwd_stats_kernel(const floa
                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                       float* __restrict__ dbias_zero,
                                                                       double* __restrict__ scratch, int scratch_cols,
-                                                                      int* __restrict__ tickets) {
+                                                                      int* __restrict__ tickets, int* __restrict__ status) {
   __shared__ double red[2048];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s1, s2;
   if (!grid_colsum2(partial, rows, (size_t)2 * Cp, c, Cp + c, c < Cp, true, red, scratch, scratch_cols, tickets, &s1, &s2)) return;
   if (c >= Cp || threadIdx.x >= 64) return;
+  if (status && c < C && !(isfinite(s1) && isfinite(s2))) atomicOr(status, kStatusBwdStats);
   c1[c] = training ? (float)(s1 / count) : 0.f;
   c2[c] = training ? (float)(s2 / count) : 0.f;
   if (c < C) {
@@ -1188,7 +1197,7 @@ int bn_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int64_t c
                         float* dgamma, float* dbeta, float* dbias_zero, const ColsumScratch& cs, hipStream_t st) {
   const int groups = ceil_div(Cp, 64);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(groups, colsum_chunks(rows)), dim3(kColsumThreads), 0, st, partial, rows, C, Cp,
-                     (double)count, training, c1, c2, dgamma, dbeta, dbias_zero, cs.sums, groups * 64, cs.tickets);
+                     (double)count, training, c1, c2, dgamma, dbeta, dbias_zero, cs.sums, groups * 64, cs.tickets, cs.status);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1300,7 +1309,7 @@ int bn_bwd_apply_launch(const void* da, int dta, int ldda, const void* dxpad, in
 template <int G, int CO, typename T>
 __global__ void head_fwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
                                 const float* __restrict__ bias, int C, int Cp, int Co, int N, int S, int s, int HW,
-                                float* __restrict__ out) {
+                                float* __restrict__ out, int* __restrict__ status) {
   // CO = compile-time bound of Co (2: one target, 4: the evidential head, 8: the rest); UN pixels per thread and
   // iteration, their loads issued together (one 16-byte load in flight per thread ran at 3.4 TB/s)
   const int g = threadIdx.x % G, pl = threadIdx.x / G;
@@ -1337,14 +1346,18 @@ __global__ void head_fwd_kernel(const T* __restrict__ a, int lda, const float* _
         const int yx = (int)(p - (int64_t)n * HW);
 #pragma unroll
         for (int co = 0; co < CO; ++co)
-          if (co < Co && co % G == g) out[(((int64_t)n * S + s) * Co + co) * HW + yx] = acc[co] + bs[co];
+          if (co < Co && co % G == g) {
+            const float o = acc[co] + bs[co];
+            out[(((int64_t)n * S + s) * Co + co) * HW + yx] = o;
+            if (status && !isfinite(o)) atomicOr(status, kStatusLogits);
+          }
       }
     }
   }
 }
 
 int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float* bias, int C, int Co, int N, int S, int s,
-                    int HW, float* out, hipStream_t st) {
+                    int HW, float* out, hipStream_t st, int* status) {
   if (Co > kMaxHeadOut || C > 256) {
     set_error("head: out_channels %d > %d or filter_base_count %d > 256 unsupported", Co, kMaxHeadOut, C);
     return MIMO_ERR_INVALID;
@@ -1356,7 +1369,7 @@ int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float*
   const int blocks = (int)std::min<int64_t>(ceil_div64(P, (256 / G) * 4), 4096);
 #define HEAD_LAUNCH2(GG, CC)                                                                                         \
   MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL((head_fwd_kernel<GG, CC, T>), dim3(blocks), dim3(256), 0, st, (const T*)a, lda, w, bias, \
-                                             C, Cp, Co, N, S, s, HW, out))
+                                             C, Cp, Co, N, S, s, HW, out, status))
 #define HEAD_LAUNCH(GG)             \
   if (Co <= 2) {                    \
     HEAD_LAUNCH2(GG, 2);            \

@@ -165,7 +165,8 @@ struct mimo_plan {
     int reduce_count = 0, reduce_blocks = 0;
   };
   StageReduce stage_reduce_tab[8];
-  ColsumScratch colsum() const { return ColsumScratch{s_sums, s_tickets}; }
+  ColsumScratch colsum() const { return ColsumScratch{s_sums, s_tickets, d_status}; }
+  int* d_status = nullptr;  // numerics status word (mimo_plan_status)
   size_t cap_act = 0, cap_pad = 0, cap_slab = 0, cap_partial = 0, cap_sums = 0;
 
   // MIMO_WGRAD_STREAM (default 1): weight gradients on a side stream — wgrad(L) (matrix-pipe bound, little HBM
@@ -754,6 +755,7 @@ struct mimo_plan {
       }
     }
     MIMO_TRY(dalloc(&s_losspart, (size_t)S * 512));
+    MIMO_TRY(dalloc(&d_status, 1));
     // ---- weight repack job tables ----
     {
       std::vector<PackJob> jobs, dg;
@@ -929,6 +931,7 @@ struct mimo_plan {
       a.ep_shift = L.shift;
       a.ep_mask = mask;
       a.ep_mask_ld = L.Cout;
+      a.status = d_status;
     }
     a.w = L.wf;
     a.bias = L.bias_p;
@@ -969,10 +972,10 @@ struct mimo_plan {
       pr = prof_begin(MIMO_PROF_BN_RELU_FWD, st);
       if (L.pool_out)
         MIMO_TRY(bn_relu_pool_fwd_launch(L.z, L.dtz, L.cout_p, L.a, this->st, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, L.N,
-                                         L.H, L.W, L.pool_out, L.pool_ld, st));
+                                         L.H, L.W, L.pool_out, L.pool_ld, st, training ? nullptr : d_status));
       else
         MIMO_TRY(bn_relu_fwd_launch(L.z, L.dtz, L.cout_p, L.a, this->st, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, P,
-                                    L.H * L.W, st));
+                                    L.H * L.W, st, training ? nullptr : d_status));
       prof_end(pr, 0.0, (L.pool_out ? 9.0 : 8.0) * (double)P * L.cout_p, st);
     }
     return MIMO_OK;
@@ -1206,7 +1209,7 @@ struct mimo_plan {
       const int blk = prof_begin(kProfTierBase, st);
       const int pr = prof_begin(MIMO_PROF_HEAD_FWD, st);
       MIMO_TRY(head_fwd_launch(o.a, this->st, o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co, N, S, s, H * W,
-                               args->out, st));
+                               args->out, st, d_status));
       prof_end(pr, 0.0, 4.0 * (double)N * H * W * (pad_channels(f) + Co), st);
       prof_end(blk, 0.0, 0.0, st);
     }
@@ -1638,6 +1641,20 @@ int mimo_plan_bind(mimo_plan* plan, float* params, float* grads, float* bn_buffe
   plan->params = params;
   plan->grads = grads;
   plan->bnbuf = bn_buffers;
+  return MIMO_OK;
+}
+
+int mimo_plan_status(mimo_plan* plan, int32_t* flags, int32_t clear, mimo_stream stream) {
+  if (!plan || !flags) {
+    set_error("mimo_plan_status: bad argument");
+    return MIMO_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int v = 0;
+  MIMO_HIP_CHECK(hipMemcpyAsync(&v, plan->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (clear) MIMO_HIP_CHECK(hipMemsetAsync(plan->d_status, 0, sizeof(int), st));
+  MIMO_HIP_CHECK(hipStreamSynchronize(st));
+  *flags = v;
   return MIMO_OK;
 }
 

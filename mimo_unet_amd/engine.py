@@ -152,6 +152,17 @@ class Plan:
                              int(x.shape[0]))
         L.check(self.lib.mimo_forward(self.handle, C.byref(args), L.current_stream()), "mimo_forward")
 
+    STATUS_BITS = {1: "a BatchNorm batch statistic of a training forward was not finite",
+                   2: "a BatchNorm-backward sum was not finite",
+                   4: "a logit was not finite"}
+
+    def status(self, clear: bool = True) -> int:
+        """Numerics status word of the plan's kernels since the last clear (mimo_plan_status; synchronises the
+        current stream).  0 = nothing recorded; bits: STATUS_BITS."""
+        flags = C.c_int32(0)
+        L.check(self.lib.mimo_plan_status(self.handle, C.byref(flags), 1 if clear else 0, L.current_stream()), "mimo_plan_status")
+        return int(flags.value)
+
     def dropout_mask(self, site: int) -> torch.Tensor:
         """Dropout multipliers of the last forward: site < num_double_convs -> [N, C]; num_double_convs + j -> the
         element-wise site j (0 center, 1 + s final s) as [N, C, H', W'] (only when the engine drew it)."""

@@ -91,6 +91,12 @@ class EvidentialUnetModel(LightningModule):
         return {"loss": loss.mean(), "label": label, "preds": y_pred, "aleatoric_std_map": aleatoric_std,
                 "epistemic_std_map": epistemic_std, "err_map": y_pred - label, "mask": mask}
 
+    def on_train_epoch_end(self) -> None:
+        self.model.check_numerics()  # see MimoUnetModel.on_train_epoch_end
+
+    def on_validation_epoch_end(self) -> None:
+        self.model.check_numerics()
+
     def configure_optimizers(self) -> Dict[str, Any]:
         if self.use_fused_optimizer:
             optimizer = FlatAdam(self.model, lr=self.learning_rate, weight_decay=self.weight_decay)

@@ -462,6 +462,32 @@ class MimoUNet(nn.Module):
             for b, e in plan.backward_stages:
                 hook(g, b, e)
 
+    def numerics_status(self, clear: bool = True) -> int:
+        """OR of the numerics status words of the live plans (`Plan.status`; one device synchronisation per plan).
+        Non-zero when a BatchNorm statistic, a BatchNorm-backward sum or a logit was not finite since the last
+        clear — a diverged run, or a value outside what the precision mode represents: the default "split16" forward
+        carries activations as fp16 (hi, lo) pairs and weights as fp16 pairs x 2^8, so |activation| >= 65520 or
+        |weight| >= 256 overflows there where the reference's fp32 path does not ("fp32" mode has fp32 range)."""
+        flags = 0
+        for plan in list(self._plans.values()):
+            flags |= plan.status(clear)
+        return flags
+
+    def check_numerics(self, clear: bool = True) -> None:
+        """Raise FloatingPointError with what was recorded (see `numerics_status`); cheap enough for once per epoch.
+        Under "16-mixed" a non-finite BACKWARD sum is the loss scaler's normal overflow probe (GradScaler skips that
+        step and halves the scale) and is not reported."""
+        flags = self.numerics_status(clear)
+        if self._geom.precision == "16-mixed":
+            flags &= ~2
+        if flags:
+            what = "; ".join(msg for bit, msg in Plan.STATUS_BITS.items() if flags & bit)
+            hint = ""
+            if self._geom.precision in ("split16", "16-mixed"):
+                hint = (f" (precision {self._geom.precision!r} carries fp16 operands: |activation| >= 65520 or |weight| >= 256 "
+                        "overflows; set_precision('fp32') or 'bf16-mixed' has fp32 exponent range)")
+            raise FloatingPointError(f"MimoUNet: {what}{hint}")
+
     def mark_parameters_changed(self) -> None:
         """Call after writing the flat parameter / buffer storage through a raw pointer."""
         self._param_epoch += 1

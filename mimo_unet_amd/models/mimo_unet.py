@@ -186,6 +186,14 @@ class MimoUnetModel(LightningModule):
         ident = torch.arange(n, device=image.device, dtype=torch.int64)[None].repeat(self.num_subnetworks, 1)
         return self.model.forward_with_loss(image, label, mask, ident)
 
+    # Lightning epoch-end hooks: one device synchronisation per epoch turns a diverged / out-of-range run into an
+    # error that says what happened (MimoUNet.check_numerics) instead of NaN losses scrolling by
+    def on_train_epoch_end(self) -> None:
+        self.model.check_numerics()
+
+    def on_validation_epoch_end(self) -> None:
+        self.model.check_numerics()
+
     def configure_optimizers(self) -> Dict[str, Any]:
         if self.use_fused_optimizer:
             optimizer = FlatAdam(self.model, lr=self.learning_rate, weight_decay=self.weight_decay)

@@ -880,3 +880,43 @@ def test_two_forwards_then_the_first_ones_backward():
     p1, p2 = model(xa)
     (p1.square().mean() + p2.mean()).backward()
     assert torch.equal(model.model.flat_gradients(), ref[0]) and len(model.model._plans) == n_plans + 1
+
+
+@pytest.mark.gpu
+def test_numerics_status_reports_an_fp16_range_overflow_instead_of_silent_nans():
+    """The default split16 forward carries fp16 (hi, lo) pairs: a weight >= 256 (x 2^8 = fp16 inf) poisons the output
+    where the reference's fp32 path does not.  The kernels record non-finite BatchNorm statistics / logits in the plan's
+    status word; `check_numerics` (called by the Lightning epoch-end hooks) turns it into an error that says so, the
+    fp32 mode runs the same weights cleanly, and the word is cleared by the read."""
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    model = build_model(cfg, state_from(fx, "init/"))
+    x = torch.rand(3, 2, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
+    lab = torch.rand(3, 1, 32, 32, generator=torch.Generator().manual_seed(4)).cuda()
+    model.train()
+    out = model.training_step({"image": x, "label": lab}, 0)
+    assert torch.isfinite(out["loss"]) and model.model.numerics_status() == 0
+    model.on_train_epoch_end()  # nothing recorded: no error
+    w = dict(model.model.named_parameters())["core.down2.conv.double_conv.0.weight"]
+    with torch.no_grad():
+        w[0, 0, 1, 1] = 300.0  # representable in fp32 and bf16, not as fp16 x 2^8
+    out = model.training_step({"image": x, "label": lab}, 0)
+    # the loss may well stay finite: training-mode BatchNorm turns the poisoned channel into NaNs and the ReLU's fmaxf
+    # drops them — a silently dead channel; the status word is what tells
+    assert model.model.numerics_status(clear=False) & 1
+    with pytest.raises(FloatingPointError, match="fp16"):
+        model.on_train_epoch_end()
+    assert model.model.numerics_status() == 0  # cleared by the check
+    model.eval()
+    x5 = x[:, None].repeat(1, 2, 1, 1, 1)
+    with torch.no_grad():
+        model(x5)  # inference plan: BatchNorm + ReLU folded into the convolution epilogue, which checks its input
+    assert model.model.numerics_status() & 1
+    model(x5)      # eval forward with autograd: the separate BatchNorm + ReLU pass checks
+    assert model.model.numerics_status() & 1
+    ref = build_model(cfg, state_from(fx, "init/"), precision="fp32")  # (a fresh loss buffer: the first model's holds a NaN)
+    with torch.no_grad():
+        dict(ref.model.named_parameters())["core.down2.conv.double_conv.0.weight"][0, 0, 1, 1] = 300.0
+    ref.train()
+    out = ref.training_step({"image": x, "label": lab}, 0)
+    assert torch.isfinite(out["loss"]) and ref.model.numerics_status() == 0
