@@ -55,6 +55,14 @@ __device__ __forceinline__ f32x4_ mfma16(Elem<true>::V8 a, Elem<true>::V8 b, f32
 }
 constexpr float kF16WeightScale = 256.f;  // 2^8, exact
 
+#ifdef MIMO_CONV_STAMPS
+// timing-only instrumentation (-DMIMO_CONV_STAMPS): per kernel role, shader-clock ticks summed over one wave of every
+// workgroup — [0] forward consumers: barrier wait, [1] their total, [2] forward producers: wait (DMA / barrier), [3]
+// their total, [4..7] the same for the data gradient
+__device__ unsigned long long g_conv_stamps[8];
+#define STAMP_NOW() __builtin_amdgcn_s_memtime()
+#endif
+
 // Kernel modes (template parameter MODE of the convolution kernels and launchers):
 //   0  split16 data gradient : bf16 (hi, lo) pairs, input pre-split (dz),       3 MFMAs per product
 //   1  split16 forward       : fp16 (hi, lo) pairs, fp32 input split on the way, 3 MFMAs per product
@@ -625,7 +633,18 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     }                                                                                                \
   }
     // all vector-memory operations but the N youngest (this phase's input loads) are done: the DMA'd weights are in LDS
+#ifdef MIMO_CONV_STAMPS
+    unsigned long long sp_wait = 0;
+    const unsigned long long sp_begin = STAMP_NOW();
+#define WS_DMA_WAIT(N)                                                                               \
+  {                                                                                                  \
+    const unsigned long long s0_ = STAMP_NOW();                                                      \
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");    \
+    sp_wait += STAMP_NOW() - s0_;                                                                    \
+  }
+#else
 #define WS_DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
     const int nphases = 3 * nstages;
     WS_LOAD_X(0, XU, 0)  // nstages >= 1: the grid never exceeds the tile count
     if (WDMA) {
@@ -687,11 +706,29 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #undef WS_STORE_W
 #undef WS_DMA_W
 #undef WS_DMA_WAIT
+#ifdef MIMO_CONV_STAMPS
+    if (ptid == 0) {
+      atomicAdd(&g_conv_stamps[(FWD ? 0 : 4) + 2], sp_wait);
+      atomicAdd(&g_conv_stamps[(FWD ? 0 : 4) + 3], STAMP_NOW() - sp_begin);
+    }
+#endif
     if (FWD && a.stats) __syncthreads();  // the consumers combine their BatchNorm sums through LDS (see the end)
     return;
   }
 
   // =============================== consumers ===============================
+#ifdef MIMO_CONV_STAMPS
+  unsigned long long st_wait = 0;
+  const unsigned long long st_begin = STAMP_NOW();
+#define STAMP_BAR_C                                  \
+  {                                                  \
+    const unsigned long long s0_ = STAMP_NOW();      \
+    __syncthreads();                                 \
+    st_wait += STAMP_NOW() - s0_;                    \
+  }
+#else
+#define STAMP_BAR_C __syncthreads();
+#endif
   // Software pipeline over taps: the 2*(MF+NF) fragment reads of tap t+1 are issued before the 3*MF*NF
   // MFMAs of tap t (two register sets; sched_group_barrier pins the order — left alone, the compiler
   // reads every fragment right before its first use and the lone MFMA wave of the SIMD eats the LDS
@@ -873,7 +910,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     const bool pc_ = PAIR && (j_ + 1) % nchunks == 0; /* phase of a paired chunk (r_ = 0, 1) */       \
     const int ro_ = pc_ ? 2 * r_ : r_;                                                               \
     const int pd_ = pc_ ? (r_ == 0 ? pair_d : pair_d2) : 0;                                          \
-    __syncthreads(); /* this phase is staged; the buffers of the previous one are released */        \
+    STAMP_BAR_C /* this phase is staged; the buffers of the previous one are released */             \
     C_READ_B((P) ^ 1, 0)                                                                             \
     C_READ_A(0, 0, 0)                                                                                \
     if (!(FIRST)) {                                                                                  \
@@ -912,6 +949,12 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     C_MFMA(1, 0, MF - 1)
   }
   C_EPILOGUE(ti)
+#ifdef MIMO_CONV_STAMPS
+  if (tid == 0) {
+    atomicAdd(&g_conv_stamps[(FWD ? 0 : 4) + 0], st_wait);
+    atomicAdd(&g_conv_stamps[(FWD ? 0 : 4) + 1], STAMP_NOW() - st_begin);
+  }
+#endif
   __syncthreads();  // matches the producers' last barrier: their (dead) LDS stores are done
   if (FWD && a.stats) {
     // one partial-statistics row per workgroup: the four consumer waves add their sums through LDS (4 x fewer rows
@@ -1220,6 +1263,16 @@ int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const fl
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
+
+#ifdef MIMO_CONV_STAMPS
+}  // namespace mimo
+extern "C" int mimo_debug_conv_stamps(unsigned long long* out) {  // reads and clears the counters
+  unsigned long long z[8] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mimo::g_conv_stamps), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(mimo::g_conv_stamps), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+namespace mimo {
+#endif
 
 int pack_weights_bf16x3_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
                                const int* row_map, const int* col_map, int transposed, hipStream_t stream, int pair) {
