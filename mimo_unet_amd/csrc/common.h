@@ -73,6 +73,9 @@ struct ConvLaunch {
   int ep_mask_ld = 0;
   int* status = nullptr;  // with ep_scale: bit 0 is OR-ed in when a convolution output is not finite (the ReLU would drop a NaN)
   int pair = 0;  // split kernel: a.wpk holds the tap-paired image of the last chunk (conv3x3_pair_tail)
+  // != 0: a.wpk holds the wide kernel's image — [16-channel chunk][tap][wide rows][hi 16 | lo 16] — and the launch runs
+  // on conv_wide.hip (value = packed rows, conv3x3_wide_rows)
+  int wide = 0;
 };
 // returns number of partial-stat rows (spatial blocks) through *rows when stats != nullptr
 int conv3x3_launch(const ConvLaunch& a, int* rows, hipStream_t stream);
@@ -85,6 +88,15 @@ int pack_weights_bf16x3_launch(const float* w, void* dst, int f16, int cout, int
 // 1 when conv3x3_bf16x3_launch(mode) runs a layer with cin_p input channels and Ho x Wo outputs on the tap-paired
 // instance (last chunk <= 16 channels: two taps per MFMA); the weights must then be packed with pair = 1
 int conv3x3_pair_tail(int mode, int cin_p, int Ho, int Wo);
+// wide decomposition (conv_wide.hip; which layers: sched::wide_config).  rows = output channels of the launch (forward:
+// the padded Cout; data gradient: the layer's padded input channels); returns the packed weight rows, 0 = the layer
+// stays on conv_bf16x3.hip.  The packer and the launch must agree (ConvLaunch::wide).
+int conv3x3_wide_rows(int mode, int N, int cin_p, int rows, int Ho, int Wo);
+size_t conv3x3_wide_weight_elems(int cin_p, int rows_pad);  // 16-bit elements of the packed image
+int conv3x3_wide_stat_rows();
+int conv3x3_wide_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t stream);
+int pack_weights_wide_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
+                             const int* row_map, const int* col_map, int nrows_map, int transposed, hipStream_t stream);
 int conv3x3_pick_nfrag(int cout);            // fragments (of 16 output channels) per workgroup
 int conv3x3_cout_pad(int cout);              // packed weight rows for that choice
 int conv3x3_stat_rows(int N, int Ho, int Wo);  // spatial workgroups == partial-stat rows
@@ -144,7 +156,9 @@ int wgrad_reduce_blocks(int cin_pad, int cout_pad);  // workgroups one layer nee
 
 // All weight repacks of a step in ONE launch (a per-layer launch each cost more in dispatch gaps than in
 // work): a device table of jobs, blockIdx.y = job.  kind 0: fp32 [tap][rows_pad][cols]; 1 / 2: fp16 / bf16
-// (hi, lo) pairs [chunk][tap][rows_pad][hi 32 | lo 32]; bias_n > 0 additionally copies the layer's bias.
+// (hi, lo) pairs [chunk][tap][rows_pad][hi 32 | lo 32]; 3 / 4: fp16 / bf16 pairs in the wide kernel's layout
+// [16-channel chunk][tap][rows_pad][hi 16 | lo 16] (rows beyond map_rows are zero); bias_n > 0 additionally copies the
+// layer's bias.
 struct PackJob {
   int64_t w_off, bias_off;  // float offsets into the bound parameter buffer
   void* dst;
@@ -152,6 +166,7 @@ struct PackJob {
   const int *row_map, *col_map;
   int kind, cout, cin, rows_pad, cols, transposed, total, bias_n;
   int pair;  // kind 1 / 2: tap-paired image of the last chunk (conv3x3_pair_tail)
+  int map_rows;  // kind 3 / 4: entries of row_map (rows_pad may exceed it)
 };
 int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream);
 

@@ -1135,6 +1135,7 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
 
 // mode: see MIMO_CONV_MODE_CONSTANTS (0 split16 dgrad, 1 split16 forward, 2 bf16 forward, 3 bf16 dgrad)
 int conv3x3_bf16x3_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t stream) {
+  if (a.wide) return conv3x3_wide_launch(a, mode, rows, stream);  // weights packed for conv_wide.hip
   if (!a.wpk || a.ldx % 4 != 0 || a.cout_pad % 16 != 0 || a.Hi < 2 || a.Wi < 2 || mode < 0 || mode > 7 ||
       (mode >= 4 && (a.ldx % 8 != 0 || a.cin_p % 8 != 0 || a.ldy % 4 != 0))) {
     set_error("conv3x3 split: bad geometry or mode");
@@ -1218,6 +1219,12 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
     if (j.kind == 0) {
       col = i % j.cols;
       row = i / j.cols;
+    } else if (j.kind >= 3) {  // wide layout: 16-channel chunks
+      k = i & 15;
+      const int rest = i >> 4;
+      row = rest % j.rows_pad;
+      chunk = rest / j.rows_pad;
+      col = chunk * 16 + k;
     } else {
       k = i & 31;
       const int rest = i >> 5;
@@ -1228,7 +1235,7 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
     float v[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) v[t] = 0.f;
-    if (col < j.cols) {
+    if (col < j.cols && (j.kind < 3 || row < j.map_rows)) {
       const int rm = j.row_map[row], cm = j.col_map[col];
       if (rm >= 0 && cm >= 0) {
         const int co = j.transposed ? cm : rm, ci = j.transposed ? rm : cm;
@@ -1237,7 +1244,7 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
         for (int t = 0; t < 9; ++t) v[t] = src[j.transposed ? 8 - t : t];  // transposed: taps flipped (kh, kw -> 2-kh, 2-kw)
       }
     }
-    const bool paired = j.kind != 0 && j.pair && chunk == (j.cols + 31) / 32 - 1;
+    const bool paired = (j.kind == 1 || j.kind == 2) && j.pair && chunk == (j.cols + 31) / 32 - 1;
     if (paired && k >= 16) continue;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -1246,6 +1253,17 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
       if (paired) pair_slot(tap, k, &slot, &kk);
       if (j.kind == 0) {
         reinterpret_cast<float*>(j.dst)[((size_t)tap * j.rows_pad + row) * j.cols + col] = x;
+      } else if (j.kind == 3) {
+        const float xs = x * kF16WeightScale;
+        const _Float16 hi = (_Float16)xs, lo = (_Float16)(xs - (float)hi);
+        _Float16* d = reinterpret_cast<_Float16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 32;
+        d[k] = hi;
+        d[16 + k] = lo;
+      } else if (j.kind == 4) {
+        const __bf16 hi = (__bf16)x, lo = (__bf16)(x - (float)hi);
+        __bf16* d = reinterpret_cast<__bf16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 32;
+        d[k] = hi;
+        d[16 + k] = lo;
       } else if (j.kind == 1) {
         const float xs = x * kF16WeightScale;
         const _Float16 hi = (_Float16)xs, lo = (_Float16)(xs - (float)hi);

@@ -1,0 +1,606 @@
+// 3x3 convolution (forward / data gradient), split16 arithmetic, "wide" decomposition (round 3).
+//
+// Same arithmetic as conv_bf16x3.hip (a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on the 16-bit MFMA, fp16 pairs in the
+// forward, bf16 pairs in the data gradient, fp32 accumulation) on a decomposition that moves fewer bytes and issues
+// fewer instructions per MFMA.  What the round-2 ablation found (profiles/r02/conv_ablation.txt): the 256-pixel x
+// 64-channel kernel is bound by neither the MFMA pipe (50-56 % busy) nor HBM but by everything around the MFMAs — the
+// staging waves re-stream 74 KB of weights per 46 KB input tile and 32-channel chunk, the lone MFMA wave of a SIMD reads
+// 0.33 ds_read_b128 per MFMA and shares the SIMD's issue port (a 16x16x32 MFMA holds it for 8 of its 16 cycles) with
+// the staging wave next to it, and there is a workgroup barrier every 108-144 MFMAs.  Here:
+//   * tile = 512 output pixels x 32 / 64 output channels; K is walked in 16-channel chunks ("stages"), so the halo
+//     tile of a stage is 612 x [hi 16 | lo 16] = 39 KB and two of them fit beside the weights.  Per MFMA cycle the
+//     workgroup stages 37-53 % fewer bytes than the 256-pixel kernel (the weight image of a chunk serves twice the pixels).
+//   * v_mfma_f32_32x32x16_{f16,bf16}: a consumer wave owns 128 pixels x NB channels = 4 x NF accumulator tiles of 32 x 32
+//     (128 registers at NB = 64).  Half the MFMA instructions for the same flops (the issue port is held 8 of 32
+//     cycles), 0.25 ds_read_b128 per 16-cycle MFMA equivalent, and K = 16 per instruction: channel counts pad to 16,
+//     not 32 (45 -> 48, no tap pairing needed).
+//   * weights by LDS-DMA into unpadded 64-byte rows (XOR swizzle on the per-lane SOURCE address): NB = 64: one tap row
+//     (3 taps) per phase, ring of three buffers, DMA two phases ahead of its use; NB = 32: all nine taps of a chunk
+//     per phase, two buffers.  One workgroup barrier per 72 (NB = 64) / 108 (NB = 32) MFMAs of 32 cycles, i.e. per
+//     2304 / 3456 matrix-pipe cycles (256-pixel kernel: 1152-2304).
+//   * input rows are 80 bytes (64 + 16 pad): ds_read_b128 by 16 consecutive pixels hits 16 distinct 16-byte slots
+//     (5 is coprime to 16), offsets of the nine taps are immediates / phase scalars.
+//   * accumulators transposed (weights = MFMA A operand): lane (pixel, half h) holds channels 8j + 4h .. +3, j = 0..3,
+//     of each 32-channel tile -> 16-byte stores.  BatchNorm partial sums: a lane sees 16 channels per tile; adjacent
+//     pixel lanes split them (one DPP reduce-scatter step per tile) so that the sums persist in 4 registers per tile
+//     and moment instead of 16.
+// Wave roles as in conv3x3_ws_kernel: waves 0-3 consume (ds_read + MFMA + epilogue), waves 4-7 stage (global loads two
+// stages ahead in registers, fp32 -> fp16 hi/lo split or 16-byte copies of the pre-split dz, LDS-DMA of the weights);
+// persistent workgroups, one per CU, XCD-aware order (channel tiles of a pixel tile share an L2).
+// Which layers run here: sched::wide_config (sched.h) — the packer lays the weights out for the decomposition the
+// launch will use (ConvLaunch::wide).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "sched.h"
+
+namespace mimo {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8_t a, bf16x8_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(f16x8_t a, f16x8_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// value of the lane with the lowest bit flipped (quad_perm [1, 0, 3, 2])
+__device__ __forceinline__ float dpp_xor1(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+
+constexpr float kWideF16Scale = 256.f;  // forward weights are packed x 2^8 (as conv_bf16x3.hip)
+constexpr int kXPitch = 80;             // bytes per input row: [hi 16 | lo 16] 16-bit values + 16 pad
+constexpr int kMaxPix = sched::kWideMaxPix;
+constexpr int kXBytes = kMaxPix * kXPitch;  // 51200
+
+}  // namespace
+
+// MODE 0: data gradient (bf16 pairs, input = pre-split dz records [hi rc | lo rc] per 32-channel chunk)
+// MODE 1: forward (fp16 pairs, fp32 input split on the way into LDS; bias, BatchNorm sums, inference epilogue)
+// NF: 32-channel tiles per workgroup; TPP: taps per phase (3 = one tap row, 9 = a whole chunk)
+// EPI (forward): the inference epilogue — eval-mode BatchNorm + ReLU (+ Dropout2d multipliers) folded into the store, no
+// statistics; else bias + BatchNorm partial sums
+template <int NF, int MODE, int TPP, bool EPI>
+__global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX,
+                                                                int numTiles, int gx, int coTiles) {
+  static_assert(MODE == 0 || MODE == 1, "split16 modes");
+  static_assert((NF == 2 && TPP == 3) || (NF == 1 && TPP == 9), "instances: 64 channels x tap rows, 32 channels x chunks");
+  constexpr bool FWD = MODE == 1;
+  constexpr bool STATS = FWD && !EPI;
+  static_assert(FWD || !EPI, "the inference epilogue belongs to the forward");
+  typedef typename std::conditional<FWD, f16x8_t, bf16x8_t>::type V8;
+  constexpr int NB = NF * 32;
+  constexpr int MF = 4;                      // 32-pixel fragments per consumer wave
+  constexpr int SM = NF == 1 ? 2 : 1;        // fragments per software-pipeline slot (6 MFMAs per slot)
+  constexpr int NSLOT = MF / SM;
+  constexpr int PARTS = 9 / TPP;             // phases per stage
+  constexpr int XU = TPP == 3 ? 12 : 10;     // 16-byte units of an input tile per producer thread (640 x 4 / 256)
+  constexpr int XP = XU / PARTS;
+  constexpr int WUNITS = TPP * NB * 4;       // 16-byte units of a phase's weights
+  constexpr int WU = (WUNITS + 255) / 256;   // DMA instructions per producer wave and phase (the same for every wave)
+  constexpr int WPHB = WU * 256 * 16;        // bytes per weight buffer (rounded up to whole DMA rounds)
+  constexpr int NWB = TPP == 3 ? 3 : 2;      // weight buffers
+  static_assert(2 * kXBytes + NWB * WPHB <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kXBytes + NWB * WPHB];
+  unsigned char* const xs = lds;
+  unsigned char* const ws = lds + 2 * kXBytes;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int TCP = TC + 2, TRP = TR + 2;
+  const int npix_lds = TRP * TCP, npix_out = TR * TC;
+  const int nchunks = (a.cin_p + 15) / 16;
+  const int v_ = xcd_virtual_index((int)blockIdx.x, gx * coTiles);
+  const int vbx = v_ / coTiles;
+  const int co0 = (v_ - vbx * coTiles) * NB;
+  const int ntiles_mine = vbx < numTiles ? (numTiles - 1 - vbx) / gx + 1 : 0;
+  const int nstages = ntiles_mine * nchunks;
+  const int nphases = PARTS * nstages;
+  const int rows_pad = coTiles * NB;  // packed weight rows per tap
+
+  if (wave >= 4) {
+    // =============================== producers ===============================
+    const int ptid = tid - 256;
+    f32x4 xreg[XU];
+    const unsigned ws_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ws;
+    // weight unit u = ptid + 256 k of a phase: LDS row u >> 2 = tap * NB + channel, slot u & 3 <- source slot
+    // (u & 3) ^ ((channel >> 2) & 3).  Units past the phase's image (WUNITS not a multiple of 256) re-read its
+    // last unit into the buffer's slack.
+    int wsrc[WU];
+#pragma unroll
+    for (int k = 0; k < WU; ++k) {
+      const int u = min(ptid + k * 256, WUNITS - 1), row = u >> 2;
+      const int tp = row / NB, ch = row - tp * NB;
+      wsrc[k] = (tp * rows_pad + ch) * 4 + ((u & 3) ^ ((ch >> 2) & 3));
+    }
+    int u_rc[XU], u_off[XU];
+#pragma unroll
+    for (int k = 0; k < XU; ++k) {
+      const int u = ptid + k * 256;
+      const int p = min(u >> 2, npix_lds - 1);
+      const int tr = p / TCP, tc = p - tr * TCP;
+      u_rc[k] = (tr << 16) | tc;
+      // byte offset from the tile's first halo pixel (tiles whose halo lies inside the image)
+      u_off[k] = FWD ? ((tr * a.Wi + tc) * a.ldx + 4 * (u & 3)) * 4
+                     : (tr * a.Wi + tc) * a.ldx * 4 + ((u & 3) >> 1) * 64 + (u & 1) * 16;
+    }
+    const u32x4* wpk = reinterpret_cast<const u32x4*>(a.wpk);
+
+    // input units K0..K1 of stage STAGE = (tile STAGE / nchunks, chunk STAGE % nchunks) -> registers
+#define WD_LOAD_X(K0, K1, STAGE)                                                                     \
+  {                                                                                                  \
+    const int st_ = (STAGE);                                                                         \
+    const int ti_ = st_ / nchunks, ck_ = st_ - ti_ * nchunks;                                        \
+    int t_ = vbx + ti_ * gx;                                                                         \
+    const int tx_ = t_ % tilesX;                                                                     \
+    t_ /= tilesX;                                                                                    \
+    const int ty_ = t_ % tilesY;                                                                     \
+    const int n_ = t_ / tilesY;                                                                      \
+    const int y0_ = ty_ * TR - a.off, x0_ = tx_ * TC - a.off;                                        \
+    const float* ximg_ = a.x + (size_t)n_ * a.Hi * a.Wi * a.ldx;                                     \
+    /* forward: channels ck*16 .. +15 of the fp32 tensor; data gradient: half (ck & 1) of 32-channel record ck >> 1 */ \
+    const int rc_ = min(32, a.cin_p - (ck_ >> 1) * 32);                                              \
+    const bool full_ = FWD ? ck_ * 16 + 16 <= a.cin_p : rc_ == 32;                                   \
+    if (full_ && y0_ >= 0 && y0_ + TRP <= a.Hi && x0_ >= 0 && x0_ + TCP <= a.Wi) {                   \
+      /* halo inside the image, full chunk (wave-uniform): scalar tile base + per-thread constant */ \
+      const char* tb_ = reinterpret_cast<const char*>(ximg_ + ((size_t)y0_ * a.Wi + x0_) * a.ldx) +  \
+                        (FWD ? ck_ * 64 : (ck_ >> 1) * 128 + (ck_ & 1) * 32);                        \
+      _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_)                                         \
+        xreg[k_] = *reinterpret_cast<const f32x4*>(tb_ + u_off[k_]);                                 \
+    } else {                                                                                         \
+      _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                       \
+        int iy_ = y0_ + (u_rc[k_] >> 16), ix_ = x0_ + (u_rc[k_] & 0xffff);                           \
+        bool in_ = true;                                                                             \
+        if (FWD) { /* reflect padding */                                                             \
+          iy_ = max(iy_, -iy_);                                                                      \
+          iy_ = max(min(iy_, 2 * a.Hi - 2 - iy_), 0);                                                \
+          ix_ = max(ix_, -ix_);                                                                      \
+          ix_ = max(min(ix_, 2 * a.Wi - 2 - ix_), 0);                                                \
+        } else { /* zero outside the image (transposed convolution) */                               \
+          in_ = iy_ >= 0 && iy_ < a.Hi && ix_ >= 0 && ix_ < a.Wi;                                    \
+        }                                                                                            \
+        const int q_ = (ptid + k_ * 256) & 3;                                                        \
+        const int o_ = in_ ? (iy_ * a.Wi + ix_) * a.ldx : 0;                                         \
+        /* masked-out units are LOADED from the zero page (common.h), never selected after the load */ \
+        if (FWD) {                                                                                   \
+          const int ch_ = ck_ * 16 + 4 * q_;                                                         \
+          xreg[k_] = *reinterpret_cast<const f32x4*>(ch_ < a.cin_p ? ximg_ + o_ + ch_ : kZeroPage);  \
+        } else {                                                                                     \
+          const int e_ = (ck_ & 1) * 16 + (q_ & 1) * 8; /* first channel of the unit within its 32-channel record */ \
+          const unsigned short* s_ = reinterpret_cast<const unsigned short*>(ximg_ + o_) +           \
+                                     ((ck_ >> 1) * 64 + (q_ >> 1) * rc_ + e_);                       \
+          xreg[k_] = *reinterpret_cast<const f32x4*>(in_ && e_ < rc_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
+        }                                                                                            \
+      }                                                                                              \
+    }                                                                                                \
+  }
+#define WD_STORE_X(K0, K1, BUF)                                                                      \
+  _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                           \
+    const int u_ = ptid + k_ * 256;                                                                  \
+    const int p_ = u_ >> 2, q_ = u_ & 3;                                                             \
+    if (p_ < npix_lds) {                                                                             \
+      const f32x4 v_ = xreg[k_];                                                                     \
+      unsigned char* row_ = xs + (BUF) * kXBytes + p_ * kXPitch;                                     \
+      if (FWD) {                                                                                     \
+        f16x4_t hi_, lo_;                                                                            \
+        hi_[0] = (_Float16)v_[0];                                                                    \
+        hi_[1] = (_Float16)v_[1];                                                                    \
+        hi_[2] = (_Float16)v_[2];                                                                    \
+        hi_[3] = (_Float16)v_[3];                                                                    \
+        lo_[0] = (_Float16)(v_[0] - (float)hi_[0]);                                                  \
+        lo_[1] = (_Float16)(v_[1] - (float)hi_[1]);                                                  \
+        lo_[2] = (_Float16)(v_[2] - (float)hi_[2]);                                                  \
+        lo_[3] = (_Float16)(v_[3] - (float)hi_[3]);                                                  \
+        *reinterpret_cast<f16x4_t*>(row_ + q_ * 8) = hi_;                                            \
+        *reinterpret_cast<f16x4_t*>(row_ + 32 + q_ * 8) = lo_;                                       \
+      } else {                                                                                       \
+        *reinterpret_cast<f32x4*>(row_ + q_ * 16) = v_;                                              \
+      }                                                                                              \
+    }                                                                                                \
+  }
+    // weights of global phase PH (stage PH / PARTS, part PH % PARTS) -> weight buffer BUF, by LDS-DMA.  Inline asm, not
+    // the builtin: with a DMA it knows of in flight hipcc waits vmcnt(0) in front of every use of an ordinary load
+    // (conv_bf16x3.hip WS_DMA_W).  M0 = LDS byte address of lane 0, saved and restored inside the statement.
+#define WD_DMA_W(BUF, PH)                                                                            \
+  {                                                                                                  \
+    const int phw_ = (PH);                                                                           \
+    const int ck_ = (phw_ / PARTS) % nchunks, r_ = phw_ % PARTS;                                     \
+    const u32x4* src_ = wpk + ((size_t)(ck_ * 9 + r_ * TPP) * rows_pad + co0) * 4;                   \
+    _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                              \
+      const unsigned dst_ = __builtin_amdgcn_readfirstlane(                                          \
+          ws_lds + (unsigned)((BUF) * WPHB + (k_ * 256 + (ptid & ~63)) * 16));                       \
+      unsigned keep_;                                                                                \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep_) : "v"(src_ + wsrc[k_]), "s"(dst_) : "memory");                     \
+    }                                                                                                \
+  }
+    // all vector-memory operations but the N youngest are done; LDS stores retired; phase barrier
+#define WD_WAIT_BAR(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+
+    // ---- prologue: stage 0 in input buffer 0, weights of phase 0 (and 1) on their way; input of stage 1 in registers
+    WD_LOAD_X(0, XU, 0)
+    WD_DMA_W(0, 0)
+    if (NWB == 3) {
+      WD_DMA_W(1, min(1, nphases - 1))
+    }
+    WD_STORE_X(0, XU, 0)
+    WD_LOAD_X(0, XU, min(1, nstages - 1))
+    WD_WAIT_BAR(XU)  // every DMA above is older than these XU loads
+    // ---- phase (j, R): store part R of stage j + 1 into the input buffer the consumers released at the start of stage
+    // j, start the DMA of a later phase's weights into the buffer released at the last barrier, refill the registers
+    // with part R of stage j + 2.  Straight-line: past the end the loads re-read the last stage and the stores / DMAs
+    // go to buffers nobody reads any more (exact vmcnt counts need unconditional code).
+    int wslot = NWB == 3 ? 2 : 1;  // buffer of the next DMA = (ph + NWB - 1) % NWB
+    for (int j = 0; j < nstages; ++j) {
+      const int xb = (j + 1) & 1;
+#define WD_PHASE(R)                                                                                  \
+  {                                                                                                  \
+    const int ph_ = PARTS * j + (R);                                                                 \
+    WD_STORE_X((R) * XP, ((R) + 1) * XP, xb)                                                         \
+    WD_DMA_W(wslot, min(ph_ + NWB - 1, nphases - 1))                                                 \
+    wslot = wslot + 1 == NWB ? 0 : wslot + 1;                                                        \
+    WD_LOAD_X((R) * XP, ((R) + 1) * XP, min(j + 2, nstages - 1))                                     \
+    /* three buffers: the weights of phase ph + 1 were issued one phase ago, in front of that phase's XP loads */ \
+    WD_WAIT_BAR(NWB == 3 ? XP + WU + XP : XP)                                                        \
+  }
+      WD_PHASE(0)
+      if (PARTS == 3) {
+        WD_PHASE(1)
+        WD_PHASE(2)
+      }
+#undef WD_PHASE
+    }
+#undef WD_LOAD_X
+#undef WD_STORE_X
+#undef WD_DMA_W
+#undef WD_WAIT_BAR
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs past the end still target this workgroup's LDS
+    if (STATS) __syncthreads();                       // the consumers combine their BatchNorm sums through LDS
+    return;
+  }
+
+  // =============================== consumers ===============================
+  const int px = lane & 31, h = lane >> 5;
+  int pbase[MF], prc[MF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m) {
+    const int idx = (wave * MF + m) * 32 + px;
+    const int r = idx / TC, c = idx - r * TC;
+    pbase[m] = idx < npix_out ? (r * TCP + c) * kXPitch + h * 16 : h * 16;
+    prc[m] = idx < npix_out ? (r << 16) | c : (0x4000 << 16);  // tile-relative (row, column); 0x4000 = not in the tile
+  }
+  // weight fragment (MFMA A operand): lane (row px of the 32-channel tile, K half h): hi at slot h, lo at slot 2 + h,
+  // slots XOR-swizzled by (row >> 2) & 3
+  const int wsw = (px >> 2) & 3;
+  const int w_hi = px * 64 + ((h ^ wsw) << 4), w_lo = px * 64 + (((2 + h) ^ wsw) << 4);
+  const int row1 = TCP * kXPitch;  // input-tile byte offset of one tap row
+
+  f32x16 acc[MF][NF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][nf][i] = 0.f;
+  // BatchNorm partial sums over all tiles of this persistent workgroup.  Lane (px, h) holds, of channel quad j of tile
+  // nf (channels 8 j + 4 h .. + 3), the two channels 2 (px & 1) .. + 1 — summed over its own and its neighbour's pixels
+  f32x2 s1[NF][4], s2[NF][4];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1[nf][j] = f32x2{0.f, 0.f};
+      s2[nf][j] = f32x2{0.f, 0.f};
+    }
+  const bool odd = px & 1;
+
+  V8 af[2][SM][2], wf[2][NF][2];  // [register set][fragment][hi, lo]
+
+  // weights of tap T (within the phase) -> register set WS_
+#define WC_READ_W(WS_, T)                                                                            \
+  _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
+    wf[WS_][nf][0] = *reinterpret_cast<const V8*>(wb_ + ((T) * NB + nf * 32) * 64 + w_hi);           \
+    wf[WS_][nf][1] = *reinterpret_cast<const V8*>(wb_ + ((T) * NB + nf * 32) * 64 + w_lo);           \
+  }
+  // pixel fragments of slot S, tap T -> register set AS_.  Tap T of a phase: TPP = 3: (tap row of the phase, T);
+  // TPP = 9: (T / 3, T % 3)
+#define WC_READ_A(AS_, T, S)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < SM; ++i) {                                                   \
+    const unsigned char* p_ = xb_ + pbase[(S) * SM + i] +                                            \
+                              (TPP == 3 ? ro_ + (T) * kXPitch : ((T) / 3) * row1 + ((T) % 3) * kXPitch); \
+    af[AS_][i][0] = *reinterpret_cast<const V8*>(p_);                                                \
+    af[AS_][i][1] = *reinterpret_cast<const V8*>(p_ + 32);                                           \
+  }
+#define WC_MFMA(AS_, WS_, S)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                     \
+    _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                              \
+      acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][0], af[AS_][i][1], acc[(S) * SM + i][nf]);          \
+      acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][1], af[AS_][i][0], acc[(S) * SM + i][nf]);          \
+      acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][0], af[AS_][i][0], acc[(S) * SM + i][nf]);          \
+    }
+  // order of a slot pinned for the scheduler: its LDS reads (of the NEXT slot's fragments), then its MFMAs — left
+  // alone hipcc sinks every read to just before its first use (one register set) and the lone MFMA wave of the SIMD
+  // eats the LDS latency per fragment
+#define WC_PIN(NREADS)                                                                               \
+  __builtin_amdgcn_sched_group_barrier(0x100, (NREADS), 0);                                          \
+  __builtin_amdgcn_sched_group_barrier(0x008, 3 * SM * NF, 0);
+  // bias, store, BatchNorm partial sums of tile TI (accumulators complete), then clear them
+  typedef float OT;
+#define WC_EPILOGUE(TI)                                                                              \
+  {                                                                                                  \
+    int t_ = vbx + (TI) * gx;                                                                        \
+    const int tx_ = t_ % tilesX;                                                                     \
+    t_ /= tilesX;                                                                                    \
+    const int ty_ = t_ % tilesY;                                                                     \
+    const int n_ = t_ / tilesY;                                                                      \
+    const int y0_ = ty_ * TR, x0_ = tx_ * TC;                                                        \
+    OT* yimg_ = reinterpret_cast<OT*>(a.y) + (size_t)n_ * a.Ho * a.Wo * a.ldy + co0 + 4 * h;         \
+    int yo_[MF]; /* element offset of the lane's pixel in the image; < 0: not stored */              \
+    _Pragma("unroll") for (int m = 0; m < MF; ++m) {                                                 \
+      const int oy = y0_ + (prc[m] >> 16), ox = x0_ + (prc[m] & 0xffff);                             \
+      yo_[m] = (oy < a.Ho && ox < a.Wo) ? (oy * a.Wo + ox) * a.ldy : -1;                             \
+    }                                                                                                \
+    _Pragma("unroll") for (int nf = 0; nf < NF; ++nf)                                                \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+        const int c_ = co0 + nf * 32 + 8 * j + 4 * h;                                                \
+        f32x4 b_ = f32x4{0.f, 0.f, 0.f, 0.f}, esc_ = b_, esh_ = b_, emk_ = f32x4{1.f, 1.f, 1.f, 1.f}; \
+        if (FWD && c_ < a.cout_pad) b_ = *reinterpret_cast<const f32x4*>(a.bias + c_);               \
+        if (EPI && c_ < a.cout_store) {                                                              \
+          esc_ = *reinterpret_cast<const f32x4*>(a.ep_scale + c_);                                   \
+          esh_ = *reinterpret_cast<const f32x4*>(a.ep_shift + c_);                                   \
+          if (a.ep_mask)                                                                             \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
+              if (c_ + i_ < a.ep_mask_ld) emk_[i_] = a.ep_mask[(size_t)n_ * a.ep_mask_ld + c_ + i_]; \
+        }                                                                                            \
+        f32x4 t4_ = f32x4{0.f, 0.f, 0.f, 0.f}, q4_ = t4_;                                            \
+        _Pragma("unroll") for (int m = 0; m < MF; ++m) {                                             \
+          f32x4 v = f32x4{acc[m][nf][4 * j], acc[m][nf][4 * j + 1], acc[m][nf][4 * j + 2], acc[m][nf][4 * j + 3]}; \
+          if (FWD) v = v * (1.f / kWideF16Scale) + b_;                                               \
+          if (EPI) {                                                                                 \
+            if (a.status && yo_[m] >= 0 && !(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]))) \
+              atomicOr(a.status, 1);                                                                 \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
+              v[i_] = fmaxf(fmaf(v[i_], esc_[i_], esh_[i_]), 0.f) * emk_[i_];                        \
+          }                                                                                          \
+          if (yo_[m] >= 0) {                                                                         \
+            if (c_ < a.cout_store) *reinterpret_cast<f32x4*>(yimg_ + yo_[m] + nf * 32 + 8 * j) = v;  \
+            if (STATS) {                                                                             \
+              t4_ += v;                                                                              \
+              q4_ += v * v;                                                                          \
+            }                                                                                        \
+          }                                                                                          \
+        }                                                                                            \
+        if (STATS) { /* the lane keeps channels 2 odd .. + 1 of the quad and gets its neighbour's share of them */ \
+          const float k0_ = odd ? t4_[2] : t4_[0], k1_ = odd ? t4_[3] : t4_[1];                      \
+          const float g0_ = odd ? t4_[0] : t4_[2], g1_ = odd ? t4_[1] : t4_[3];                      \
+          s1[nf][j] += f32x2{k0_ + dpp_xor1(g0_), k1_ + dpp_xor1(g1_)};                              \
+          const float l0_ = odd ? q4_[2] : q4_[0], l1_ = odd ? q4_[3] : q4_[1];                      \
+          const float h0_ = odd ? q4_[0] : q4_[2], h1_ = odd ? q4_[1] : q4_[3];                      \
+          s2[nf][j] += f32x2{l0_ + dpp_xor1(h0_), l1_ + dpp_xor1(h1_)};                              \
+        }                                                                                            \
+      }                                                                                              \
+    _Pragma("unroll") for (int m = 0; m < MF; ++m)                                                   \
+      _Pragma("unroll") for (int nf = 0; nf < NF; ++nf)                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) acc[m][nf][i_] = 0.f;                      \
+  }
+  // One phase.  On entry the previous phase's last slot is pending (pixel set 1, weight set P): it is multiplied
+  // behind the barrier, under the first reads of this phase.  Slots alternate the pixel sets (an even number per
+  // phase), taps alternate the weight sets (an odd number per phase, so consecutive phases swap P).
+#define WC_PHASE(P, FIRST)                                                                           \
+  {                                                                                                  \
+    const int j_ = ph / PARTS, r_ = ph - PARTS * j_;                                                 \
+    const unsigned char* xb_ = xs + (j_ & 1) * kXBytes;                                              \
+    const unsigned char* wb_ = ws + wslot * WPHB;                                                    \
+    const int ro_ = r_ * row1;                                                                       \
+    (void)ro_;                                                                                       \
+    __syncthreads(); /* this phase is staged; the buffers of the previous one are released */        \
+    WC_READ_W((P) ^ 1, 0)                                                                            \
+    WC_READ_A(0, 0, 0)                                                                               \
+    if (!(FIRST)) {                                                                                  \
+      WC_MFMA(1, P, NSLOT - 1)                                                                       \
+      WC_PIN(2 * NF + 2 * SM)                                                                        \
+      if (tile_done) {                                                                               \
+        WC_EPILOGUE(ti)                                                                              \
+        ++ti;                                                                                        \
+      }                                                                                              \
+    }                                                                                                \
+    _Pragma("unroll") for (int t = 0; t < TPP; ++t)                                                  \
+      _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                            \
+        const int g_ = t * NSLOT + s;                                                                \
+        const int ws_ = (t & 1) ? (P) : ((P) ^ 1);                                                   \
+        if (!(t == TPP - 1 && s == NSLOT - 1)) {                                                     \
+          if (s + 1 < NSLOT) {                                                                       \
+            WC_READ_A((g_ + 1) & 1, t, s + 1)                                                        \
+          } else {                                                                                   \
+            WC_READ_W(ws_ ^ 1, t + 1)                                                                \
+            WC_READ_A((g_ + 1) & 1, t + 1, 0)                                                        \
+          }                                                                                          \
+          WC_MFMA(g_ & 1, ws_, s)                                                                    \
+          /* a slot of the FIRST phase's head has the phase's opening reads in front of it too */    \
+          if ((FIRST) && g_ == 0) {                                                                  \
+            WC_PIN(2 * NF + 2 * SM + 2 * SM)                                                         \
+          } else if (s + 1 < NSLOT) {                                                                \
+            WC_PIN(2 * SM)                                                                           \
+          } else {                                                                                   \
+            WC_PIN(2 * NF + 2 * SM)                                                                  \
+          }                                                                                          \
+        }                                                                                            \
+      }                                                                                              \
+    tile_done = r_ == PARTS - 1 && (j_ + 1) % nchunks == 0;                                          \
+    ++ph;                                                                                            \
+    wslot = wslot + 1 == NWB ? 0 : wslot + 1;                                                        \
+  }
+
+  int ph = 0, ti = 0, wslot = 0;
+  bool tile_done = false;
+  if (nphases > 0) {
+    WC_PHASE(1, true)  // leaves weight set 0 pending
+    while (ph + 1 < nphases) {
+      WC_PHASE(0, false)
+      WC_PHASE(1, false)
+    }
+    if (ph < nphases) {
+      WC_PHASE(0, false)
+      WC_MFMA(1, 1, NSLOT - 1)
+    } else {
+      WC_MFMA(1, 0, NSLOT - 1)
+    }
+    WC_EPILOGUE(ti)
+  }
+  __syncthreads();  // matches the producers' last barrier
+  if (STATS) {
+    // one partial-statistics row per workgroup: lanes of equal (px & 1, h) hold the same channels
+    float* red = reinterpret_cast<float*>(xs);  // [4 waves][2][NB]
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int d = 2; d < 32; d <<= 1) {
+            s1[nf][j][i] += __shfl_xor(s1[nf][j][i], d);
+            s2[nf][j][i] += __shfl_xor(s2[nf][j][i], d);
+          }
+        if (px < 2) {
+          const int c = nf * 32 + 8 * j + 4 * h + 2 * px;
+          *reinterpret_cast<f32x2*>(red + (wave * 2 + 0) * NB + c) = s1[nf][j];
+          *reinterpret_cast<f32x2*>(red + (wave * 2 + 1) * NB + c) = s2[nf][j];
+        }
+      }
+    __syncthreads();  // also executed by the producers
+    if (tid < 2 * NB) {
+      const int which = tid / NB, c = tid - which * NB;
+      const float v = (red[(0 * 2 + which) * NB + c] + red[(1 * 2 + which) * NB + c]) +
+                      (red[(2 * 2 + which) * NB + c] + red[(3 * 2 + which) * NB + c]);
+      if (co0 + c < a.cout_pad) a.stats[((size_t)vbx * 2 + which) * a.cout_pad + co0 + c] = v;
+    }
+  }
+#undef WC_READ_W
+#undef WC_READ_A
+#undef WC_MFMA
+#undef WC_EPILOGUE
+#undef WC_PIN
+#undef WC_PHASE
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int wide_force() {
+  static const int f = [] {
+    const char* e = getenv("MIMO_CONV_WIDE");  // 0: never; 2: whenever the geometry is supported; default: cost rule
+    const int v = e ? atoi(e) : 1;
+    return v == 0 ? -1 : v >= 2 ? 1 : 0;
+  }();
+  return f;
+}
+
+// 0 = the layer runs on conv_bf16x3.hip; else the packed weight rows of the wide layout (ConvLaunch::wide)
+int conv3x3_wide_rows(int mode, int N, int cin_p, int rows, int Ho, int Wo) {
+  return sched::wide_config(mode, N, cin_p, rows, Ho, Wo, wide_force()).rows_pad;
+}
+// 16-bit elements of the packed wide weight image
+size_t conv3x3_wide_weight_elems(int cin_p, int rows_pad) { return (size_t)ceil_div(cin_p, 16) * 9 * rows_pad * 32; }
+int conv3x3_wide_stat_rows() { return 256; }  // one row per persistent workgroup column
+
+int conv3x3_wide_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t stream) {
+  const sched::WideCfg c = sched::wide_config(mode, a.N, a.cin_p, a.cout_store, a.Ho, a.Wo, 1);
+  if (!a.wpk || c.nf == 0 || c.rows_pad != a.wide || a.ldx % 4 != 0 || a.ldy % 4 != 0 || a.Hi < 2 || a.Wi < 2) {
+    set_error("conv3x3 wide: weights packed for %d rows, launch geometry gives %d (nf %d)", a.wide, c.rows_pad, c.nf);
+    return MIMO_ERR_INVALID;
+  }
+  const int tilesY = ceil_div(a.Ho, c.TR), tilesX = ceil_div(a.Wo, c.TC);
+  const int numTiles = a.N * tilesY * tilesX;
+  const int coTiles = c.rows_pad / (c.nf * 32);
+  const int gx = sched::wide_grid_x(numTiles, coTiles);
+  if (rows) *rows = gx;
+  dim3 grid(gx * coTiles);
+#define WIDE_LAUNCH(NF_, MODE_, TPP_, EPI_)                                                                        \
+  hipLaunchKernelGGL((conv3x3_wide_kernel<NF_, MODE_, TPP_, EPI_>), grid, dim3(512), 0, stream, a, c.TR, c.TC, tilesY, \
+                     tilesX, numTiles, gx, coTiles)
+  if (mode == 1) {
+    if (!a.bias || (a.ep_scale ? (a.stats || !a.ep_shift) : !a.stats)) {
+      set_error("conv3x3 wide forward: bias plus either the statistics rows or the inference epilogue");
+      return MIMO_ERR_INVALID;
+    }
+    if (a.ep_scale) {
+      if (c.nf == 2)
+        WIDE_LAUNCH(2, 1, 3, true);
+      else
+        WIDE_LAUNCH(1, 1, 9, true);
+    } else {
+      if (c.nf == 2)
+        WIDE_LAUNCH(2, 1, 3, false);
+      else
+        WIDE_LAUNCH(1, 1, 9, false);
+    }
+  } else {
+    if (c.nf == 2)
+      WIDE_LAUNCH(2, 0, 3, false);
+    else
+      WIDE_LAUNCH(1, 0, 9, false);
+  }
+#undef WIDE_LAUNCH
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+// weight packing: torch OIHW -> [chunk of 16 input channels][tap][rows_pad][hi 16 | lo 16] 16-bit (64-byte rows).
+// Element formulas as pack_weights_bf16x3_kernel (conv_bf16x3.hip): row / column maps, transposed = data gradient.
+template <bool F16>
+__global__ void pack_weights_wide_kernel(const float* __restrict__ w, void* __restrict__ dstv, int cout, int cin,
+                                         int rows_pad, int cols, int nchunks, const int* __restrict__ row_map,
+                                         const int* __restrict__ col_map, int nrows_map, int transposed) {
+  typedef typename std::conditional<F16, _Float16, __bf16>::type ET;
+  ET* dst = reinterpret_cast<ET*>(dstv);
+  const int total = nchunks * 9 * rows_pad * 16;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k = i & 15;
+    int rest = i >> 4;
+    const int row = rest % rows_pad;
+    rest /= rows_pad;
+    const int tap = rest % 9, chunk = rest / 9;
+    const int col = chunk * 16 + k;
+    float v = 0.f;
+    if (col < cols && row < nrows_map) {
+      const int rm = row_map[row], cm = col_map[col];
+      if (rm >= 0 && cm >= 0) {
+        const int co = transposed ? cm : rm, ci = transposed ? rm : cm;
+        const int kh = transposed ? 2 - tap / 3 : tap / 3, kw = transposed ? 2 - tap % 3 : tap % 3;
+        v = w[(((size_t)co * cin + ci) * 3 + kh) * 3 + kw];
+      }
+    }
+    if (F16) v *= kWideF16Scale;
+    const ET hi = (ET)v;
+    const ET lo = (ET)(v - (float)hi);
+    ET* d = dst + (((size_t)chunk * 9 + tap) * rows_pad + row) * 32;
+    d[k] = hi;
+    d[16 + k] = lo;
+  }
+}
+
+int pack_weights_wide_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
+                             const int* row_map, const int* col_map, int nrows_map, int transposed, hipStream_t stream) {
+  const int nchunks = ceil_div(cols, 16);
+  const int total = nchunks * 9 * rows_pad * 16;
+  const int blocks = min(ceil_div(total, 256), 4096);
+  if (f16)
+    hipLaunchKernelGGL(pack_weights_wide_kernel<true>, dim3(blocks), dim3(256), 0, stream, w, dst, cout, cin, rows_pad, cols,
+                       nchunks, row_map, col_map, nrows_map, transposed);
+  else
+    hipLaunchKernelGGL(pack_weights_wide_kernel<false>, dim3(blocks), dim3(256), 0, stream, w, dst, cout, cin, rows_pad, cols,
+                       nchunks, row_map, col_map, nrows_map, transposed);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+}  // namespace mimo

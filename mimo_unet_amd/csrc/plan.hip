@@ -70,6 +70,7 @@ struct ConvBN {
   float *wf = nullptr, *wd = nullptr, *bias_p = nullptr;
   void *wf16 = nullptr, *wd16 = nullptr;  // split-bf16 packed weights (MIMO_PREC_SPLIT16)
   bool fwd_split = false, dg_split = false, wg_split = false;
+  int fwd_wide = 0, dg_wide = 0;  // != 0: the launch runs on conv_wide.hip, value = packed weight rows (conv3x3_wide_rows)
   int *cin_map = nullptr, *fwd_row_map = nullptr, *dg_row_map = nullptr, *dg_col_map = nullptr;
   float* z = nullptr;
   float* dz_own = nullptr;  // MIMO_WGRAD_STREAM=2: this layer's own dz buffer (its weight gradient may run much later)
@@ -435,14 +436,20 @@ struct mimo_plan {
     L.dg_split = mfma16 && (mixed || L.cout_p >= 16);
     L.dtz = L.fwd_split ? st : ST_F32;
     if (L.wg_split && !L.dg_split) any_mixed_dz = true;
+    if (cfg.precision == MIMO_PREC_SPLIT16) {  // decomposition per layer and direction (sched::wide_config)
+      if (L.fwd_split) L.fwd_wide = conv3x3_wide_rows(1, n, L.cin_p, L.cout_p, h, w);
+      if (L.dg_split) L.dg_wide = conv3x3_wide_rows(0, n, L.cout_p, L.cin_p, h + 2, w + 2);
+    }
     if (L.fwd_split) {
       uint16_t* q = nullptr;
-      MIMO_TRY(dalloc(&q, (size_t)ceil_div(L.cin_p, 32) * 9 * L.cout_pad * 64));
+      MIMO_TRY(dalloc(&q, L.fwd_wide ? conv3x3_wide_weight_elems(L.cin_p, L.fwd_wide)
+                                     : (size_t)ceil_div(L.cin_p, 32) * 9 * L.cout_pad * 64));
       L.wf16 = q;
     }
     if (L.dg_split && train_bufs) {
       uint16_t* q = nullptr;
-      MIMO_TRY(dalloc(&q, (size_t)ceil_div(L.cout_p, 32) * 9 * L.dg_rows * 64));
+      MIMO_TRY(dalloc(&q, L.dg_wide ? conv3x3_wide_weight_elems(L.cout_p, L.dg_wide)
+                                    : (size_t)ceil_div(L.cout_p, 32) * 9 * L.dg_rows * 64));
       L.wd16 = q;
     }
     MIMO_TRY(upload_ints(&L.cin_map, in_chmap));
@@ -778,6 +785,13 @@ struct mimo_plan {
           j.dst = L->fwd_split ? L->wf16 : (void*)L->wf;
           j.total = L->fwd_split ? ceil_div(j.cols, 32) * 9 * j.rows_pad * 32 : 9 * j.rows_pad * j.cols;
           j.pair = L->fwd_split ? conv3x3_pair_tail(fwd_mode(), L->cin_p, L->H, L->W) : 0;
+          if (L->fwd_wide) {  // conv_wide.hip layout: 16-channel chunks, fp16 pairs
+            j.kind = 3;
+            j.map_rows = L->cout_pad;
+            j.rows_pad = L->fwd_wide;
+            j.total = ceil_div(j.cols, 16) * 9 * j.rows_pad * 16;
+            j.pair = 0;
+          }
           jobs.push_back(j);
           PackJob d{};
           d.w_off = L->off_w;
@@ -793,6 +807,13 @@ struct mimo_plan {
           d.dst = L->dg_split ? L->wd16 : (void*)L->wd;
           d.total = L->dg_split ? ceil_div(d.cols, 32) * 9 * d.rows_pad * 32 : 9 * d.rows_pad * d.cols;
           d.pair = L->dg_split ? conv3x3_pair_tail(dgrad_mode(), L->cout_p, L->H + 2, L->W + 2) : 0;
+          if (L->dg_wide) {  // bf16 pairs
+            d.kind = 4;
+            d.map_rows = L->dg_rows;
+            d.rows_pad = L->dg_wide;
+            d.total = ceil_div(d.cols, 16) * 9 * d.rows_pad * 16;
+            d.pair = 0;
+          }
           dg.push_back(d);
         }
       n_fwd_jobs = (int)jobs.size();
@@ -948,7 +969,8 @@ struct mimo_plan {
     int rows = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
     a.wpk = L.wf16;
-    a.pair = L.fwd_split ? conv3x3_pair_tail(fwd_mode(), L.cin_p, L.H, L.W) : 0;
+    a.pair = (L.fwd_split && !L.fwd_wide) ? conv3x3_pair_tail(fwd_mode(), L.cin_p, L.H, L.W) : 0;
+    a.wide = L.fwd_wide;
     int pr = prof_begin(MIMO_PROF_CONV_FWD, st);
     if (L.fwd_split)
       MIMO_TRY(conv3x3_bf16x3_launch(a, fwd_mode(), &rows, st));
@@ -1315,7 +1337,8 @@ struct mimo_plan {
       a.cout_store = L.cin_p;
       a.off = 2;
       a.wpk = L.wd16;
-      a.pair = L.dg_split ? conv3x3_pair_tail(dgrad_mode(), L.cout_p, L.H + 2, L.W + 2) : 0;
+      a.pair = (L.dg_split && !L.dg_wide) ? conv3x3_pair_tail(dgrad_mode(), L.cout_p, L.H + 2, L.W + 2) : 0;
+      a.wide = L.dg_wide;
       pr = prof_begin(MIMO_PROF_CONV_DGRAD, st);
       if (L.dg_split)
         MIMO_TRY(conv3x3_bf16x3_launch(a, dgrad_mode(), nullptr, st));

@@ -1,0 +1,106 @@
+// Host-side schedulers of libmimo_hip.so: tile shapes, channel-tile widths, split counts, the XCD workgroup order.
+// Pure integer arithmetic with no HIP dependency, so that tests/host/sched_test.cpp compiles this header with
+// g++ -fsanitize=address,undefined and sweeps every function over its whole argument range (tests/test_sched_cpu.py).
+#pragma once
+
+namespace mimo {
+namespace sched {
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int rup(int a, int b) { return cdiv(a, b) * b; }
+
+// Workgroups are dealt round-robin to the 8 XCDs in linear-id order; this maps a linear id to a virtual index such
+// that every XCD owns one CONTIGUOUS range of virtual indices.  Bijective on [0, total) for any total >= 1.
+// (device copy: xcd_virtual_index in common.h — same formula, kept in step by tests/test_sched_cpu.py)
+static inline int xcd_virtual_index(int linear, int total) {
+  const int k = linear & 7, slot = linear >> 3;
+  const int base = total >> 3, rem = total & 7;
+  return k * base + (k < rem ? k : rem) + slot;
+}
+
+// Output tile TR x TC of `npix` pixels whose halo (TR + 2) x (TC + 2) fits `maxpix` LDS rows: the shape that wastes
+// the fewest tile slots over an Ho x Wo image, ties broken by the smaller halo.  TR, TC >= 1; TR * TC <= npix;
+// (TR + 2) * (TC + 2) <= maxpix whenever some shape satisfies it (callers pass maxpix >= 3 * (4 + 2)).
+static inline void pick_tile_n(int Ho, int Wo, int npix, int maxpix, int* TR, int* TC) {
+  double best_eff = -1.0;
+  int best_tr = 1, best_tc = 4, best_pix = 1 << 30;
+  for (int k = 1; k <= Wo; ++k) {
+    int tc = cdiv(Wo, k);
+    if (tc > npix) continue;
+    int tr = npix / tc;
+    if (tr > Ho) tr = Ho;
+    while (tr > 1 && (tr + 2) * (tc + 2) > maxpix) --tr;
+    if (tr < 1 || (tr + 2) * (tc + 2) > maxpix) continue;
+    double eff = double(Ho) * Wo / (double(cdiv(Ho, tr)) * cdiv(Wo, tc) * npix);
+    int pix = (tr + 2) * (tc + 2);
+    if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && pix < best_pix)) {
+      best_eff = eff;
+      best_tr = tr;
+      best_tc = tc;
+      best_pix = pix;
+    }
+    if (tc <= 4) break;
+  }
+  *TR = best_tr;
+  *TC = best_tc;
+}
+
+// ---- wide convolution (conv_wide.hip): 512-pixel tiles, 16-channel K chunks, 32x32x16 MFMA ----------------------
+constexpr int kWideNPix = 512;    // output pixels per tile (4 consumer waves x 4 fragments of 32 pixels)
+constexpr int kWideMaxPix = 640;  // LDS rows of an input halo tile
+
+struct WideCfg {
+  int nf;        // 32-channel tiles per workgroup (1 or 2); 0 = layer stays on the 256-pixel kernel
+  int rows_pad;  // packed weight rows = channel tiles x 32 x nf
+  int TR, TC;
+};
+
+// Which decomposition a split16 3x3 convolution runs on.  `rows` = output channels of the launch (forward: Cout;
+// data gradient: the layer's padded input channels), Ho x Wo its output domain.
+// force: -1 = never, 0 = by the cost rule, 1 = whenever the geometry is supported.
+static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, int Wo, int force) {
+  WideCfg c{0, 0, 0, 0};
+  if (force < 0 || mode < 0 || mode > 1 || rows < 1 || cin_p < 16 || Ho < 2 || Wo < 2) return c;
+  int TR, TC;
+  pick_tile_n(Ho, Wo, kWideNPix, kWideMaxPix, &TR, &TC);
+  if ((TR + 2) * (TC + 2) > kWideMaxPix) return c;
+  const int tiles = N * cdiv(Ho, TR) * cdiv(Wo, TC);
+  const double eff = double(N) * Ho * Wo / (double(tiles) * kWideNPix);
+  const int r32 = cdiv(rows, 32);
+  // channel-tile width: two 32-channel tiles per workgroup unless the padding that costs exceeds what the second tile's
+  // reuse of the staged input is worth (~10 %)
+  const int nf = (r32 >= 2 && double(rup(r32, 2)) / r32 <= 1.10 + 1e-9) ? 2 : 1;
+  const int cotiles = cdiv(r32, nf);
+  if (force == 0) {
+    // padded MFMA work of both decompositions relative to the logical work: the 256-pixel kernel pads K to 32
+    // (tap pairing: a <= 16-channel tail costs 2/3 of a chunk) and the channels to 16
+    const int k16 = rup(cin_p, 16);
+    int TRo, TCo;
+    pick_tile_n(Ho, Wo, 256, 360, &TRo, &TCo);
+    const double eff_o = double(Ho) * Wo / (double(cdiv(Ho, TRo)) * cdiv(Wo, TCo) * 256);
+    const int tail = cin_p - 32 * (cdiv(cin_p, 32) - 1);
+    const double k_o = 32.0 * (cdiv(cin_p, 32) - 1) + (tail <= 16 ? 64.0 / 3.0 : 32.0);
+    const double work_w = double(k16) * (cotiles * nf * 32) / eff;
+    const double work_o = k_o * rup(rows, 16) / eff_o;
+    // the wide kernel must fill the chip (persistent, one workgroup per CU) and not pad away its advantage (~25 %)
+    if (tiles * cotiles < 192 || work_w > 1.20 * work_o) return c;
+  }
+  c.nf = nf;
+  c.rows_pad = cotiles * nf * 32;
+  c.TR = TR;
+  c.TC = TC;
+  return c;
+}
+
+// persistent grid of the wide kernel: gx pixel-tile columns x cotiles channel tiles, every workgroup of a launch walks
+// the same number of tiles (+-1)
+static inline int wide_grid_x(int numTiles, int cotiles) {
+  int gx = 256 / cotiles;
+  if (gx < 1) gx = 1;
+  if (gx > numTiles) gx = numTiles;
+  const int per = cdiv(numTiles, gx);
+  return cdiv(numTiles, per);
+}
+
+}  // namespace sched
+}  // namespace mimo

@@ -41,6 +41,11 @@ CONV_CASES = [
     (1, 3, 5, 4, 4), (1, 128, 128, 4, 60),
     # last 32-channel chunk with <= 16 channels on the persistent kernel: tap-paired K steps (three chunks; one chunk)
     (1, 40, 40, 75, 30), (2, 24, 24, 13, 75),
+    # shapes of the wide decomposition (conv_wide.hip: 512-pixel tiles, 16-channel chunks; forced on the small cases by
+    # tests/test_variants_gpu.py::conv_wide_forced): several tiles per workgroup column, one / two 32-channel tiles per
+    # workgroup with a half-empty last one, odd sizes, a 3-chunk input with a short tail, many images
+    (2, 64, 64, 60, 60), (1, 64, 96, 45, 30), (3, 32, 32, 120, 72), (1, 48, 40, 90, 45), (12, 32, 32, 48, 96),
+    (1, 37, 53, 40, 100),
 ]
 
 

@@ -26,6 +26,8 @@ VARIANTS = {
     "conv_ws_mf2_off": {"MIMO_CONV_WS_MF2": "0"},       # thin forward layers on 256-pixel tiles, one workgroup per CU
     "conv_wdma_off": {"MIMO_CONV_WDMA": "0"},           # convolution weights staged through registers, not by LDS-DMA
     "conv_pair_tail_off": {"MIMO_CONV_PAIR_TAIL": "0"},  # short last K chunks with one tap per MFMA
+    "conv_wide_forced": {"MIMO_CONV_WIDE": "2"},        # every supported split16 convolution on conv_wide.hip
+    "conv_wide_off": {"MIMO_CONV_WIDE": "0"},           # ... and none of them (256-pixel kernels everywhere)
 }
 
 
