@@ -84,17 +84,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
   constexpr int SM = NF == 1 ? 2 : 1;        // fragments per software-pipeline slot (6 MFMAs per slot)
   constexpr int NSLOT = MF / SM;
   constexpr int PARTS = 9 / TPP;             // phases per stage
-  constexpr int XU = TPP == 3 ? 12 : 10;     // 16-byte units of an input tile per producer thread (640 x 4 / 256)
-  constexpr int XP = XU / PARTS;
+  constexpr int XU = 10;                     // 16-byte units of an input tile per producer thread (640 x 4 / 256)
+  // units [XK0(R), XK0(R + 1)) are staged in phase R of a stage: 4 + 4 + 2 over three phases, all ten in one
+#define XK0(R) (PARTS == 1 ? ((R) <= 0 ? 0 : XU) : ((R) <= 0 ? 0 : (R) == 1 ? 4 : (R) == 2 ? 8 : XU))
+#define XKN(R) (XK0((R) + 1) - XK0(R)) /* loads of phase R */
   constexpr int WUNITS = TPP * NB * 4;       // 16-byte units of a phase's weights
   constexpr int WU = (WUNITS + 255) / 256;   // DMA instructions per producer wave and phase (the same for every wave)
   constexpr int WPHB = WU * 256 * 16;        // bytes per weight buffer (rounded up to whole DMA rounds)
   constexpr int NWB = TPP == 3 ? 3 : 2;      // weight buffers
-  static_assert(2 * kXBytes + NWB * WPHB <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kXBytes + NWB * WPHB];
+  constexpr int EPIB = FWD ? 3 * NB * 4 : 0;  // per-channel epilogue constants: bias, inference scale, shift
+  static_assert(2 * kXBytes + NWB * WPHB + EPIB <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kXBytes + NWB * WPHB + EPIB];
   unsigned char* const xs = lds;
   unsigned char* const ws = lds + 2 * kXBytes;
+  float* const epi = reinterpret_cast<float*>(lds + 2 * kXBytes + NWB * WPHB);
 
+#ifdef MIMO_WIDE_ABLATE
+  // timing-only builds (-DMIMO_WIDE_ABLATE=bits, results are wrong): 1 = producers skip the input-tile loads, 2 = the
+  // input-tile LDS stores, 4 = the weight DMA; 8 = consumers skip the MFMAs, 16 = the fragment reads, 32 = the per-tile
+  // epilogue (the accumulators stay live); 64 = every input tile addressed as an interior one, 128 = ... and read
+  // from the first tile's addresses (cache-hot)
+  constexpr int abl = MIMO_WIDE_ABLATE;
+#else
+  constexpr int abl = 0;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int TCP = TC + 2, TRP = TR + 2;
@@ -108,8 +121,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
   const int nphases = PARTS * nstages;
   const int rows_pad = coTiles * NB;  // packed weight rows per tap
 
+  if (FWD) {
+    // The epilogue's per-channel constants come from LDS: a global load in the epilogue would be waited for with
+    // vmcnt(0), which on this chip also waits for every output store in flight (stores count in vmcnt)
+    if (tid < NB) {
+      const int c = co0 + tid;
+      epi[tid] = c < a.cout_pad ? a.bias[c] : 0.f;
+      if (EPI) {
+        epi[NB + tid] = c < a.cout_store ? a.ep_scale[c] : 0.f;
+        epi[2 * NB + tid] = c < a.cout_store ? a.ep_shift[c] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+
   if (wave >= 4) {
     // =============================== producers ===============================
+    // The staging waves share their SIMD's issue port with an MFMA wave, so what they cost is their INSTRUCTION count
+    // (timing builds: with the MFMAs compiled out a phase of the first version took 0.95 us of producer instructions —
+    // per-phase scalar division chains decoding the stage, ~20 vector instructions of reflection / bounds arithmetic
+    // per 16-byte unit).  Everything that depends only on the tile is therefore computed once per tile: the byte offset
+    // of each unit's source pixel from the image base (reflected / clipped), its validity bit, the image base; a stage
+    // adds the chunk's byte offset.  The stage / phase bookkeeping is incremental (no divisions in the loop).
     const int ptid = tid - 256;
     f32x4 xreg[XU];
     const unsigned ws_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ws;
@@ -121,74 +154,115 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     for (int k = 0; k < WU; ++k) {
       const int u = min(ptid + k * 256, WUNITS - 1), row = u >> 2;
       const int tp = row / NB, ch = row - tp * NB;
-      wsrc[k] = (tp * rows_pad + ch) * 4 + ((u & 3) ^ ((ch >> 2) & 3));
+      wsrc[k] = ((tp * rows_pad + ch) * 4 + ((u & 3) ^ ((ch >> 2) & 3))) * 16;  // bytes from the phase's first row
     }
-    int u_rc[XU], u_off[XU];
+    const unsigned wdst0 = __builtin_amdgcn_readfirstlane(ws_lds + (unsigned)((ptid & ~63) * 16));  // this wave's 1 KB
+    int u_rc[XU];   // halo-tile coordinates of the thread's units: (row << 16) | column
+    int u_off[XU];  // current load tile: byte offset of the unit's source from the image base (chunk 0)
+    unsigned u_val = 0;  // ... bit k: the source pixel lies inside the image (data gradient; the forward reflects)
 #pragma unroll
     for (int k = 0; k < XU; ++k) {
-      const int u = ptid + k * 256;
-      const int p = min(u >> 2, npix_lds - 1);
+      const int p = min((ptid + k * 256) >> 2, npix_lds - 1);
       const int tr = p / TCP, tc = p - tr * TCP;
       u_rc[k] = (tr << 16) | tc;
-      // byte offset from the tile's first halo pixel (tiles whose halo lies inside the image)
-      u_off[k] = FWD ? ((tr * a.Wi + tc) * a.ldx + 4 * (u & 3)) * 4
-                     : (tr * a.Wi + tc) * a.ldx * 4 + ((u & 3) >> 1) * 64 + (u & 1) * 16;
+      u_off[k] = 0;
     }
-    const u32x4* wpk = reinterpret_cast<const u32x4*>(a.wpk);
-
-    // input units K0..K1 of stage STAGE = (tile STAGE / nchunks, chunk STAGE % nchunks) -> registers
-#define WD_LOAD_X(K0, K1, STAGE)                                                                     \
+    const int uq = ptid & 3;  // 16-byte slot of the thread's units within the LDS row (u & 3: 256 is a multiple of 4)
+    // byte offset of the unit within its pixel, full chunks: forward 4 channels x 4 B per slot; data gradient: 32-channel
+    // record [hi 32 | lo 32] bf16, the chunk's half adds 32 B per stage
+    const int uq_off = FWD ? 16 * uq : (uq >> 1) * 64 + (uq & 1) * 16;
+    const char* const wpk = reinterpret_cast<const char*>(a.wpk) + (size_t)co0 * 64;
+    const int wph_bytes = TPP * rows_pad * 64;  // weight bytes between consecutive phases of a tile
+    // ---- load stream: the stage whose input tile is being fetched (two stages ahead of the consumers) ----
+    int l_stage = 0, l_ck = 0, l_ti = 0;
+    const char* l_img = nullptr;  // image base of the load tile
+    int l_y0 = 0, l_x0 = 0;
+    bool l_new = true;            // the stage is the first of its tile: unit offsets are recomputed part by part
+#define WD_TILE(TI)                                                                                  \
   {                                                                                                  \
-    const int st_ = (STAGE);                                                                         \
-    const int ti_ = st_ / nchunks, ck_ = st_ - ti_ * nchunks;                                        \
-    int t_ = vbx + ti_ * gx;                                                                         \
+    int t_ = vbx + (TI) * gx;                                                                        \
     const int tx_ = t_ % tilesX;                                                                     \
     t_ /= tilesX;                                                                                    \
     const int ty_ = t_ % tilesY;                                                                     \
     const int n_ = t_ / tilesY;                                                                      \
-    const int y0_ = ty_ * TR - a.off, x0_ = tx_ * TC - a.off;                                        \
-    const float* ximg_ = a.x + (size_t)n_ * a.Hi * a.Wi * a.ldx;                                     \
-    /* forward: channels ck*16 .. +15 of the fp32 tensor; data gradient: half (ck & 1) of 32-channel record ck >> 1 */ \
-    const int rc_ = min(32, a.cin_p - (ck_ >> 1) * 32);                                              \
-    const bool full_ = FWD ? ck_ * 16 + 16 <= a.cin_p : rc_ == 32;                                   \
-    if (full_ && y0_ >= 0 && y0_ + TRP <= a.Hi && x0_ >= 0 && x0_ + TCP <= a.Wi) {                   \
-      /* halo inside the image, full chunk (wave-uniform): scalar tile base + per-thread constant */ \
-      const char* tb_ = reinterpret_cast<const char*>(ximg_ + ((size_t)y0_ * a.Wi + x0_) * a.ldx) +  \
-                        (FWD ? ck_ * 64 : (ck_ >> 1) * 128 + (ck_ & 1) * 32);                        \
-      _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_)                                         \
-        xreg[k_] = *reinterpret_cast<const f32x4*>(tb_ + u_off[k_]);                                 \
+    l_y0 = ty_ * TR - a.off;                                                                         \
+    l_x0 = tx_ * TC - a.off;                                                                         \
+    l_img = reinterpret_cast<const char*>(a.x + (size_t)n_ * a.Hi * a.Wi * a.ldx);                   \
+  }
+    // unit offsets K0..K1 of the load tile (first stage of a tile)
+#define WD_OFFS(K0, K1)                                                                              \
+  _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                           \
+    int iy_ = l_y0 + (u_rc[k_] >> 16), ix_ = l_x0 + (u_rc[k_] & 0xffff);                             \
+    if (FWD) { /* reflect padding */                                                                 \
+      iy_ = max(iy_, -iy_);                                                                          \
+      iy_ = max(min(iy_, 2 * a.Hi - 2 - iy_), 0);                                                    \
+      ix_ = max(ix_, -ix_);                                                                          \
+      ix_ = max(min(ix_, 2 * a.Wi - 2 - ix_), 0);                                                    \
+    } else { /* zero outside the image (transposed convolution) */                                   \
+      const bool in_ = iy_ >= 0 && iy_ < a.Hi && ix_ >= 0 && ix_ < a.Wi;                             \
+      u_val = in_ ? u_val | (1u << k_) : u_val & ~(1u << k_);                                        \
+      iy_ = in_ ? iy_ : 0;                                                                           \
+      ix_ = in_ ? ix_ : 0;                                                                           \
+    }                                                                                                \
+    u_off[k_] = (iy_ * a.Wi + ix_) * a.ldx * 4 + uq_off;                                             \
+  }
+    // input units K0..K1 of the load stage -> registers.  Masked-out units are LOADED from the zero page (common.h),
+    // never selected after the load.  A short last chunk takes the path with per-unit channel tests.
+#define WD_LOAD_X(K0, K1)                                                                            \
+  if (abl & 1) {                                                                                     \
+    _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) xreg[k_] = f32x4{1.f, 2.f, 3.f, 4.f};     \
+  } else {                                                                                           \
+    if (l_new) {                                                                                     \
+      WD_OFFS(K0, K1)                                                                                \
+    }                                                                                                \
+    const int rc_ = min(32, a.cin_p - (l_ck >> 1) * 32); /* data gradient: channels of the 32-channel record */ \
+    const bool full_ = FWD ? l_ck * 16 + 16 <= a.cin_p : rc_ == 32;                                  \
+    const char* b_ = l_img + (FWD ? l_ck * 64 : (l_ck >> 1) * 128 + (l_ck & 1) * 32);                \
+    if (full_) {                                                                                     \
+      _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                       \
+        if (FWD)                                                                                     \
+          xreg[k_] = *reinterpret_cast<const f32x4*>(b_ + u_off[k_]);                                \
+        else                                                                                         \
+          xreg[k_] = *reinterpret_cast<const f32x4*>(                                                \
+              (u_val >> k_) & 1 ? b_ + u_off[k_] : reinterpret_cast<const char*>(kZeroPage));        \
+      }                                                                                              \
     } else {                                                                                         \
       _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                       \
-        int iy_ = y0_ + (u_rc[k_] >> 16), ix_ = x0_ + (u_rc[k_] & 0xffff);                           \
-        bool in_ = true;                                                                             \
-        if (FWD) { /* reflect padding */                                                             \
-          iy_ = max(iy_, -iy_);                                                                      \
-          iy_ = max(min(iy_, 2 * a.Hi - 2 - iy_), 0);                                                \
-          ix_ = max(ix_, -ix_);                                                                      \
-          ix_ = max(min(ix_, 2 * a.Wi - 2 - ix_), 0);                                                \
-        } else { /* zero outside the image (transposed convolution) */                               \
-          in_ = iy_ >= 0 && iy_ < a.Hi && ix_ >= 0 && ix_ < a.Wi;                                    \
-        }                                                                                            \
-        const int q_ = (ptid + k_ * 256) & 3;                                                        \
-        const int o_ = in_ ? (iy_ * a.Wi + ix_) * a.ldx : 0;                                         \
-        /* masked-out units are LOADED from the zero page (common.h), never selected after the load */ \
         if (FWD) {                                                                                   \
-          const int ch_ = ck_ * 16 + 4 * q_;                                                         \
-          xreg[k_] = *reinterpret_cast<const f32x4*>(ch_ < a.cin_p ? ximg_ + o_ + ch_ : kZeroPage);  \
-        } else {                                                                                     \
-          const int e_ = (ck_ & 1) * 16 + (q_ & 1) * 8; /* first channel of the unit within its 32-channel record */ \
-          const unsigned short* s_ = reinterpret_cast<const unsigned short*>(ximg_ + o_) +           \
-                                     ((ck_ >> 1) * 64 + (q_ >> 1) * rc_ + e_);                       \
-          xreg[k_] = *reinterpret_cast<const f32x4*>(in_ && e_ < rc_ ? reinterpret_cast<const float*>(s_) : kZeroPage); \
+          const bool ok_ = l_ck * 16 + 4 * uq < a.cin_p;                                             \
+          xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? b_ + u_off[k_] : reinterpret_cast<const char*>(kZeroPage)); \
+        } else { /* record [hi rc | lo rc]: the lo half sits rc, not 32, elements behind the hi half */ \
+          const int e_ = (l_ck & 1) * 16 + (uq & 1) * 8;                                             \
+          const bool ok_ = ((u_val >> k_) & 1) && e_ < rc_;                                          \
+          xreg[k_] = *reinterpret_cast<const f32x4*>(                                                \
+              ok_ ? b_ + u_off[k_] + (uq >> 1) * (rc_ - 32) * 2 : reinterpret_cast<const char*>(kZeroPage)); \
         }                                                                                            \
       }                                                                                              \
     }                                                                                                \
   }
+    // the load stream moves on to the next stage (stays on the last one past the end)
+#define WD_NEXT_STAGE()                                                                              \
+  {                                                                                                  \
+    l_new = false;                                                                                   \
+    if (l_stage + 1 < nstages) {                                                                     \
+      ++l_stage;                                                                                     \
+      if (++l_ck == nchunks) {                                                                       \
+        l_ck = 0;                                                                                    \
+        ++l_ti;                                                                                      \
+        l_new = true;                                                                                \
+        WD_TILE(l_ti)                                                                                \
+      }                                                                                              \
+    }                                                                                                \
+  }
 #define WD_STORE_X(K0, K1, BUF)                                                                      \
-  _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                           \
-    const int u_ = ptid + k_ * 256;                                                                  \
-    const int p_ = u_ >> 2, q_ = u_ & 3;                                                             \
-    if (p_ < npix_lds) {                                                                             \
+  if (abl & 2) {                                                                                     \
+    _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) asm volatile("" ::"v"(xreg[k_]));         \
+  } else _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                    \
+    const int p_ = (ptid + k_ * 256) >> 2;                                                           \
+    /* UNCONDITIONAL: rows [npix_lds, 640) are slack nobody reads.  A store skipped by a branch leaves its load    \
+       un-waited on that path, and hipcc then drains the whole queue (vmcnt(0)) before it reuses the register —   \
+       every phase, which collapsed the prefetch depth to zero (found in the ISA) */                              \
+    {                                                                                                \
       const f32x4 v_ = xreg[k_];                                                                     \
       unsigned char* row_ = xs + (BUF) * kXBytes + p_ * kXPitch;                                     \
       if (FWD) {                                                                                     \
@@ -201,41 +275,57 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
         lo_[1] = (_Float16)(v_[1] - (float)hi_[1]);                                                  \
         lo_[2] = (_Float16)(v_[2] - (float)hi_[2]);                                                  \
         lo_[3] = (_Float16)(v_[3] - (float)hi_[3]);                                                  \
-        *reinterpret_cast<f16x4_t*>(row_ + q_ * 8) = hi_;                                            \
-        *reinterpret_cast<f16x4_t*>(row_ + 32 + q_ * 8) = lo_;                                       \
+        *reinterpret_cast<f16x4_t*>(row_ + uq * 8) = hi_;                                            \
+        *reinterpret_cast<f16x4_t*>(row_ + 32 + uq * 8) = lo_;                                       \
       } else {                                                                                       \
-        *reinterpret_cast<f32x4*>(row_ + q_ * 16) = v_;                                              \
+        *reinterpret_cast<f32x4*>(row_ + uq * 16) = v_;                                              \
       }                                                                                              \
     }                                                                                                \
   }
-    // weights of global phase PH (stage PH / PARTS, part PH % PARTS) -> weight buffer BUF, by LDS-DMA.  Inline asm, not
-    // the builtin: with a DMA it knows of in flight hipcc waits vmcnt(0) in front of every use of an ordinary load
-    // (conv_bf16x3.hip WS_DMA_W).  M0 = LDS byte address of lane 0, saved and restored inside the statement.
-#define WD_DMA_W(BUF, PH)                                                                            \
+    // ---- weight stream: phases in consumer order; w_src walks the packed image of the channel tile, back to its start
+    // at every tile.  LDS-DMA by inline asm, not the builtin: with a DMA it knows of in flight hipcc waits vmcnt(0) in
+    // front of every use of an ordinary load (conv_bf16x3.hip WS_DMA_W).  M0 = LDS byte address of the wave's first
+    // lane, saved and restored inside the statement.
+    int w_ph = 0, w_pht = 0;  // phase index of the next DMA, its index within the tile
+    const char* w_src = wpk;
+    const int pht_n = PARTS * nchunks;
+#define WD_DMA_W(BUF)                                                                                \
   {                                                                                                  \
-    const int phw_ = (PH);                                                                           \
-    const int ck_ = (phw_ / PARTS) % nchunks, r_ = phw_ % PARTS;                                     \
-    const u32x4* src_ = wpk + ((size_t)(ck_ * 9 + r_ * TPP) * rows_pad + co0) * 4;                   \
-    _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                              \
-      const unsigned dst_ = __builtin_amdgcn_readfirstlane(                                          \
-          ws_lds + (unsigned)((BUF) * WPHB + (k_ * 256 + (ptid & ~63)) * 16));                       \
-      unsigned keep_;                                                                                \
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                   : "=&s"(keep_) : "v"(src_ + wsrc[k_]), "s"(dst_) : "memory");                     \
+    if (!(abl & 4)) {                                                                                \
+      _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                            \
+        const unsigned dst_ = wdst0 + (unsigned)((BUF) * WPHB + k_ * 4096);                          \
+        unsigned keep_;                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(w_src + wsrc[k_]), "s"(dst_) : "memory");                  \
+      }                                                                                              \
+    }                                                                                                \
+    if (w_ph + 1 < nphases) { /* past the end: the last phase's weights again, into a buffer nobody reads */ \
+      ++w_ph;                                                                                        \
+      w_src += wph_bytes;                                                                            \
+      if (++w_pht == pht_n) {                                                                        \
+        w_pht = 0;                                                                                   \
+        w_src = wpk;                                                                                 \
+      }                                                                                              \
     }                                                                                                \
   }
     // all vector-memory operations but the N youngest are done; LDS stores retired; phase barrier
-#define WD_WAIT_BAR(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#define WD_WAIT_BAR(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"((abl & 5) ? 0 : (N)) : "memory");
 
     // ---- prologue: stage 0 in input buffer 0, weights of phase 0 (and 1) on their way; input of stage 1 in registers
-    WD_LOAD_X(0, XU, 0)
-    WD_DMA_W(0, 0)
+    WD_TILE(0)
+    WD_LOAD_X(0, XU)
+    WD_DMA_W(0)
     if (NWB == 3) {
-      WD_DMA_W(1, min(1, nphases - 1))
+      WD_DMA_W(1)
     }
     WD_STORE_X(0, XU, 0)
-    WD_LOAD_X(0, XU, min(1, nstages - 1))
-    WD_WAIT_BAR(XU)  // every DMA above is older than these XU loads
+    WD_NEXT_STAGE()
+    WD_LOAD_X(0, XU)
+    // Every load of the prologue is waited for HERE, visibly to the compiler: the loop's first consumer of a register
+    // is otherwise waited for with the count that is safe on the path from the prologue too — vmcnt(0) if that
+    // register was the prologue's last load — once per loop iteration (found in the ISA)
+    _Pragma("unroll") for (int k_ = 0; k_ < XU; ++k_) asm volatile("" ::"v"(xreg[k_]));
+    WD_WAIT_BAR(0)
     // ---- phase (j, R): store part R of stage j + 1 into the input buffer the consumers released at the start of stage
     // j, start the DMA of a later phase's weights into the buffer released at the last barrier, refill the registers
     // with part R of stage j + 2.  Straight-line: past the end the loads re-read the last stage and the stores / DMAs
@@ -243,15 +333,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     int wslot = NWB == 3 ? 2 : 1;  // buffer of the next DMA = (ph + NWB - 1) % NWB
     for (int j = 0; j < nstages; ++j) {
       const int xb = (j + 1) & 1;
+      WD_NEXT_STAGE()  // the load stream: stage j + 2
 #define WD_PHASE(R)                                                                                  \
   {                                                                                                  \
-    const int ph_ = PARTS * j + (R);                                                                 \
-    WD_STORE_X((R) * XP, ((R) + 1) * XP, xb)                                                         \
-    WD_DMA_W(wslot, min(ph_ + NWB - 1, nphases - 1))                                                 \
+    WD_STORE_X(XK0(R), XK0((R) + 1), xb)                                                             \
+    WD_DMA_W(wslot)                                                                                  \
     wslot = wslot + 1 == NWB ? 0 : wslot + 1;                                                        \
-    WD_LOAD_X((R) * XP, ((R) + 1) * XP, min(j + 2, nstages - 1))                                     \
-    /* three buffers: the weights of phase ph + 1 were issued one phase ago, in front of that phase's XP loads */ \
-    WD_WAIT_BAR(NWB == 3 ? XP + WU + XP : XP)                                                        \
+    WD_LOAD_X(XK0(R), XK0((R) + 1))                                                                  \
+    /* three buffers: the weights of phase ph + 1 were issued one phase ago, in front of that phase's input loads */ \
+    WD_WAIT_BAR(NWB == 3 ? XKN(((R) + 2) % 3) + WU + XKN(R) : XKN(R))                                \
   }
       WD_PHASE(0)
       if (PARTS == 3) {
@@ -260,10 +350,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       }
 #undef WD_PHASE
     }
+#undef WD_TILE
+#undef WD_OFFS
+#undef WD_NEXT_STAGE
 #undef WD_LOAD_X
 #undef WD_STORE_X
 #undef WD_DMA_W
 #undef WD_WAIT_BAR
+#undef XK0
+#undef XKN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs past the end still target this workgroup's LDS
     if (STATS) __syncthreads();                       // the consumers combine their BatchNorm sums through LDS
     return;
@@ -308,21 +403,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
 
   // weights of tap T (within the phase) -> register set WS_
 #define WC_READ_W(WS_, T)                                                                            \
-  _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
+  if (!(abl & 16)) _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
     wf[WS_][nf][0] = *reinterpret_cast<const V8*>(wb_ + ((T) * NB + nf * 32) * 64 + w_hi);           \
     wf[WS_][nf][1] = *reinterpret_cast<const V8*>(wb_ + ((T) * NB + nf * 32) * 64 + w_lo);           \
   }
   // pixel fragments of slot S, tap T -> register set AS_.  Tap T of a phase: TPP = 3: (tap row of the phase, T);
   // TPP = 9: (T / 3, T % 3)
 #define WC_READ_A(AS_, T, S)                                                                         \
-  _Pragma("unroll") for (int i = 0; i < SM; ++i) {                                                   \
+  if (!(abl & 16)) _Pragma("unroll") for (int i = 0; i < SM; ++i) {                                                   \
     const unsigned char* p_ = xb_ + pbase[(S) * SM + i] +                                            \
                               (TPP == 3 ? ro_ + (T) * kXPitch : ((T) / 3) * row1 + ((T) % 3) * kXPitch); \
     af[AS_][i][0] = *reinterpret_cast<const V8*>(p_);                                                \
     af[AS_][i][1] = *reinterpret_cast<const V8*>(p_ + 32);                                           \
   }
 #define WC_MFMA(AS_, WS_, S)                                                                         \
-  _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                     \
+  if (abl & 8) {                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < SM; ++i) {                                                 \
+      asm volatile("" ::"v"(af[AS_][i][0]), "v"(af[AS_][i][1]));                                     \
+    }                                                                                                \
+    _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                              \
+      asm volatile("" ::"v"(wf[WS_][nf][0]), "v"(wf[WS_][nf][1]));                                   \
+    }                                                                                                \
+  } else _Pragma("unroll") for (int i = 0; i < SM; ++i)                                              \
     _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                              \
       acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][0], af[AS_][i][1], acc[(S) * SM + i][nf]);          \
       acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][1], af[AS_][i][0], acc[(S) * SM + i][nf]);          \
@@ -349,16 +451,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     _Pragma("unroll") for (int m = 0; m < MF; ++m) {                                                 \
       const int oy = y0_ + (prc[m] >> 16), ox = x0_ + (prc[m] & 0xffff);                             \
       yo_[m] = (oy < a.Ho && ox < a.Wo) ? (oy * a.Wo + ox) * a.ldy : -1;                             \
+      if (abl & 32) yo_[m] = (acc[m][0][0] + acc[m][NF - 1][15] == 12345.678f) ? yo_[m] : -1;        \
     }                                                                                                \
     _Pragma("unroll") for (int nf = 0; nf < NF; ++nf)                                                \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
         const int c_ = co0 + nf * 32 + 8 * j + 4 * h;                                                \
         f32x4 b_ = f32x4{0.f, 0.f, 0.f, 0.f}, esc_ = b_, esh_ = b_, emk_ = f32x4{1.f, 1.f, 1.f, 1.f}; \
-        if (FWD && c_ < a.cout_pad) b_ = *reinterpret_cast<const f32x4*>(a.bias + c_);               \
-        if (EPI && c_ < a.cout_store) {                                                              \
-          esc_ = *reinterpret_cast<const f32x4*>(a.ep_scale + c_);                                   \
-          esh_ = *reinterpret_cast<const f32x4*>(a.ep_shift + c_);                                   \
-          if (a.ep_mask)                                                                             \
+        if (FWD) b_ = *reinterpret_cast<const f32x4*>(epi + c_ - co0);                               \
+        if (EPI) {                                                                                   \
+          esc_ = *reinterpret_cast<const f32x4*>(epi + NB + c_ - co0);                               \
+          esh_ = *reinterpret_cast<const f32x4*>(epi + 2 * NB + c_ - co0);                           \
+          if (a.ep_mask && c_ < a.cout_store)                                                        \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                         \
               if (c_ + i_ < a.ep_mask_ld) emk_[i_] = a.ep_mask[(size_t)n_ * a.ep_mask_ld + c_ + i_]; \
         }                                                                                            \

@@ -72,18 +72,22 @@ static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, 
   const int nf = (r32 >= 2 && double(rup(r32, 2)) / r32 <= 1.10 + 1e-9) ? 2 : 1;
   const int cotiles = cdiv(r32, nf);
   if (force == 0) {
-    // padded MFMA work of both decompositions relative to the logical work: the 256-pixel kernel pads K to 32
-    // (tap pairing: a <= 16-channel tail costs 2/3 of a chunk) and the channels to 16
+    // Cost of both decompositions in padded-MFMA units, constants fitted to per-layer timings of cfg3 at batch 32
+    // (profiles/r03/conv_layers_ab.txt; the rule loses 0.3 % against picking the faster kernel per layer):
+    //   wide:      K padded to 16, channels to 32 * nf, / tile efficiency, x (1 + a / K chunks): the per-tile epilogue
+    //              and pipeline fill, a = 1.2 (64-channel tiles) / 0.2 (32-channel tiles, one barrier per chunk)
+    //   256-pixel: K padded to 32 (tap pairing: a <= 16-channel tail costs 2/3 of a chunk), channels to 16, x 1.15
+    //              (its matrix pipe is ~15 % less busy)
     const int k16 = rup(cin_p, 16);
     int TRo, TCo;
     pick_tile_n(Ho, Wo, 256, 360, &TRo, &TCo);
     const double eff_o = double(Ho) * Wo / (double(cdiv(Ho, TRo)) * cdiv(Wo, TCo) * 256);
     const int tail = cin_p - 32 * (cdiv(cin_p, 32) - 1);
     const double k_o = 32.0 * (cdiv(cin_p, 32) - 1) + (tail <= 16 ? 64.0 / 3.0 : 32.0);
-    const double work_w = double(k16) * (cotiles * nf * 32) / eff;
-    const double work_o = k_o * rup(rows, 16) / eff_o;
-    // the wide kernel must fill the chip (persistent, one workgroup per CU) and not pad away its advantage (~25 %)
-    if (tiles * cotiles < 192 || work_w > 1.20 * work_o) return c;
+    const double t_w = double(k16) * (cotiles * nf * 32) / eff * (1.0 + (nf == 2 ? 1.2 : 0.2) / (k16 / 16));
+    const double t_o = 1.15 * k_o * rup(rows, 16) / eff_o;
+    // the wide kernel is persistent with one workgroup per CU: it needs enough (pixel tile, channel tile) pairs
+    if (tiles * cotiles < 128 || t_w >= t_o) return c;
   }
   c.nf = nf;
   c.rows_pad = cotiles * nf * 32;
