@@ -58,7 +58,7 @@ struct WideCfg {
 // Which decomposition a split16 3x3 convolution runs on.  `rows` = output channels of the launch (forward: Cout;
 // data gradient: the layer's padded input channels), Ho x Wo its output domain.
 // force: -1 = never, 0 = by the cost rule, 1 = whenever the geometry is supported.
-static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, int Wo, int force) {
+static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, int Wo, int force, int nf_force = 0) {
   WideCfg c{0, 0, 0, 0};
   if (force < 0 || mode < 0 || mode > 1 || rows < 1 || cin_p < 16 || Ho < 2 || Wo < 2) return c;
   int TR, TC;
@@ -69,7 +69,7 @@ static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, 
   const int r32 = cdiv(rows, 32);
   // channel-tile width: two 32-channel tiles per workgroup unless the padding that costs exceeds what the second tile's
   // reuse of the staged input is worth (~10 %)
-  const int nf = (r32 >= 2 && double(rup(r32, 2)) / r32 <= 1.10 + 1e-9) ? 2 : 1;
+  const int nf = nf_force ? nf_force : (r32 >= 2 && double(rup(r32, 2)) / r32 <= 1.10 + 1e-9) ? 2 : 1;
   const int cotiles = cdiv(r32, nf);
   if (force == 0) {
     // Cost of both decompositions in padded-MFMA units, constants fitted to per-layer timings of cfg3 at batch 32
