@@ -96,7 +96,8 @@ size_t conv3x3_wide_weight_elems(int cin_p, int rows_pad);  // 16-bit elements o
 int conv3x3_wide_stat_rows();
 int conv3x3_wide_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t stream);
 int pack_weights_wide_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
-                             const int* row_map, const int* col_map, int nrows_map, int transposed, hipStream_t stream);
+                             const int* row_map, const int* col_map, int nrows_map, int transposed, hipStream_t stream,
+                             int single = 0);
 int conv3x3_pick_nfrag(int cout);            // fragments (of 16 output channels) per workgroup
 int conv3x3_cout_pad(int cout);              // packed weight rows for that choice
 int conv3x3_stat_rows(int N, int Ho, int Wo);  // spatial workgroups == partial-stat rows
@@ -157,8 +158,9 @@ int wgrad_reduce_blocks(int cin_pad, int cout_pad);  // workgroups one layer nee
 // All weight repacks of a step in ONE launch (a per-layer launch each cost more in dispatch gaps than in
 // work): a device table of jobs, blockIdx.y = job.  kind 0: fp32 [tap][rows_pad][cols]; 1 / 2: fp16 / bf16
 // (hi, lo) pairs [chunk][tap][rows_pad][hi 32 | lo 32]; 3 / 4: fp16 / bf16 pairs in the wide kernel's layout
-// [16-channel chunk][tap][rows_pad][hi 16 | lo 16] (rows beyond map_rows are zero); bias_n > 0 additionally copies the
-// layer's bias.
+// [16-channel chunk][tap][rows_pad][hi 16 | lo 16]; 5 / 6: fp16 (x 2^8) / bf16 single values in the wide kernel's
+// 16-bit storage layout [32-channel chunk][tap][rows_pad][32] (kinds 3-6: rows beyond map_rows are zero); bias_n > 0
+// additionally copies the layer's bias.
 struct PackJob {
   int64_t w_off, bias_off;  // float offsets into the bound parameter buffer
   void* dst;

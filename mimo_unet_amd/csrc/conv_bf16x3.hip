@@ -1219,6 +1219,12 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
     if (j.kind == 0) {
       col = i % j.cols;
       row = i / j.cols;
+    } else if (j.kind >= 5) {  // wide layout, 16-bit storage modes: 32-channel chunks of single values
+      k = i & 31;
+      const int rest = i >> 5;
+      row = rest % j.rows_pad;
+      chunk = rest / j.rows_pad;
+      col = chunk * 32 + k;
     } else if (j.kind >= 3) {  // wide layout: 16-channel chunks
       k = i & 15;
       const int rest = i >> 4;
@@ -1253,6 +1259,10 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
       if (paired) pair_slot(tap, k, &slot, &kk);
       if (j.kind == 0) {
         reinterpret_cast<float*>(j.dst)[((size_t)tap * j.rows_pad + row) * j.cols + col] = x;
+      } else if (j.kind == 5) {
+        reinterpret_cast<_Float16*>(j.dst)[(((size_t)chunk * 9 + tap) * j.rows_pad + row) * 32 + k] = (_Float16)(x * kF16WeightScale);
+      } else if (j.kind == 6) {
+        reinterpret_cast<__bf16*>(j.dst)[(((size_t)chunk * 9 + tap) * j.rows_pad + row) * 32 + k] = (__bf16)x;
       } else if (j.kind == 3) {
         const float xs = x * kF16WeightScale;
         const _Float16 hi = (_Float16)xs, lo = (_Float16)(xs - (float)hi);

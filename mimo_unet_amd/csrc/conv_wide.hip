@@ -67,18 +67,27 @@ constexpr int kXBytes = kMaxPix * kXPitch;  // 51200
 
 // MODE 0: data gradient (bf16 pairs, input = pre-split dz records [hi rc | lo rc] per 32-channel chunk)
 // MODE 1: forward (fp16 pairs, fp32 input split on the way into LDS; bias, BatchNorm sums, inference epilogue)
+// MODE 4 / 5: bf16-mixed forward / data gradient; MODE 6 / 7: fp16-mixed (mimo_precision *_MIXED: activations and
+//   gradients stored as plain NHWC 16-bit tensors).  One MFMA per product; the 64-byte LDS row then holds 32 channels
+//   of ONE value each where the split modes hold [hi 16 | lo 16], a chunk is 32 channels = two K = 16 MFMA steps on
+//   the row's two halves, the loaders are 16-byte copies, the output is rounded once in the epilogue.
 // NF: 32-channel tiles per workgroup; TPP: taps per phase (3 = one tap row, 9 = a whole chunk)
 // EPI (forward): the inference epilogue — eval-mode BatchNorm + ReLU (+ Dropout2d multipliers) folded into the store, no
 // statistics; else bias + BatchNorm partial sums
 template <int NF, int MODE, int TPP, bool EPI>
 __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX,
                                                                 int numTiles, int gx, int coTiles) {
-  static_assert(MODE == 0 || MODE == 1, "split16 modes");
+  static_assert(MODE == 0 || MODE == 1 || (MODE >= 4 && MODE <= 7), "split16 and 16-bit storage modes");
   static_assert((NF == 2 && TPP == 3) || (NF == 1 && TPP == 9), "instances: 64 channels x tap rows, 32 channels x chunks");
-  constexpr bool FWD = MODE == 1;
+  constexpr bool FWD = MODE == 1 || MODE == 4 || MODE == 6;
+  constexpr bool S16 = MODE >= 4;                 // 16-bit storage: plain 16-bit input and output, one MFMA per product
+  constexpr bool F16 = MODE == 1 || MODE >= 6;    // element type fp16 (else bf16); fp16 forward weights carry x 2^8
+  constexpr bool CVT = MODE == 1;                 // the loader splits fp32 input into fp16 (hi, lo)
+  constexpr int CKC = S16 ? 32 : 16;              // input channels per chunk
   constexpr bool STATS = FWD && !EPI;
   static_assert(FWD || !EPI, "the inference epilogue belongs to the forward");
-  typedef typename std::conditional<FWD, f16x8_t, bf16x8_t>::type V8;
+  typedef typename std::conditional<F16, f16x8_t, bf16x8_t>::type V8;
+  typedef typename std::conditional<F16, _Float16, __bf16>::type ET;
   constexpr int NB = NF * 32;
   constexpr int MF = 4;                      // 32-pixel fragments per consumer wave
   constexpr int SM = NF == 1 ? 2 : 1;        // fragments per software-pipeline slot (6 MFMAs per slot)
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
   const int lane = tid & 63, wave = tid >> 6;
   const int TCP = TC + 2, TRP = TR + 2;
   const int npix_lds = TRP * TCP, npix_out = TR * TC;
-  const int nchunks = (a.cin_p + 15) / 16;
+  const int nchunks = (a.cin_p + CKC - 1) / CKC;
   const int v_ = xcd_virtual_index((int)blockIdx.x, gx * coTiles);
   const int vbx = v_ / coTiles;
   const int co0 = (v_ - vbx * coTiles) * NB;
@@ -170,7 +179,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     const int uq = ptid & 3;  // 16-byte slot of the thread's units within the LDS row (u & 3: 256 is a multiple of 4)
     // byte offset of the unit within its pixel, full chunks: forward 4 channels x 4 B per slot; data gradient: 32-channel
     // record [hi 32 | lo 32] bf16, the chunk's half adds 32 B per stage
-    const int uq_off = FWD ? 16 * uq : (uq >> 1) * 64 + (uq & 1) * 16;
+    const int uq_off = (CVT || S16) ? 16 * uq : (uq >> 1) * 64 + (uq & 1) * 16;
+    const int esz = S16 ? 2 : 4;  // bytes per element of the input tensor (ldx counts elements)
     const char* const wpk = reinterpret_cast<const char*>(a.wpk) + (size_t)co0 * 64;
     const int wph_bytes = TPP * rows_pad * 64;  // weight bytes between consecutive phases of a tile
     // ---- load stream: the stage whose input tile is being fetched (two stages ahead of the consumers) ----
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     const int n_ = t_ / tilesY;                                                                      \
     l_y0 = ty_ * TR - a.off;                                                                         \
     l_x0 = tx_ * TC - a.off;                                                                         \
-    l_img = reinterpret_cast<const char*>(a.x + (size_t)n_ * a.Hi * a.Wi * a.ldx);                   \
+    l_img = reinterpret_cast<const char*>(a.x) + (size_t)n_ * a.Hi * a.Wi * a.ldx * esz;             \
   }
     // unit offsets K0..K1 of the load tile (first stage of a tile)
 #define WD_OFFS(K0, K1)                                                                              \
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       iy_ = in_ ? iy_ : 0;                                                                           \
       ix_ = in_ ? ix_ : 0;                                                                           \
     }                                                                                                \
-    u_off[k_] = (iy_ * a.Wi + ix_) * a.ldx * 4 + uq_off;                                             \
+    u_off[k_] = (iy_ * a.Wi + ix_) * a.ldx * esz + uq_off;                                           \
   }
     // input units K0..K1 of the load stage -> registers.  Masked-out units are LOADED from the zero page (common.h),
     // never selected after the load.  A short last chunk takes the path with per-unit channel tests.
@@ -215,9 +225,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     if (l_new) {                                                                                     \
       WD_OFFS(K0, K1)                                                                                \
     }                                                                                                \
-    const int rc_ = min(32, a.cin_p - (l_ck >> 1) * 32); /* data gradient: channels of the 32-channel record */ \
-    const bool full_ = FWD ? l_ck * 16 + 16 <= a.cin_p : rc_ == 32;                                  \
-    const char* b_ = l_img + (FWD ? l_ck * 64 : (l_ck >> 1) * 128 + (l_ck & 1) * 32);                \
+    const int rc_ = min(32, a.cin_p - (l_ck >> 1) * 32); /* split16 data gradient: channels of the 32-channel record */ \
+    /* a unit = 16 bytes of one pixel: 4 fp32 channels (split16 forward), 8 16-bit channels (16-bit storage), 8 bf16  \
+       values of a pair record's hi or lo half (split16 data gradient) */                              \
+    const bool full_ = (CVT || S16) ? l_ck * CKC + CKC <= a.cin_p : rc_ == 32;                       \
+    const char* b_ = l_img + ((CVT || S16) ? l_ck * 64 : (l_ck >> 1) * 128 + (l_ck & 1) * 32);       \
     if (full_) {                                                                                     \
       _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                       \
         if (FWD)                                                                                     \
@@ -228,8 +240,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       }                                                                                              \
     } else {                                                                                         \
       _Pragma("unroll") for (int k_ = (K0); k_ < (K1); ++k_) {                                       \
-        if (FWD) {                                                                                   \
-          const bool ok_ = l_ck * 16 + 4 * uq < a.cin_p;                                             \
+        if (CVT || S16) {                                                                            \
+          const bool ok_ = (FWD || ((u_val >> k_) & 1)) && l_ck * CKC + (CKC / 4) * uq < a.cin_p;    \
           xreg[k_] = *reinterpret_cast<const f32x4*>(ok_ ? b_ + u_off[k_] : reinterpret_cast<const char*>(kZeroPage)); \
         } else { /* record [hi rc | lo rc]: the lo half sits rc, not 32, elements behind the hi half */ \
           const int e_ = (l_ck & 1) * 16 + (uq & 1) * 8;                                             \
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     {                                                                                                \
       const f32x4 v_ = xreg[k_];                                                                     \
       unsigned char* row_ = xs + (BUF) * kXBytes + p_ * kXPitch;                                     \
-      if (FWD) {                                                                                     \
+      if (CVT) {                                                                                     \
         f16x4_t hi_, lo_;                                                                            \
         hi_[0] = (_Float16)v_[0];                                                                    \
         hi_[1] = (_Float16)v_[1];                                                                    \
@@ -426,8 +438,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     }                                                                                                \
   } else _Pragma("unroll") for (int i = 0; i < SM; ++i)                                              \
     _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                              \
-      acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][0], af[AS_][i][1], acc[(S) * SM + i][nf]);          \
-      acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][1], af[AS_][i][0], acc[(S) * SM + i][nf]);          \
+      if (S16) { /* the row's halves are channels 0-15 and 16-31 of the chunk */                     \
+        acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][1], af[AS_][i][1], acc[(S) * SM + i][nf]);        \
+      } else { /* (hi, lo) pairs: lo.hi + hi.lo + hi.hi */                                           \
+        acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][0], af[AS_][i][1], acc[(S) * SM + i][nf]);        \
+        acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][1], af[AS_][i][0], acc[(S) * SM + i][nf]);        \
+      }                                                                                              \
       acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][0], af[AS_][i][0], acc[(S) * SM + i][nf]);          \
     }
   // order of a slot pinned for the scheduler: its LDS reads (of the NEXT slot's fragments), then its MFMAs — left
@@ -435,9 +451,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
   // eats the LDS latency per fragment
 #define WC_PIN(NREADS)                                                                               \
   __builtin_amdgcn_sched_group_barrier(0x100, (NREADS), 0);                                          \
-  __builtin_amdgcn_sched_group_barrier(0x008, 3 * SM * NF, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, (S16 ? 2 : 3) * SM * NF, 0);
   // bias, store, BatchNorm partial sums of tile TI (accumulators complete), then clear them
-  typedef float OT;
+  typedef typename std::conditional<S16, ET, float>::type OT;  // element type of the output tensor
+  typedef ET et4 __attribute__((ext_vector_type(4)));
 #define WC_EPILOGUE(TI)                                                                              \
   {                                                                                                  \
     int t_ = vbx + (TI) * gx;                                                                        \
@@ -468,7 +485,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
         f32x4 t4_ = f32x4{0.f, 0.f, 0.f, 0.f}, q4_ = t4_;                                            \
         _Pragma("unroll") for (int m = 0; m < MF; ++m) {                                             \
           f32x4 v = f32x4{acc[m][nf][4 * j], acc[m][nf][4 * j + 1], acc[m][nf][4 * j + 2], acc[m][nf][4 * j + 3]}; \
-          if (FWD) v = v * (1.f / kWideF16Scale) + b_;                                               \
+          if (F16) v = v * (1.f / kWideF16Scale); /* fp16 weights are packed x 2^8 */                \
+          if (FWD) v = v + b_;                                                                       \
           if (EPI) {                                                                                 \
             if (a.status && yo_[m] >= 0 && !(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]))) \
               atomicOr(a.status, 1);                                                                 \
@@ -476,7 +494,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
               v[i_] = fmaxf(fmaf(v[i_], esc_[i_], esh_[i_]), 0.f) * emk_[i_];                        \
           }                                                                                          \
           if (yo_[m] >= 0) {                                                                         \
-            if (c_ < a.cout_store) *reinterpret_cast<f32x4*>(yimg_ + yo_[m] + nf * 32 + 8 * j) = v;  \
+            if (c_ < a.cout_store) {                                                                 \
+              if (S16) {                                                                             \
+                et4 o_;                                                                              \
+                o_[0] = (ET)v[0];                                                                    \
+                o_[1] = (ET)v[1];                                                                    \
+                o_[2] = (ET)v[2];                                                                    \
+                o_[3] = (ET)v[3];                                                                    \
+                *reinterpret_cast<et4*>(yimg_ + yo_[m] + nf * 32 + 8 * j) = o_;                      \
+              } else {                                                                               \
+                *reinterpret_cast<f32x4*>(yimg_ + yo_[m] + nf * 32 + 8 * j) = v;                     \
+              }                                                                                      \
+            }                                                                                        \
             if (STATS) {                                                                             \
               t4_ += v;                                                                              \
               q4_ += v * v;                                                                          \
@@ -639,49 +668,65 @@ int conv3x3_wide_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t st
 #define WIDE_LAUNCH(NF_, MODE_, TPP_, EPI_)                                                                        \
   hipLaunchKernelGGL((conv3x3_wide_kernel<NF_, MODE_, TPP_, EPI_>), grid, dim3(512), 0, stream, a, c.TR, c.TC, tilesY, \
                      tilesX, numTiles, gx, coTiles)
-  if (mode == 1) {
-    if (!a.bias || (a.ep_scale ? (a.stats || !a.ep_shift) : !a.stats)) {
-      set_error("conv3x3 wide forward: bias plus either the statistics rows or the inference epilogue");
-      return MIMO_ERR_INVALID;
-    }
-    if (a.ep_scale) {
-      if (c.nf == 2)
-        WIDE_LAUNCH(2, 1, 3, true);
-      else
-        WIDE_LAUNCH(1, 1, 9, true);
-    } else {
-      if (c.nf == 2)
-        WIDE_LAUNCH(2, 1, 3, false);
-      else
-        WIDE_LAUNCH(1, 1, 9, false);
-    }
-  } else {
-    if (c.nf == 2)
-      WIDE_LAUNCH(2, 0, 3, false);
-    else
-      WIDE_LAUNCH(1, 0, 9, false);
+  const bool fwd = mode == 1 || mode == 4 || mode == 6;
+  if (fwd && (!a.bias || (a.ep_scale ? (a.stats || !a.ep_shift) : !a.stats))) {
+    set_error("conv3x3 wide forward: bias plus either the statistics rows or the inference epilogue");
+    return MIMO_ERR_INVALID;
   }
+  if (mode >= 4 && (a.ldx % 8 != 0 || a.cin_p % 8 != 0)) {
+    set_error("conv3x3 wide, 16-bit storage: channel counts must be multiples of 8");
+    return MIMO_ERR_INVALID;
+  }
+#define WIDE_FWD(MODE_)            \
+  if (a.ep_scale) {                \
+    if (c.nf == 2)                 \
+      WIDE_LAUNCH(2, MODE_, 3, true);  \
+    else                           \
+      WIDE_LAUNCH(1, MODE_, 9, true);  \
+  } else {                         \
+    if (c.nf == 2)                 \
+      WIDE_LAUNCH(2, MODE_, 3, false); \
+    else                           \
+      WIDE_LAUNCH(1, MODE_, 9, false); \
+  }
+#define WIDE_DG(MODE_)             \
+  if (c.nf == 2)                   \
+    WIDE_LAUNCH(2, MODE_, 3, false);   \
+  else                             \
+    WIDE_LAUNCH(1, MODE_, 9, false);
+  switch (mode) {
+    case 1: WIDE_FWD(1) break;
+    case 4: WIDE_FWD(4) break;
+    case 6: WIDE_FWD(6) break;
+    case 0: WIDE_DG(0) break;
+    case 5: WIDE_DG(5) break;
+    default: WIDE_DG(7) break;
+  }
+#undef WIDE_FWD
+#undef WIDE_DG
 #undef WIDE_LAUNCH
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
 
-// weight packing: torch OIHW -> [chunk of 16 input channels][tap][rows_pad][hi 16 | lo 16] 16-bit (64-byte rows).
-// Element formulas as pack_weights_bf16x3_kernel (conv_bf16x3.hip): row / column maps, transposed = data gradient.
-template <bool F16>
+// weight packing: torch OIHW -> [chunk][tap][rows_pad][64 bytes]: split16 modes: chunks of 16 input channels, row =
+// [hi 16 | lo 16]; 16-bit storage modes (single): chunks of 32 input channels, row = 32 values.  fp16 images carry
+// x 2^8.  Element formulas as pack_weights_bf16x3_kernel (conv_bf16x3.hip): row / column maps, transposed = data gradient.
+template <bool F16, bool SINGLE>
 __global__ void pack_weights_wide_kernel(const float* __restrict__ w, void* __restrict__ dstv, int cout, int cin,
                                          int rows_pad, int cols, int nchunks, const int* __restrict__ row_map,
                                          const int* __restrict__ col_map, int nrows_map, int transposed) {
   typedef typename std::conditional<F16, _Float16, __bf16>::type ET;
+  constexpr int CK = SINGLE ? 32 : 16;
   ET* dst = reinterpret_cast<ET*>(dstv);
-  const int total = nchunks * 9 * rows_pad * 16;
+  const int total = nchunks * 9 * rows_pad * CK;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int k = i & 15;
-    int rest = i >> 4;
+    const int k = i % CK;
+    int rest = i / CK;
     const int row = rest % rows_pad;
     rest /= rows_pad;
     const int tap = rest % 9, chunk = rest / 9;
-    const int col = chunk * 16 + k;
+    const int col = chunk * CK + k;
     float v = 0.f;
     if (col < cols && row < nrows_map) {
       const int rm = row_map[row], cm = col_map[col];
@@ -693,24 +738,34 @@ __global__ void pack_weights_wide_kernel(const float* __restrict__ w, void* __re
     }
     if (F16) v *= kWideF16Scale;
     const ET hi = (ET)v;
-    const ET lo = (ET)(v - (float)hi);
     ET* d = dst + (((size_t)chunk * 9 + tap) * rows_pad + row) * 32;
     d[k] = hi;
-    d[16 + k] = lo;
+    if (!SINGLE) d[16 + k] = (ET)(v - (float)hi);
   }
 }
 
+// single != 0: the 16-bit storage modes' image (one value per weight, 32-channel chunks)
 int pack_weights_wide_launch(const float* w, void* dst, int f16, int cout, int cin, int rows_pad, int cols,
-                             const int* row_map, const int* col_map, int nrows_map, int transposed, hipStream_t stream) {
-  const int nchunks = ceil_div(cols, 16);
-  const int total = nchunks * 9 * rows_pad * 16;
+                             const int* row_map, const int* col_map, int nrows_map, int transposed, hipStream_t stream,
+                             int single) {
+  const int nchunks = ceil_div(cols, single ? 32 : 16);
+  const int total = nchunks * 9 * rows_pad * (single ? 32 : 16);
   const int blocks = min(ceil_div(total, 256), 4096);
-  if (f16)
-    hipLaunchKernelGGL(pack_weights_wide_kernel<true>, dim3(blocks), dim3(256), 0, stream, w, dst, cout, cin, rows_pad, cols,
-                       nchunks, row_map, col_map, nrows_map, transposed);
-  else
-    hipLaunchKernelGGL(pack_weights_wide_kernel<false>, dim3(blocks), dim3(256), 0, stream, w, dst, cout, cin, rows_pad, cols,
-                       nchunks, row_map, col_map, nrows_map, transposed);
+#define PW_LAUNCH(F_, S_)                                                                                              \
+  hipLaunchKernelGGL((pack_weights_wide_kernel<F_, S_>), dim3(blocks), dim3(256), 0, stream, w, dst, cout, cin, rows_pad, \
+                     cols, nchunks, row_map, col_map, nrows_map, transposed)
+  if (f16) {
+    if (single)
+      PW_LAUNCH(true, true);
+    else
+      PW_LAUNCH(true, false);
+  } else {
+    if (single)
+      PW_LAUNCH(false, true);
+    else
+      PW_LAUNCH(false, false);
+  }
+#undef PW_LAUNCH
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

@@ -122,7 +122,7 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   MIMO_TRY(pack_weights_launch(w, wf, cout, cin, cout_pad, cin_p, rm, cm, 0, st));
   const int fmode = mixed ? (f16s ? 6 : 4) : (bf16 ? 2 : 1);
   // split16: the decomposition the plan would pick for this geometry (conv_wide.hip or conv_bf16x3.hip)
-  const int wide = precision == MIMO_PREC_SPLIT16 ? conv3x3_wide_rows(fmode, n, cin_p, cout_p, h, wd) : 0;
+  const int wide = (precision == MIMO_PREC_SPLIT16 || mixed) ? conv3x3_wide_rows(fmode, n, cin_p, cout_p, h, wd) : 0;
   const int pair = (split && !wide) ? conv3x3_pair_tail(fmode, cin_p, h, wd) : 0;
   if (wide) {
     wpk = t.get<uint16_t>(conv3x3_wide_weight_elems(cin_p, wide));
@@ -130,7 +130,7 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
       set_error("mimo_op_conv3x3_forward: allocation failed");
       return MIMO_ERR_HIP;
     }
-    MIMO_TRY(pack_weights_wide_launch(w, wpk, 1, cout, cin, wide, cin_p, rm, cm, cout_pad, 0, st));
+    MIMO_TRY(pack_weights_wide_launch(w, wpk, bf16 ? 0 : 1, cout, cin, wide, cin_p, rm, cm, cout_pad, 0, st, mixed ? 1 : 0));
   } else if (split)
     MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, bf16 ? 0 : 1, cout, cin, cout_pad, cin_p, rm, cm, 0, st, pair));
   if (bias) MIMO_HIP_CHECK(hipMemcpyAsync(bp, bias, cout * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -198,7 +198,7 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
   }
   MIMO_TRY(pack_weights_launch(w, wdp, cout, cin, rows_pad, cout_p, rm, cm, 1, st));
   const int dmode = mixed ? (f16s ? 7 : 5) : (bf16 ? 3 : 0);
-  const int wide = precision == MIMO_PREC_SPLIT16 ? conv3x3_wide_rows(dmode, n, cout_p, cin_p, h + 2, wd + 2) : 0;
+  const int wide = (precision == MIMO_PREC_SPLIT16 || mixed) ? conv3x3_wide_rows(dmode, n, cout_p, cin_p, h + 2, wd + 2) : 0;
   const int pair = (split && !wide) ? conv3x3_pair_tail(dmode, cout_p, h + 2, wd + 2) : 0;
   if (wide) {
     wpk = t.get<uint16_t>(conv3x3_wide_weight_elems(cout_p, wide));
@@ -206,7 +206,7 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
       set_error("mimo_op_conv3x3_dgrad: allocation failed");
       return MIMO_ERR_HIP;
     }
-    MIMO_TRY(pack_weights_wide_launch(w, wpk, 0, cout, cin, wide, cout_p, rm, cm, rows_pad, 1, st));
+    MIMO_TRY(pack_weights_wide_launch(w, wpk, f16s ? 1 : 0, cout, cin, wide, cout_p, rm, cm, rows_pad, 1, st, mixed ? 1 : 0));
   } else if (split)
     MIMO_TRY(pack_weights_bf16x3_launch(w, wpk, f16s ? 1 : 0, cout, cin, rows_pad, cout_p, rm, cm, 1, st, pair));
   const float* dz_in = dz;

@@ -436,9 +436,9 @@ struct mimo_plan {
     L.dg_split = mfma16 && (mixed || L.cout_p >= 16);
     L.dtz = L.fwd_split ? st : ST_F32;
     if (L.wg_split && !L.dg_split) any_mixed_dz = true;
-    if (cfg.precision == MIMO_PREC_SPLIT16) {  // decomposition per layer and direction (sched::wide_config)
-      if (L.fwd_split) L.fwd_wide = conv3x3_wide_rows(1, n, L.cin_p, L.cout_p, h, w);
-      if (L.dg_split) L.dg_wide = conv3x3_wide_rows(0, n, L.cout_p, L.cin_p, h + 2, w + 2);
+    if (cfg.precision == MIMO_PREC_SPLIT16 || mixed) {  // decomposition per layer and direction (sched::wide_config)
+      if (L.fwd_split) L.fwd_wide = conv3x3_wide_rows(fwd_mode(), n, L.cin_p, L.cout_p, h, w);
+      if (L.dg_split) L.dg_wide = conv3x3_wide_rows(dgrad_mode(), n, L.cout_p, L.cin_p, h + 2, w + 2);
     }
     if (L.fwd_split) {
       uint16_t* q = nullptr;
@@ -785,11 +785,11 @@ struct mimo_plan {
           j.dst = L->fwd_split ? L->wf16 : (void*)L->wf;
           j.total = L->fwd_split ? ceil_div(j.cols, 32) * 9 * j.rows_pad * 32 : 9 * j.rows_pad * j.cols;
           j.pair = L->fwd_split ? conv3x3_pair_tail(fwd_mode(), L->cin_p, L->H, L->W) : 0;
-          if (L->fwd_wide) {  // conv_wide.hip layout: 16-channel chunks, fp16 pairs
-            j.kind = 3;
+          if (L->fwd_wide) {  // conv_wide.hip layouts: 16-channel chunks of fp16 pairs / 32-channel chunks of 16-bit values
+            j.kind = !mixed ? 3 : f16 ? 5 : 6;
             j.map_rows = L->cout_pad;
             j.rows_pad = L->fwd_wide;
-            j.total = ceil_div(j.cols, 16) * 9 * j.rows_pad * 16;
+            j.total = mixed ? ceil_div(j.cols, 32) * 9 * j.rows_pad * 32 : ceil_div(j.cols, 16) * 9 * j.rows_pad * 16;
             j.pair = 0;
           }
           jobs.push_back(j);
@@ -807,11 +807,11 @@ struct mimo_plan {
           d.dst = L->dg_split ? L->wd16 : (void*)L->wd;
           d.total = L->dg_split ? ceil_div(d.cols, 32) * 9 * d.rows_pad * 32 : 9 * d.rows_pad * d.cols;
           d.pair = L->dg_split ? conv3x3_pair_tail(dgrad_mode(), L->cout_p, L->H + 2, L->W + 2) : 0;
-          if (L->dg_wide) {  // bf16 pairs
-            d.kind = 4;
+          if (L->dg_wide) {  // bf16 pairs / 16-bit values
+            d.kind = !mixed ? 4 : f16 ? 5 : 6;
             d.map_rows = L->dg_rows;
             d.rows_pad = L->dg_wide;
-            d.total = ceil_div(d.cols, 16) * 9 * d.rows_pad * 16;
+            d.total = mixed ? ceil_div(d.cols, 32) * 9 * d.rows_pad * 32 : ceil_div(d.cols, 16) * 9 * d.rows_pad * 16;
             d.pair = 0;
           }
           dg.push_back(d);

@@ -60,7 +60,9 @@ struct WideCfg {
 // force: -1 = never, 0 = by the cost rule, 1 = whenever the geometry is supported.
 static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, int Wo, int force, int nf_force = 0) {
   WideCfg c{0, 0, 0, 0};
-  if (force < 0 || mode < 0 || mode > 1 || rows < 1 || cin_p < 16 || Ho < 2 || Wo < 2) return c;
+  const bool s16 = mode >= 4 && mode <= 7;  // 16-bit storage modes: 32-channel chunks, one MFMA per product
+  if (force < 0 || !(mode == 0 || mode == 1 || s16) || rows < 1 || cin_p < 16 || Ho < 2 || Wo < 2) return c;
+  if (s16 && cin_p % 8 != 0) return c;
   int TR, TC;
   pick_tile_n(Ho, Wo, kWideNPix, kWideMaxPix, &TR, &TC);
   if ((TR + 2) * (TC + 2) > kWideMaxPix) return c;
@@ -78,14 +80,15 @@ static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, 
     //              and pipeline fill, a = 1.2 (64-channel tiles) / 0.2 (32-channel tiles, one barrier per chunk)
     //   256-pixel: K padded to 32 (tap pairing: a <= 16-channel tail costs 2/3 of a chunk), channels to 16, x 1.15
     //              (its matrix pipe is ~15 % less busy)
-    const int k16 = rup(cin_p, 16);
+    const int k16 = rup(cin_p, s16 ? 32 : 16);
     int TRo, TCo;
     pick_tile_n(Ho, Wo, 256, 360, &TRo, &TCo);
     const double eff_o = double(Ho) * Wo / (double(cdiv(Ho, TRo)) * cdiv(Wo, TCo) * 256);
     const int tail = cin_p - 32 * (cdiv(cin_p, 32) - 1);
-    const double k_o = 32.0 * (cdiv(cin_p, 32) - 1) + (tail <= 16 ? 64.0 / 3.0 : 32.0);
-    const double t_w = double(k16) * (cotiles * nf * 32) / eff * (1.0 + (nf == 2 ? 1.2 : 0.2) / (k16 / 16));
-    const double t_o = 1.15 * k_o * rup(rows, 16) / eff_o;
+    const double k_o = 32.0 * (cdiv(cin_p, 32) - 1) + ((tail <= 16 && !s16) ? 64.0 / 3.0 : 32.0);
+    const double t_w = double(k16) * (cotiles * nf * 32) / eff * (1.0 + (nf == 2 ? 1.2 : 0.2) / (k16 / (s16 ? 32 : 16)));
+    // (16-bit storage modes, one MFMA per product: the 256-pixel kernel is bound by its staging there, x 1.45)
+    const double t_o = (s16 ? 1.45 : 1.15) * k_o * rup(rows, 16) / eff_o;
     // the wide kernel is persistent with one workgroup per CU: it needs enough (pixel tile, channel tile) pairs
     if (tiles * cotiles < 128 || t_w >= t_o) return c;
   }

@@ -36,6 +36,7 @@ def run(reps):
     shapes = [s for i, s in enumerate(SHAPES) if only is None or str(i) in only.split(",")]
     labels = []
     st = L.current_stream()
+    prec = int(os.environ.get("MIMO_LAYER_BENCH_PREC", "1"))  # mimo_precision: 1 split16, 3 bf16-mixed, 4 16-mixed
     for (N, H, W, Ci, Co) in shapes:
         cip, cop = pad8(Ci), pad8(Co)
         g = torch.Generator(device="cuda").manual_seed(1)
@@ -50,9 +51,9 @@ def run(reps):
         stats = torch.zeros(2, Co, dtype=torch.float64, device="cuda")
         for _ in range(reps):
             L.check(lib.mimo_op_conv3x3_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), z.data_ptr(), stats.data_ptr(),
-                                                N, H, W, Ci, cip, Co, cop, 1, st), "fwd")
+                                                N, H, W, Ci, cip, Co, cop, prec, st), "fwd")
             labels.append(f"fwd {Ci}->{Co}@{H} {N}")
-            L.check(lib.mimo_op_conv3x3_dgrad(dz.data_ptr(), w.data_ptr(), dx.data_ptr(), N, H, W, Ci, cip, Co, cop, 1, st),
+            L.check(lib.mimo_op_conv3x3_dgrad(dz.data_ptr(), w.data_ptr(), dx.data_ptr(), N, H, W, Ci, cip, Co, cop, prec, st),
                     "dgrad")
             labels.append(f"dgrad {Ci}->{Co}@{H} {N}")
         torch.cuda.synchronize()

@@ -272,7 +272,10 @@ def test_bf16_conv_kernels_against_rounded_operand_reference(case):
 
 @pytest.mark.parametrize("mode", ["bf16-mixed", "16-mixed"])
 @pytest.mark.parametrize("case", [(1, 64, 64, 30, 30), (2, 16, 16, 45, 30), (1, 16, 16, 120, 240), (2, 32, 32, 21, 42),
-                                  (1, 6, 7, 16, 33), (1, 50, 70, 8, 60), (2, 2, 2, 24, 8)], ids=lambda c: "x".join(map(str, c)))
+                                  (1, 6, 7, 16, 33), (1, 50, 70, 8, 60), (2, 2, 2, 24, 8),
+                                  # shapes of the wide decomposition (conv_wide.hip, 32-channel chunks in these modes)
+                                  (2, 64, 64, 60, 60), (1, 48, 40, 90, 45), (3, 32, 32, 120, 72), (1, 37, 53, 40, 100)],
+                         ids=lambda c: "x".join(map(str, c)))
 def test_storage_mode_conv_kernels_against_rounded_reference(case, mode):
     """The 16-bit STORAGE kernels (conv modes 4-7, weight-gradient operand modes 1-2): inputs arrive as bf16 / fp16
     NHWC tensors, products are exact, accumulation fp32, the output is rounded ONCE to the storage type.  Reference:

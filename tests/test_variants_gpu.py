@@ -38,6 +38,8 @@ def test_kernel_variant(name):
     sel = ("tests/test_ops_gpu.py::test_conv3x3_forward_dgrad_wgrad "
            "tests/test_network_gpu.py::test_train_steps_match_reference_golden "
            "tests/test_network_gpu.py::test_mc_dropout_ensemble_golden").split()
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "split16 or mc_dropout", *sel],
+    if name.startswith("conv_wide"):  # the wide kernel also serves the 16-bit storage modes
+        sel.append("tests/test_ops_gpu.py::test_storage_mode_conv_kernels_against_rounded_reference")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "split16 or mc_dropout or storage_mode", *sel],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
