@@ -615,7 +615,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       const int which = tid / NB, c = tid - which * NB;
       const float v = (red[(0 * 2 + which) * NB + c] + red[(1 * 2 + which) * NB + c]) +
                       (red[(2 * 2 + which) * NB + c] + red[(3 * 2 + which) * NB + c]);
-      if (co0 + c < a.cout_pad) a.stats[((size_t)vbx * 2 + which) * a.cout_pad + co0 + c] = v;
+      // (a.stats == nullptr: a forward that needs neither statistics nor the inference epilogue — eval mode with autograd)
+      if (a.stats && co0 + c < a.cout_pad) a.stats[((size_t)vbx * 2 + which) * a.cout_pad + co0 + c] = v;
     }
   }
 #undef WC_READ_W
@@ -669,8 +670,8 @@ int conv3x3_wide_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t st
   hipLaunchKernelGGL((conv3x3_wide_kernel<NF_, MODE_, TPP_, EPI_>), grid, dim3(512), 0, stream, a, c.TR, c.TC, tilesY, \
                      tilesX, numTiles, gx, coTiles)
   const bool fwd = mode == 1 || mode == 4 || mode == 6;
-  if (fwd && (!a.bias || (a.ep_scale ? (a.stats || !a.ep_shift) : !a.stats))) {
-    set_error("conv3x3 wide forward: bias plus either the statistics rows or the inference epilogue");
+  if (fwd && (!a.bias || (a.ep_scale && (a.stats || !a.ep_shift)))) {
+    set_error("conv3x3 wide forward: needs the bias; statistics rows and the inference epilogue exclude each other");
     return MIMO_ERR_INVALID;
   }
   if (mode >= 4 && (a.ldx % 8 != 0 || a.cin_p % 8 != 0)) {
