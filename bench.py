@@ -145,16 +145,39 @@ def cpu_baseline(c, batch=8, warmup=2, steps=5, threads=None):
         O.train_step(ts, image, label, None, perms)
         times.append(time.perf_counter() - t0)
     dt = sum(times[warmup:]) / steps
-    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+            "threads": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"{steps} timed steps ({warmup} warm-up) of the same network shape at batch {batch}, fp32, "
                       f"torch {torch.__version__} CPU, {dt * 1e3:.0f} ms/step"}
 
 
+def visible_gpu_count(sysfs="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process tree will see, WITHOUT any HIP / torch.cuda call (the parent of an N-rank run must not
+    initialise the GPU before it starts its children): KFD topology nodes with SIMDs, cut down by
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None when sysfs does not say."""
+    if not os.path.isdir(os.path.dirname(os.path.dirname(sysfs))):
+        return 0  # no KFD driver at all: no AMD GPU on this host
+    try:
+        n = 0
+        for node in sorted(os.listdir(sysfs)):
+            with open(os.path.join(sysfs, node, "properties")) as fh:
+                props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args):
-    """Parent of an N-rank run: start the ranks as a CHILD process tree before this process touches the GPU
-    (never re-exec a process that has initialised HIP), forward its output, return its status."""
-    have = torch.cuda.device_count()  # does not initialise the GPU on this image
-    if have < args.gpus and os.environ.get("MIMO_BENCH_BACKEND", "nccl") == "nccl":
+    """Parent of an N-rank run: start the ranks as a CHILD process tree; this process never touches the GPU (no
+    torch.cuda / HIP call: a process that has initialised HIP must not fork-exec), forwards the children's output
+    and returns their status."""
+    have = visible_gpu_count()
+    if have is not None and have < args.gpus and os.environ.get("MIMO_BENCH_BACKEND", "nccl") == "nccl":
         raise SystemExit(f"--gpus {args.gpus} but only {have} GPU(s) visible (MIMO_BENCH_BACKEND=gloo lets ranks share one)")
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
@@ -208,6 +231,14 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend)
+        if dist.get_backend() != backend:
+            raise SystemExit(f"process group runs on {dist.get_backend()!r}, {backend!r} was requested")
+        # one GPU per rank under RCCL (ranks may share a device only in the gloo functional check)
+        devs = [None] * dist.get_world_size()
+        dist.all_gather_object(devs, f"{socket.gethostname()}:{torch.cuda.get_device_properties(dev).uuid}"
+                               if hasattr(torch.cuda.get_device_properties(dev), "uuid") else f"{socket.gethostname()}:{dev}")
+        if backend == "nccl" and len(set(devs)) != len(devs):
+            raise SystemExit(f"RCCL ranks share a GPU: {devs}")
 
     torch.manual_seed(1)
     model = make_model(c).cuda()
@@ -218,17 +249,19 @@ def main():
             dist.broadcast(t.data, 0)
     opt = model.configure_optimizers()["optimizer"]
     opt.reduce_scale = 1.0 / world
-    if args.scaling == "strong":
-        # the global batch, identical on every rank, sharded by rank (ddp.shard_batch: rows [r*B, (r+1)*B))
-        from mimo_unet_amd.ddp import shard_batch
-        g = torch.Generator(device="cuda").manual_seed(100)
-        image = torch.rand(c["batch"], c["Ci"], c["H"], c["W"], device="cuda", generator=g)
-        batch = shard_batch({"image": image, "label": learnable_label(image, generator=g)}, rank, world)
-        batch = {k: v.contiguous() for k, v in batch.items()}
-    else:
+    def make_batch(scaling):
+        if scaling == "strong":
+            # the global batch, identical on every rank, sharded by rank (ddp.shard_batch: rows [r*B, (r+1)*B))
+            from mimo_unet_amd.ddp import shard_batch
+            g = torch.Generator(device="cuda").manual_seed(100)
+            image = torch.rand(c["batch"], c["Ci"], c["H"], c["W"], device="cuda", generator=g)
+            b = shard_batch({"image": image, "label": learnable_label(image, generator=g)}, rank, world)
+            return {k: v.contiguous() for k, v in b.items()}
         g = torch.Generator(device="cuda").manual_seed(100 + rank)
-        image = torch.rand(B, c["Ci"], c["H"], c["W"], device="cuda", generator=g)
-        batch = {"image": image, "label": learnable_label(image, generator=g)}
+        image = torch.rand(c["batch"], c["Ci"], c["H"], c["W"], device="cuda", generator=g)
+        return {"image": image, "label": learnable_label(image, generator=g)}
+
+    batch = make_batch(args.scaling)
 
     from mimo_unet_amd.ddp import FlatGradientAllReducer
     reducer = FlatGradientAllReducer() if dist is not None else None
@@ -265,21 +298,29 @@ def main():
             optimizer_step()
         return out["loss"]
 
-    for i in range(args.warmup):
-        step(i)
+    def timed_pass():
+        """--warmup untimed steps, then EXACTLY --steps steps between barrier + synchronize; max over ranks"""
+        for i in range(args.warmup):
+            step(i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss = step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, float(loss.detach())
+
+    # ---- timed region (the regime of --scaling): no instrumentation ----
+    elapsed, final_loss = timed_pass()
     plan = next(p for p in model.model._plans.values() if not p.inference_only)
-    # ---- timed region: EXACTLY --steps steps, no instrumentation ----
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    final_loss = float(loss.detach())
     # ---- second pass: HIP events on the launch stream around every kernel class / resolution tier ----
     prof, tiers, kind_tiers, psteps = {}, [], {}, max(0, args.profile_steps)
     if psteps:
@@ -289,11 +330,15 @@ def main():
         torch.cuda.synchronize()
         prof, tiers, kind_tiers = plan.profile_read(), plan.profile_read_tiers(), plan.profile_read_kind_tiers()
         plan.profile(False)
+    # ---- N > 1: the OTHER regime too, from a second timed pass (SURVEY 8d/e contract cfg3 as 32 GLOBAL = strong;
+    # Lightning DDP semantics = the batch per device = weak), so that one line carries both, labelled ----
+    other = "strong" if args.scaling == "weak" else "weak"
+    other_elapsed = None
+    if world > 1 and not (other == "strong" and c["batch"] % world):
+        batch = make_batch(other)
+        other_elapsed, _ = timed_pass()
     identical = None
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # data-parallel invariant: the same initial parameters + the same summed gradients => bit-identical parameters
         flat = model.model.flat_parameters()
         ref = flat.clone()
@@ -307,6 +352,12 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
+    per_gpu = {"weak": c["batch"], "strong": c["batch"] // world}
+    regime = {args.scaling: (value, ms_per_step)}
+    if other_elapsed is not None:
+        regime[other] = (world * per_gpu[other] * args.steps / other_elapsed, other_elapsed / args.steps * 1e3)
+    elif world == 1:
+        regime[other] = regime[args.scaling]  # one GPU: both regimes are the same run
     mixed = precision in ("bf16-mixed", "16-mixed")
     tier_bytes, bytes_per_image = algorithmic_bytes_per_image(c, 2 if mixed else 4)
     weight_bytes = 3.0 * 4.0 * sum(cin * cout * k * k for _, cin, cout, _, _, k in conv_layers(c))
@@ -325,7 +376,17 @@ def main():
                    "global_batch": world * B, "per_gpu_batch": B, "image": [c["H"], c["W"]], "scaling": args.scaling,
                    "labels": "learnable_label(image): 5x5-smoothed channel mix + U(-0.025, 0.025) noise; same batch every step",
                    "parallelism": f"dp{world}" + ("" if dist is None else f" ({backend}: bucketed all-reduce started inside the backward)"),
-                   "rccl_ranks": None if dist is None else dist.get_world_size(),
+                   "world_size": world, "backend": None if dist is None else backend,
+                   # ranks that really ran RCCL (None under the gloo functional check and at one rank)
+                   "rccl_ranks": dist.get_world_size() if dist is not None and backend == "nccl" else None,
+                   "rank_devices": None if dist is None else devs,
+                   # both data-parallel regimes, each from its own timed pass of --steps steps (value = the --scaling one)
+                   "weak_images_per_s": round(regime["weak"][0], 2) if "weak" in regime else None,
+                   "weak_ms_per_step": round(regime["weak"][1], 3) if "weak" in regime else None,
+                   "weak_per_gpu_batch": per_gpu["weak"],
+                   "strong_images_per_s": round(regime["strong"][0], 2) if "strong" in regime else None,
+                   "strong_ms_per_step": round(regime["strong"][1], 3) if "strong" in regime else None,
+                   "strong_global_batch": c["batch"],
                    "params_bit_identical_across_ranks": identical,
                    "optimizer": "adam(lr=1e-3) fused", "final_loss": round(final_loss, 5),
                    "streams": ("weight gradients on the caller's stream" if os.environ.get("MIMO_WGRAD_STREAM") == "0" else

@@ -23,6 +23,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations below are its whole dynamic symbol table
+ * (tests/test_host_cpu.py checks `nm -D` against this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct mimo_plan mimo_plan;
 typedef void* mimo_stream; /* hipStream_t */
@@ -298,6 +303,9 @@ int mimo_op_maxpool2x2(const float* x, float* y, int32_t n, int32_t h, int32_t w
 int mimo_op_upsample_cat(const float* skip, const float* low, float* out, int32_t n, int32_t hs, int32_t ws,
                          int32_t cs_p, int32_t hl, int32_t wl, int32_t cl_p, mimo_stream stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

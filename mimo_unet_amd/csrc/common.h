@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/mimo_hip.h"
+#include "sched.h"
 
 namespace mimo {
 
@@ -44,9 +45,7 @@ static inline int store_bytes(int dt) { return dt == ST_F32 ? 4 : 2; }
 // operand tiles (the channel tiles of one pixel tile; neighbouring pixel tiles sharing halo rows) are
 // neighbours in virtual order and therefore meet in one L2 instead of eight.
 __device__ __forceinline__ int xcd_virtual_index(int linear, int total) {
-  const int k = linear & 7, slot = linear >> 3;
-  const int base = total >> 3, rem = total & 7;  // XCD j receives base + (j < rem) workgroups
-  return k * base + (k < rem ? k : rem) + slot;
+  return sched::xcd_virtual_index(linear, total);  // sched.h: host-testable
 }
 
 // ------------------------------------------------------------------ conv3x3 (conv3x3.hip)
@@ -132,28 +131,6 @@ size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad);
 // dW[co][ci][kh][kw] (torch OIHW) = sum over splits of partial[..][tap][cin_map^-1(ci)][co]
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map,
                         int cin_p, int cin, int cout, float* dw, hipStream_t stream);
-
-// The reductions of the weight-gradient slabs of SEVERAL layers in one launch each (per backward stage): group sums
-// (element-wise sums of up to kWgReduceFan consecutive slabs; repeated level by level) and the final sum + transposition
-// into torch's OIHW gradient.  Job tables live in device memory, built once per plan.
-constexpr int kWgReduceFan = 16;
-struct WgGroupJob {
-  const float* src;  // first slab of the group (slabs are `slab4 * 4` floats apart)
-  float* dst;
-  int count;         // slabs in this group (<= kWgReduceFan)
-  int slab4;         // float4 elements per slab
-};
-struct WgReduceJob {
-  const float* src;  // slabs to sum in the final pass
-  int n;
-  int cin_pad, cout_pad, cin_p, cin, cout;
-  const int* cin_map;
-  int64_t w_off;     // float offset of the layer's weight in the bound flat gradient buffer
-  int block_begin;   // first workgroup of this job in the launch (jobs sorted; the last entry carries the total)
-};
-int wgrad_group_jobs_launch(const WgGroupJob* jobs_dev, int njobs, int max_slab4, hipStream_t stream);
-int wgrad_reduce_jobs_launch(const WgReduceJob* jobs_dev, int njobs, int total_blocks, float* grads, hipStream_t stream);
-int wgrad_reduce_blocks(int cin_pad, int cout_pad);  // workgroups one layer needs in wgrad_reduce_jobs_launch
 
 // All weight repacks of a step in ONE launch (a per-layer launch each cost more in dispatch gaps than in
 // work): a device table of jobs, blockIdx.y = job.  kind 0: fp32 [tap][rows_pad][cols]; 1 / 2: fp16 / bf16

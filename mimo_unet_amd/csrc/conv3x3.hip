@@ -22,29 +22,7 @@ constexpr int kMaxTilePix = 360;  // (TR+2)*(TC+2) upper bound held in LDS
 // ---------------------------------------------------------------------------------------
 // tile geometry (host)
 // ---------------------------------------------------------------------------------------
-static void pick_tile(int Ho, int Wo, int* TR, int* TC) {
-  double best_eff = -1.0;
-  int best_tr = 1, best_tc = 4, best_pix = 1 << 30;
-  for (int k = 1; k <= Wo; ++k) {
-    int tc = ceil_div(Wo, k);
-    if (tc > 254) continue;
-    int tr = 256 / tc;
-    if (tr > Ho) tr = Ho;
-    while (tr > 1 && (tr + 2) * (tc + 2) > kMaxTilePix) --tr;
-    if (tr < 1 || (tr + 2) * (tc + 2) > kMaxTilePix) continue;
-    double eff = double(Ho) * Wo / (double(ceil_div(Ho, tr)) * ceil_div(Wo, tc) * 256.0);
-    int pix = (tr + 2) * (tc + 2);
-    if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && pix < best_pix)) {
-      best_eff = eff;
-      best_tr = tr;
-      best_tc = tc;
-      best_pix = pix;
-    }
-    if (tc <= 4) break;
-  }
-  *TR = best_tr;
-  *TC = best_tc;
-}
+static void pick_tile(int Ho, int Wo, int* TR, int* TC) { sched::pick_tile_n(Ho, Wo, 256, kMaxTilePix, TR, TC); }
 
 int conv3x3_stat_rows(int N, int Ho, int Wo) {
   int TR, TC;
@@ -52,21 +30,8 @@ int conv3x3_stat_rows(int N, int Ho, int Wo) {
   return N * ceil_div(Ho, TR) * ceil_div(Wo, TC);
 }
 
-int conv3x3_pick_nfrag(int cout) {
-  int nfr = ceil_div(cout, 16);
-  if (nfr <= 1) return 1;
-  int best = 2, best_cost = 1 << 30;
-  for (int nf = 4; nf >= 2; --nf) {
-    int cost = round_up(nfr, nf);
-    if (cost < best_cost) {
-      best_cost = cost;
-      best = nf;
-    }
-  }
-  return best;
-}
-
-int conv3x3_cout_pad(int cout) { return round_up(ceil_div(cout, 16), conv3x3_pick_nfrag(cout)) * 16; }
+int conv3x3_pick_nfrag(int cout) { return sched::conv_pick_nfrag(cout); }
+int conv3x3_cout_pad(int cout) { return sched::conv_cout_pad(cout); }
 
 // ---------------------------------------------------------------------------------------
 // forward-type kernel
@@ -416,7 +381,7 @@ int wgrad_launch(const WgradLaunch& a, hipStream_t stream) {
 //   A (only when splits > kReduceFan): slab group sums, element-wise, grid over (elements, groups)
 //   B: per (32 ci x 32 co) tile, sum <= kReduceFan slabs with co-contiguous reads, transpose the
 //      [9][32][32] tile through LDS and write torch's layout as 288-float contiguous runs per co
-constexpr int kReduceFan = kWgReduceFan;
+constexpr int kReduceFan = 16;  // slabs summed per group (stage A)
 
 __global__ void wgrad_group_sum_kernel(const float* __restrict__ partial, int splits, size_t slab, float* __restrict__ out) {
   const int grp = blockIdx.y;
@@ -507,50 +472,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int cout_pad, const int* __restrict__ cin_map, int cin_p,
                                                            int cin, int cout, float* __restrict__ dw) {
   wgrad_reduce_tile(partial, splits, cin_pad, cout_pad, cin_map, cin_p, cin, cout, dw, (int)blockIdx.x);
-}
-
-// ---- the same two passes for several layers per launch (job tables, common.h) ----
-__global__ void wgrad_group_jobs_kernel(const WgGroupJob* __restrict__ jobs) {
-  const WgGroupJob j = jobs[blockIdx.y];
-  const float4* src = reinterpret_cast<const float4*>(j.src);
-  float4* dst = reinterpret_cast<float4*>(j.dst);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j.slab4; i += gridDim.x * blockDim.x) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < j.count; ++s) {
-      const float4 v = src[(size_t)s * j.slab4 + i];
-      acc.x += v.x;
-      acc.y += v.y;
-      acc.z += v.z;
-      acc.w += v.w;
-    }
-    dst[i] = acc;
-  }
-}
-
-__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WgReduceJob* __restrict__ jobs, int njobs,
-                                                                float* __restrict__ grads) {
-  int k = 0;
-  while (k + 1 < njobs && (int)blockIdx.x >= jobs[k + 1].block_begin) ++k;
-  const WgReduceJob j = jobs[k];
-  wgrad_reduce_tile(j.src, j.n, j.cin_pad, j.cout_pad, j.cin_map, j.cin_p, j.cin, j.cout, grads + j.w_off,
-                    (int)blockIdx.x - j.block_begin);
-}
-
-int wgrad_reduce_blocks(int cin_pad, int cout_pad) { return ceil_div(cin_pad, 32) * ceil_div(cout_pad, 8); }
-
-int wgrad_group_jobs_launch(const WgGroupJob* jobs_dev, int njobs, int max_slab4, hipStream_t stream) {
-  if (njobs <= 0) return MIMO_OK;
-  const int bx = std::max(1, std::min(ceil_div(max_slab4, 256), 256));
-  hipLaunchKernelGGL(wgrad_group_jobs_kernel, dim3(bx, njobs), dim3(256), 0, stream, jobs_dev);
-  MIMO_KERNEL_CHECK();
-  return MIMO_OK;
-}
-
-int wgrad_reduce_jobs_launch(const WgReduceJob* jobs_dev, int njobs, int total_blocks, float* grads, hipStream_t stream) {
-  if (njobs <= 0 || total_blocks <= 0) return MIMO_OK;
-  hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3(total_blocks), dim3(256), 0, stream, jobs_dev, njobs, grads);
-  MIMO_KERNEL_CHECK();
-  return MIMO_OK;
 }
 
 // scratch (floats) the reduction needs behind the `splits` slabs of the wgrad kernels

@@ -86,29 +86,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPitchB = 144;  // bytes per LDS row (pixel or weight row)
 
-static void pick_tile_n(int Ho, int Wo, int npix, int maxpix, int* TR, int* TC) {
-  double best_eff = -1.0;
-  int best_tr = 1, best_tc = 4, best_pix = 1 << 30;
-  for (int k = 1; k <= Wo; ++k) {
-    int tc = ceil_div(Wo, k);
-    if (tc > npix) continue;
-    int tr = npix / tc;
-    if (tr > Ho) tr = Ho;
-    while (tr > 1 && (tr + 2) * (tc + 2) > maxpix) --tr;
-    if (tr < 1 || (tr + 2) * (tc + 2) > maxpix) continue;
-    double eff = double(Ho) * Wo / (double(ceil_div(Ho, tr)) * ceil_div(Wo, tc) * npix);
-    int pix = (tr + 2) * (tc + 2);
-    if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && pix < best_pix)) {
-      best_eff = eff;
-      best_tr = tr;
-      best_tc = tc;
-      best_pix = pix;
-    }
-    if (tc <= 4) break;
-  }
-  *TR = best_tr;
-  *TC = best_tc;
-}
+using sched::pick_tile_n;  // sched.h (host-testable)
 
 template <int MF>
 struct TileCfg {
@@ -429,13 +407,13 @@ constexpr int kWsMaxMF = 4;
 // vmcnt that leaves their own (younger) input-tile loads in flight, then pass a raw s_barrier.  A DMA instruction
 // writes 64 x 16 contiguous bytes, so the weight rows are unpadded 128-byte rows with the slot index XORed by
 // (row & 7) (conflict-free ds_read_b128, as SWZ); the XOR is applied to the per-lane SOURCE address.
-template <int NF, int MODE, bool SWZ, int MF_, bool PAIR = false, bool WDMA = !SWZ>
+template <int NF, int MODE, int MF_, bool PAIR = false, bool WDMA = true>
 __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC,
                                                                                           int tilesY, int tilesX,
                                                                                           int numTiles, int xcd_order,
                                                                                           int gx, int coTiles) {
   MIMO_CONV_MODE_CONSTANTS
-  static_assert(!PAIR || (!SWZ && NP == 3 && !IN16), "tap pairing: split16 modes on the padded LDS rows");
+  static_assert(!PAIR || (NP == 3 && !IN16), "tap pairing: split16 modes");
   typedef typename Elem<F16>::T ET;
   typedef typename Elem<F16>::V8 bf16x8;
   typedef typename Elem<F16>::V4 bf16x4;
@@ -451,12 +429,11 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   static_assert(XU % 3 == 0, "input tile staged in three equal parts");
   constexpr int WUNITS = 3 * NB * 8;
   constexpr int WU = (WUNITS + 255) / 256;
-  // LDS row = [hi 32 | lo 32] 16-bit values = eight 16-byte slots.  SWZ: 128-byte rows with the slot index
-  // XORed with (row & 7) — ds_read_b128 by 16 consecutive rows is then conflict-free (the 16 lanes of a
-  // read group hit 16 distinct (row parity, slot) pairs = all 64 banks); else 144-byte padded rows, which
-  // are 2-way conflicting on that read (~46 % of the LDS cycles, profiles/r01/final/pmc_SQ_INSTS_LDS.csv).
-  constexpr int PITCH = SWZ ? 128 : kPitchB;
-  constexpr bool WSWZ = SWZ || WDMA;               // weight rows: swizzled 128-byte rows
+  // LDS row = [hi 32 | lo 32] 16-bit values = eight 16-byte slots in a 144-byte padded row (2-way conflicting on the
+  // ds_read_b128 of 16 consecutive rows; conflict-free XOR-swizzled 128-byte input rows measured the same kernel
+  // times in rounds 1 and 2 and were removed in round 3)
+  constexpr int PITCH = kPitchB;
+  constexpr bool WSWZ = WDMA;                      // weight rows: swizzled 128-byte rows (the DMA writes 1 KB runs)
   constexpr int WPITCH = WSWZ ? 128 : kPitchB;
   constexpr int XBYTES = kWsMaxPix * PITCH, WROWB = 3 * NB * WPITCH;
   __shared__ __attribute__((aligned(128))) unsigned char xs[2 * XBYTES];
@@ -572,7 +549,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     if (p_ < npix_lds) {                                                                             \
       const f32x4 v_ = xreg[k_];                                                                     \
       unsigned char* row_ = xs + (BUF) * XBYTES + p_ * PITCH;                                        \
-      const int sx_ = SWZ ? (p_ & 7) : 0; /* slot XOR of this row */                                 \
+      const int sx_ = 0;                                                                             \
       if (CVT) {                                                                                     \
         bf16x4 hi_, lo_;                                                                             \
         hi_[0] = (ET)v_[0];                                                                          \
@@ -741,7 +718,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     int idx = (wave * MF + m) * 16 + lr;
     if (idx >= npix_out) idx = 0;
     const int r = idx / TC, c = idx - r * TC;
-    pbase[m] = SWZ ? r * TCP + c : (r * TCP + c) * PITCH + g * 16;  // SWZ: tile row index; else byte offset
+    pbase[m] = (r * TCP + c) * PITCH + g * 16;
   }
   // weight rows: row & 7 == lr & 7 (row = tap * NB + nf * 16 + lr), so the swizzle is a per-lane constant;
   // the lo half is slot + 4, i.e. the hi address with bit 6 flipped
@@ -799,16 +776,9 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   // chunk's phases (first: K groups 2-3 read one tile row down, slots 0-1), else 0
 #define C_READ_A(AS, KW, M)                                                                     \
   if (!(abl & 16)) {                                                                                                  \
-    if (SWZ) {                                                                                       \
-      const int row_ = pbase[M] + ro_ * TCP + (KW);                                                   \
-      const int o_ = row_ * PITCH + ((g ^ (row_ & 7)) << 4);                                         \
-      ah[AS] = *reinterpret_cast<const bf16x8*>(xb_ + o_);                                           \
-      if (NP == 3) al[AS] = *reinterpret_cast<const bf16x8*>(xb_ + (o_ ^ 64));                       \
-    } else {                                                                                         \
-      const unsigned char* p_ = xb_ + pbase[M] + pd_ + (ro_ * TCP + (KW)) * PITCH;                                            \
-      ah[AS] = *reinterpret_cast<const bf16x8*>(p_);                                                 \
-      if (NP == 3) al[AS] = *reinterpret_cast<const bf16x8*>(p_ + 64);                               \
-    }                                                                                                \
+    const unsigned char* p_ = xb_ + pbase[M] + pd_ + (ro_ * TCP + (KW)) * PITCH;                     \
+    ah[AS] = *reinterpret_cast<const bf16x8*>(p_);                                                   \
+    if (NP == 3) al[AS] = *reinterpret_cast<const bf16x8*>(p_ + 64);                                 \
   }
 #define C_MFMA(AS, BS, M)                                                                            \
   if (!(abl & 8)) _Pragma("unroll") for (int nf = 0; nf < NF; ++nf) {                                                \
@@ -1009,8 +979,7 @@ int conv3x3_ws_stat_rows(int, int, int) { return 512 * 4; }  // <= 512 persisten
 // will launch — the packer lays the chunk's weights out for it, the launch selects the PAIR instance (ConvLaunch::pair).
 int conv3x3_pair_tail(int mode, int cin_p, int Ho, int Wo) {
   static const bool on = !(getenv("MIMO_CONV_PAIR_TAIL") && atoi(getenv("MIMO_CONV_PAIR_TAIL")) == 0);
-  static const bool swz = getenv("MIMO_CONV_WS_SWIZZLE") && atoi(getenv("MIMO_CONV_WS_SWIZZLE")) != 0;
-  if (!on || swz || mode < 0 || mode > 1 || !conv_ws_enabled() || Ho * Wo < 256) return 0;
+  if (!on || mode < 0 || mode > 1 || !conv_ws_enabled() || Ho * Wo < 256) return 0;
   const int tail = cin_p - 32 * (ceil_div(cin_p, 32) - 1);
   return tail <= 16 ? 1 : 0;
 }
@@ -1031,30 +1000,25 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   gx = ceil_div(numTiles, per);
   if (rows) *rows = gx;  // one partial-statistics row per workgroup
   dim3 grid(gx * coTiles);
-  // conflict-free swizzled rows measured the same step time as the padded rows (6.97 / 7.20 vs 6.89 / 7.20 ms
-  // forward / data gradient per step): the LDS array is not what the consumers wait for.  Opt-in.
-  static const bool swz = getenv("MIMO_CONV_WS_SWIZZLE") && atoi(getenv("MIMO_CONV_WS_SWIZZLE")) != 0;
   static const int xcd_ = !(getenv("MIMO_CONV_XCD_ORDER") && atoi(getenv("MIMO_CONV_XCD_ORDER")) == 0);
   // MIMO_CONV_WDMA=0: weights staged through registers (ds_write) as before
   static const bool wdma = !(getenv("MIMO_CONV_WDMA") && atoi(getenv("MIMO_CONV_WDMA")) == 0);
   const int xcd = xcd_;
   if (a.pair) {
     if constexpr (MODE <= 1) {
-      if (swz || a.pair != conv3x3_pair_tail(MODE, a.cin_p, a.Ho, a.Wo)) {
+      if (a.pair != conv3x3_pair_tail(MODE, a.cin_p, a.Ho, a.Wo)) {
         set_error("conv3x3 split: weights packed for tap pairing, launch is not");
         return MIMO_ERR_INVALID;
       }
-      hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false, MF, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
+      hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, MF, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
     } else {
       set_error("conv3x3 split: tap pairing exists for the split16 modes only");
       return MIMO_ERR_INVALID;
     }
-  } else if (swz)
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, true, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
-  else if (wdma)
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
+  } else if (wdma)
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, MF>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
   else
-    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, false, MF, false, false>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, MF, false, false>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

@@ -73,9 +73,6 @@ struct ConvBN {
   int fwd_wide = 0, dg_wide = 0;  // != 0: the launch runs on conv_wide.hip, value = packed weight rows (conv3x3_wide_rows)
   int *cin_map = nullptr, *fwd_row_map = nullptr, *dg_row_map = nullptr, *dg_col_map = nullptr;
   float* z = nullptr;
-  float* dz_own = nullptr;  // MIMO_WGRAD_STREAM=2: this layer's own dz buffer (its weight gradient may run much later)
-  float* dzs_own = nullptr;  // ... and its own pair-split copy where the weight gradient needs one
-  float* wslab = nullptr;    // batched reduction: this layer's own weight-gradient slabs (+ group-sum levels behind them)
   int dtz = ST_F32;  // element type of z: the plan's storage type, fp32 where the fp32 kernel family writes it
   float *mean = nullptr, *invstd = nullptr, *scale = nullptr, *shift = nullptr, *c1 = nullptr, *c2 = nullptr;
   const float* in = nullptr;
@@ -153,35 +150,19 @@ struct mimo_plan {
         *s_partial = nullptr, *s_losspart = nullptr;
   double* s_sums = nullptr;
   int* s_tickets = nullptr;  // colsum tickets of the scratch set in use (zero between launches)
-  // Batched weight-gradient reduction (MIMO_WGRAD_BATCHED_REDUCE=1, opt-in): every layer keeps its own slabs and the
-  // reductions of all layers of a backward stage run as one launch per group-sum level + one final launch, instead of
-  // 1-3 small launches per layer (57 per step, 0.47 ms of kernel time).  Bit-identical.  Measured no faster (5.71 vs
-  // 5.67 ms at 4 images per GPU, 29.1 vs 29.0 ms at 32) once the weight gradients run on the side stream: the
-  // per-layer reductions already hide there, the batched ones sit at the stage boundary the caller's stream waits on.
-  bool wg_batched = false;
-  struct StageReduce {
-    std::vector<WgGroupJob*> group_jobs;  // device tables, one per level
-    std::vector<int> group_count, group_max_slab4;
-    WgReduceJob* reduce_jobs = nullptr;
-    int reduce_count = 0, reduce_blocks = 0;
-  };
-  StageReduce stage_reduce_tab[8];
   ColsumScratch colsum() const { return ColsumScratch{s_sums, s_tickets, d_status}; }
   int* d_status = nullptr;  // numerics status word (mimo_plan_status)
   size_t cap_act = 0, cap_pad = 0, cap_slab = 0, cap_partial = 0, cap_sums = 0;
 
   // MIMO_WGRAD_STREAM (default 1): weight gradients on a side stream — wgrad(L) (matrix-pipe bound, little HBM
   // traffic) overlaps the bandwidth-bound BatchNorm / gather kernels of the layers below it on the caller's stream;
-  // dz ping-pongs between wg_bufs buffers so that layer L-1 can write its dz while wgrad(L) still reads the other one.
+  // dz ping-pongs between two buffers so that layer L-1 can write its dz while wgrad(L) still reads the other one.
+  // (Measured and removed in round 3: per-layer dz buffers without back-pressure, 3-4 ping-pong buffers, releasing a
+  // weight gradient only after its layer's data gradient — none faster)
   bool wg_async = false;
-  // MIMO_WGRAD_STREAM=2 ("deferred"): every layer keeps its own dz buffer, so the weight gradients queue up on the side
-  // stream without back-pressure on the main chain — the chain (BatchNorm backward -> data gradient -> ...) never waits
-  // for a weight gradient, and an MFMA-bound kernel is always available to run beside the bandwidth-bound ones
-  bool wg_deferred = false;
   hipStream_t wg_stream = nullptr;
-  static constexpr int kDzBufs = 4;  // capacity; wg_bufs (MIMO_WGRAD_BUFFERS, default 2) are used
-  int wg_bufs = 2;
-  bool wg_release_after_dgrad = false;  // MIMO_WGRAD_RELEASE=1: a weight gradient starts when its layer's data gradient ends
+  static constexpr int kDzBufs = 2;
+  static constexpr int wg_bufs = kDzBufs;
   hipEvent_t ev_dz[kDzBufs] = {}, ev_wg[kDzBufs] = {}, ev_join = nullptr;
   bool wg_pending[kDzBufs] = {};
   float* s_dz2[kDzBufs] = {};
@@ -268,28 +249,9 @@ struct mimo_plan {
   hipStream_t cap_stream = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   uint64_t graph_key = 0;
-  // hipGraph replay of the TRAINING step (MIMO_TRAIN_GRAPH=1, opt-in): one graph for the training forward, one per
-  // backward stage (~330 launches per step otherwise — at the 4 images per GPU of an 8-way strong-scaling run the
-  // step is launch-bound).  Same staging scheme: the captured kernels read plan-owned copies of image / permutation /
-  // Dropout2d masks / label / loss mask / dloss and write the plan-owned logits buffer.
-  struct GraphSlot {
-    hipGraphExec_t exec = nullptr;
-    uint64_t key = 0;
-  };
-  static constexpr int kBwdStagesDecl = 8;
-  bool train_graph = true;
-  GraphSlot tg_fwd, tg_bwd[kBwdStagesDecl];
-  bool staged_train = false;  // the last forward was a staged (graph) training forward
-  uint64_t staged_key = 0;
-  float *g_label = nullptr, *g_lmask = nullptr, *g_dloss = nullptr;
-  int64_t g_rows = 0;  // batch rows of the caller's image / label / mask tensors in the last staged forward
   void drop_graphs() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     graph_exec = nullptr;
-    for (GraphSlot* g : {&tg_fwd, &tg_bwd[0], &tg_bwd[1], &tg_bwd[2], &tg_bwd[3], &tg_bwd[4], &tg_bwd[5], &tg_bwd[6], &tg_bwd[7]}) {
-      if (g->exec) (void)hipGraphExecDestroy(g->exec);
-      g->exec = nullptr;
-    }
   }
   float *g_x = nullptr, *g_out = nullptr;
   int64_t* g_perm = nullptr;
@@ -306,18 +268,7 @@ struct mimo_plan {
   float elem_rate(int j) const { return j == 0 ? cfg.center_dropout_rate : cfg.final_dropout_rate; }
   ElemRng elem_rng(int j) const { return ElemRng{rng_seed, rng_offset, (int)dcs.size() + j, elem_rate(j)}; }
 
-  // MIMO_SUBNET_STREAMS=1 (opt-in, forward only): the S private encoder / decoder chains are independent until
-  // the concat / after the core, so they are issued on S streams — one chain's bandwidth-bound BatchNorm /
-  // gather kernels then run beside another chain's matrix-pipe-bound convolution (+1.5 % images/s at cfg3).
-  // Per-stream copies of the scratch the chains would otherwise share.  Off by default because the
-  // per-kernel HIP-event durations the roofline is computed from become overlapped durations.
-  bool subnet_streams = false, capturing = false;
-  std::vector<hipStream_t> sub_streams;       // [S]; [0] unused (the caller's stream)
-  std::vector<hipEvent_t> sub_join;           // [S]
-  hipEvent_t sub_fork = nullptr;
-  std::vector<float*> set_partial;            // [S] forward partial-statistics rows
-  std::vector<double*> set_sums;              // [S]
-  std::vector<int*> set_tickets;              // [S]
+  bool capturing = false;
 
   // weight repack job tables (device): [0, n_fwd_jobs) forward packs (+ bias copies), then the data-gradient packs
   PackJob* pack_jobs = nullptr;
@@ -349,11 +300,6 @@ struct mimo_plan {
     drop_graphs();
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     if (wg_stream) (void)hipStreamDestroy(wg_stream);
-    for (hipStream_t t : sub_streams)
-      if (t) (void)hipStreamDestroy(t);
-    for (hipEvent_t e : sub_join)
-      if (e) (void)hipEventDestroy(e);
-    if (sub_fork) (void)hipEventDestroy(sub_fork);
     for (int i = 0; i < kDzBufs; ++i)
       for (hipEvent_t e : {ev_dz[i], ev_wg[i]})
         if (e) (void)hipEventDestroy(e);
@@ -704,23 +650,8 @@ struct mimo_plan {
       // gather kernels of layer L-1 (bandwidth-bound: they co-reside with the persistent MFMA workgroup on a CU) and
       // queues behind the data gradient of layer L; dz ping-pongs between wg_bufs buffers.  Measured +1.7 ... +4.7 %
       // images/s on three boxes (within noise on a fourth); results are bit-identical to the single-stream order.
-      // With the profiler armed (bench.py's second pass) everything runs on the caller's stream.  A requested
-      // training-step hipGraph (MIMO_TRAIN_GRAPH=1) turns it off.
-      const char* tg = getenv("MIMO_TRAIN_GRAPH");
-      wg_async = !(we && atoi(we) == 0) && !cfg.inference_only && !(tg && atoi(tg) != 0);
-      wg_deferred = wg_async && we && atoi(we) == 2;
-      if (wg_deferred)
-        for (auto& dc : dcs)
-          for (ConvBN* L : {&dc->c1, &dc->c2}) {
-            MIMO_TRY(alloc_act(&L->dz_own, (size_t)L->N * L->H * L->W * L->cout_p, st));
-            if (L->wg_split && !L->dg_split) MIMO_TRY(dalloc(&L->dzs_own, (size_t)L->N * L->H * L->W * L->cout_p));
-          }
-      if (wg_async) {
-        const char* be = getenv("MIMO_WGRAD_BUFFERS");
-        wg_bufs = be ? std::max(2, std::min(kDzBufs, atoi(be))) : 2;
-        const char* re = getenv("MIMO_WGRAD_RELEASE");
-        wg_release_after_dgrad = re && atoi(re) != 0;
-      }
+      // With the profiler armed (bench.py's second pass) everything runs on the caller's stream.
+      wg_async = !(we && atoi(we) == 0) && !cfg.inference_only;
       for (int i = 0; i < kDzBufs; ++i) s_dz2[i] = s_dz;
       if (any_mixed_dz) {
         MIMO_TRY(dalloc(&s_dzs2[0], cap_act));
@@ -742,25 +673,6 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&s_partial, cap_partial));
     MIMO_TRY(dalloc(&s_sums, cap_sums));
     MIMO_TRY(dalloc(&s_tickets, kColsumMaxGroups));
-    {
-      const char* se = getenv("MIMO_SUBNET_STREAMS");
-      subnet_streams = se && atoi(se) != 0 && S > 1;
-      set_partial.assign(S, s_partial);
-      set_sums.assign(S, s_sums);
-      set_tickets.assign(S, s_tickets);
-      sub_streams.assign(S, nullptr);
-      sub_join.assign(S, nullptr);
-      if (subnet_streams) {
-        MIMO_HIP_CHECK(hipEventCreateWithFlags(&sub_fork, hipEventDisableTiming));
-        for (int i = 1; i < S; ++i) {
-          MIMO_TRY(dalloc(&set_partial[i], cap_partial));
-          MIMO_TRY(dalloc(&set_sums[i], cap_sums));
-          MIMO_TRY(dalloc(&set_tickets[i], kColsumMaxGroups));
-          MIMO_HIP_CHECK(hipStreamCreateWithFlags(&sub_streams[i], hipStreamNonBlocking));
-          MIMO_HIP_CHECK(hipEventCreateWithFlags(&sub_join[i], hipEventDisableTiming));
-        }
-      }
-    }
     MIMO_TRY(dalloc(&s_losspart, (size_t)S * 512));
     MIMO_TRY(dalloc(&d_status, 1));
     // ---- weight repack job tables ----
@@ -823,91 +735,12 @@ struct mimo_plan {
       MIMO_TRY(dalloc(&pack_jobs, jobs.size()));
       MIMO_HIP_CHECK(hipMemcpy(pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
     }
-    // ---- batched weight-gradient reduction: per-layer slabs and per-stage job tables ----
-    {
-      const char* be = getenv("MIMO_WGRAD_BATCHED_REDUCE");
-      wg_batched = be && atoi(be) != 0 && !cfg.inference_only;
-      if (wg_batched) {
-        std::vector<std::vector<ConvBN*>> stage_layers(kBwdStagesDecl);
-        auto add = [&](int stage, DoubleConv* dc) {
-          stage_layers[stage].push_back(&dc->c2);
-          stage_layers[stage].push_back(&dc->c1);
-        };
-        for (DoubleConv* dc : up4) add(0, dc);
-        add(1, up3);
-        add(2, up2);
-        add(3, up1);
-        add(4, down4);
-        add(5, down3);
-        add(6, down2);
-        for (DoubleConv* dc : down1) add(7, dc);
-        for (DoubleConv* dc : enc_in) add(7, dc);
-        for (int stage = 0; stage < kBwdStagesDecl; ++stage) {
-          StageReduce& sr = stage_reduce_tab[stage];
-          std::vector<std::vector<WgGroupJob>> levels;
-          std::vector<WgReduceJob> red;
-          int blocks_total = 0;
-          for (ConvBN* L : stage_layers[stage]) {
-            const size_t slab = (size_t)9 * L->wg_cin_pad * L->wg_cout_pad;
-            const int blocks = wgrad_reduce_blocks(L->wg_cin_pad, L->wg_cout_pad);
-            const int final_fan = blocks >= 512 ? kWgReduceFan : 1;
-            size_t slabs = L->wg_splits;  // level outputs are placed behind the inputs
-            for (int n = L->wg_splits; n > final_fan;) {
-              n = ceil_div(n, kWgReduceFan);
-              slabs += n;
-            }
-            MIMO_TRY(dalloc(&L->wslab, slabs * slab));
-            const float* src = L->wslab;
-            int n = L->wg_splits, lvl = 0;
-            while (n > final_fan) {
-              const int groups = ceil_div(n, kWgReduceFan);
-              float* out = const_cast<float*>(src) + (size_t)n * slab;
-              if ((int)levels.size() <= lvl) levels.emplace_back();
-              for (int g = 0; g < groups; ++g)
-                levels[lvl].push_back(WgGroupJob{src + (size_t)g * kWgReduceFan * slab, out + (size_t)g * slab,
-                                                 std::min(kWgReduceFan, n - g * kWgReduceFan), (int)(slab / 4)});
-              src = out;
-              n = groups;
-              ++lvl;
-            }
-            red.push_back(WgReduceJob{src, n, L->wg_cin_pad, L->wg_cout_pad, L->cin_p, L->Cin, L->Cout, L->cin_map, L->off_w,
-                                      blocks_total});
-            blocks_total += blocks;
-          }
-          for (auto& lv : levels) {
-            WgGroupJob* d = nullptr;
-            MIMO_TRY(dalloc(&d, lv.size()));
-            MIMO_HIP_CHECK(hipMemcpy(d, lv.data(), lv.size() * sizeof(WgGroupJob), hipMemcpyHostToDevice));
-            int mx = 0;
-            for (auto& j : lv) mx = std::max(mx, j.slab4);
-            sr.group_jobs.push_back(d);
-            sr.group_count.push_back((int)lv.size());
-            sr.group_max_slab4.push_back(mx);
-          }
-          MIMO_TRY(dalloc(&sr.reduce_jobs, red.size()));
-          MIMO_HIP_CHECK(hipMemcpy(sr.reduce_jobs, red.data(), red.size() * sizeof(WgReduceJob), hipMemcpyHostToDevice));
-          sr.reduce_count = (int)red.size();
-          sr.reduce_blocks = blocks_total;
-        }
-      }
-    }
     // hipGraph staging
     const char* ge = getenv("MIMO_HIP_GRAPH");
     graph_enabled = !(ge && atoi(ge) == 0);
     MIMO_TRY(dalloc(&g_x, (size_t)N * S * Ci * H * W));
     MIMO_TRY(dalloc(&g_out, (size_t)N * S * Co * H * W));
     MIMO_TRY(dalloc(&g_perm, (size_t)S * N));
-    {
-      const char* te = getenv("MIMO_TRAIN_GRAPH");
-      // opt-in: measured on cfg3 at 32 and at 4 images per GPU the replay is no faster than the eager launch sequence
-      // (30.2 vs 30.0 ms and 7.43 vs 7.36 ms per step: the step is not launch-bound even at 4 images)
-      train_graph = graph_enabled && te && atoi(te) != 0 && !cfg.inference_only && !wg_async && !subnet_streams;
-      if (train_graph) {
-        MIMO_TRY(dalloc(&g_label, (size_t)N * (Co / 2) * H * W));
-        MIMO_TRY(dalloc(&g_lmask, (size_t)N * H * W));
-        MIMO_TRY(dalloc(&g_dloss, (size_t)S));
-      }
-    }
     g_masks.resize(dcs.size());
     g_mask_ptrs.assign(dcs.size(), nullptr);
     for (size_t i = 0; i < dcs.size(); ++i) MIMO_TRY(dalloc(&g_masks[i], (size_t)N * dcs[i]->c2.Cout));
@@ -1078,9 +911,7 @@ struct mimo_plan {
     const bool x5 = args->stride_s == img && args->stride_n == (int64_t)S * img;
     const bool x4 = args->stride_s == 0 && args->stride_n == img;
     const int64_t rows = args->x_rows > 0 ? args->x_rows : N;
-    const bool tgraph = train_graph && training_call && !prof_on && (x5 || x4) && !args->elem_masks && rows <= N;
-    staged_train = false;
-    if (!tgraph && (!graph_enabled || training_call || prof_on || !(x5 || x4) || args->elem_masks || need_derive || rows > N)) {
+    if (!graph_enabled || training_call || prof_on || !(x5 || x4) || args->elem_masks || need_derive || rows > N) {
       const int rc = forward_impl(args, st);
       derived_version = rc == MIMO_OK ? version_after : -1;
       return rc;
@@ -1099,8 +930,8 @@ struct mimo_plan {
         MIMO_HIP_CHECK(hipMemcpyAsync(g_masks[i], args->drop_masks[i], (size_t)N * dcs[i]->c2.Cout * sizeof(float),
                                       hipMemcpyDeviceToDevice, st));
     }
-    hipGraphExec_t* exec = tgraph ? &tg_fwd.exec : &graph_exec;
-    uint64_t* ekey = tgraph ? &tg_fwd.key : &graph_key;
+    hipGraphExec_t* exec = &graph_exec;
+    uint64_t* ekey = &graph_key;
     if (!*exec || key != *ekey) {
       if (*exec) {
         (void)hipGraphExecDestroy(*exec);
@@ -1117,18 +948,12 @@ struct mimo_plan {
     elem_masks.clear();
     MIMO_HIP_CHECK(hipGraphLaunch(*exec, st));
     MIMO_HIP_CHECK(hipMemcpyAsync(args->out, g_out, (size_t)N * S * Co * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
-    // what a later backward / loss reads: the staged copies for a training graph (the backward graphs hold those
-    // pointers), the caller's tensors otherwise
-    for (size_t i = 0; i < dcs.size(); ++i)
-      dcs[i]->mask = tgraph ? g_mask_ptrs[i] : (args->drop_masks ? args->drop_masks[i] : nullptr);
-    out = tgraph ? g_out : args->out;
+    for (size_t i = 0; i < dcs.size(); ++i) dcs[i]->mask = args->drop_masks ? args->drop_masks[i] : nullptr;
+    out = args->out;
     fwd_done = true;
     fwd_training = training_call;
     had_perm = args->perm != nullptr;
     loss_done = false;
-    staged_train = tgraph;
-    staged_key = key;
-    g_rows = rows;
     derived_version = version_after;  // -1 after a training forward: the optimiser step invalidates the packed weights
     return MIMO_OK;
   }
@@ -1153,30 +978,6 @@ struct mimo_plan {
     return MIMO_OK;
   }
 
-  // ---- S independent chains on S streams (subnet_streams) ----
-  int fork_streams(hipStream_t st) {
-    MIMO_HIP_CHECK(hipEventRecord(sub_fork, st));
-    for (int i = 1; i < S; ++i) MIMO_HIP_CHECK(hipStreamWaitEvent(sub_streams[i], sub_fork, 0));
-    return MIMO_OK;
-  }
-  // the stream chain s is issued on; also switches the scratch that chain uses
-  hipStream_t chain_stream(bool fork, int s, hipStream_t st) {
-    s_partial = set_partial[fork ? s : 0];
-    s_sums = set_sums[fork ? s : 0];
-    s_tickets = set_tickets[fork ? s : 0];
-    return fork && s > 0 ? sub_streams[s] : st;
-  }
-  int join_streams(hipStream_t st) {
-    for (int i = 1; i < S; ++i) {
-      MIMO_HIP_CHECK(hipEventRecord(sub_join[i], sub_streams[i]));
-      MIMO_HIP_CHECK(hipStreamWaitEvent(st, sub_join[i], 0));
-    }
-    s_partial = set_partial[0];
-    s_sums = set_sums[0];
-    s_tickets = set_tickets[0];
-    return MIMO_OK;
-  }
-
   int forward_impl(const mimo_forward_args* args, hipStream_t st) {
     if (!params || !bnbuf) {
       set_error("mimo_forward: parameters not bound (mimo_plan_bind)");
@@ -1195,14 +996,10 @@ struct mimo_plan {
     for (int s = 0; s < S; ++s)
       MIMO_TRY(pack_input_launch(args->x, args->stride_n, args->stride_s, args->perm, s, N, Ci, H, W, enc_in[s]->in_buf,
                                  Ci_p, st));
-    const bool fork = subnet_streams && !capturing;
-    if (fork) MIMO_TRY(fork_streams(st));
-    for (int s = 0; s < S; ++s) {  // chain by chain, so that the chains' kernels interleave on the device
-      hipStream_t ss = chain_stream(fork, s, st);
-      MIMO_TRY(dc_forward(enc_in[s], training, ss));
-      MIMO_TRY(dc_forward(down1[s], training, ss));
+    for (int s = 0; s < S; ++s) {  // chain by chain
+      MIMO_TRY(dc_forward(enc_in[s], training, st));
+      MIMO_TRY(dc_forward(down1[s], training, st));
     }
-    if (fork) MIMO_TRY(join_streams(st));
     MIMO_TRY(dc_forward(down2, training, st));
     MIMO_TRY(dc_forward(down3, training, st));
     MIMO_TRY(dc_forward(down4, training, st));
@@ -1216,10 +1013,7 @@ struct mimo_plan {
     MIMO_TRY(dc_forward(up1, training, st));
     MIMO_TRY(dc_forward(up2, training, st));
     MIMO_TRY(dc_forward(up3, training, st));
-    if (fork) MIMO_TRY(fork_streams(st));
     for (int s = 0; s < S; ++s) {
-      hipStream_t st_main = st;
-      hipStream_t st = chain_stream(fork, s, st_main);  // this chain's stream for the rest of the body
       MIMO_TRY(dc_forward(up4[s], training, st));
       const Act& o = up4[s]->out;
       // final_dropouts[s]: in place, the head (forward and weight gradient) is the only reader
@@ -1235,7 +1029,6 @@ struct mimo_plan {
       prof_end(pr, 0.0, 4.0 * (double)N * H * W * (pad_channels(f) + Co), st);
       prof_end(blk, 0.0, 0.0, st);
     }
-    if (fork) MIMO_TRY(join_streams(st));
     out = args->out;
     fwd_done = true;
     fwd_training = training;
@@ -1252,19 +1045,6 @@ struct mimo_plan {
     if (!label_ || !loss_out) {
       set_error("mimo_loss_forward: null argument");
       return MIMO_ERR_INVALID;
-    }
-    if (staged_train) {
-      // the backward graphs read plan-owned copies (the caller's label / mask tensors move from step to step); perm_
-      // is the permutation of the forward, staged there
-      if ((perm_ != nullptr) != had_perm) {
-        set_error("mimo_loss_forward: permutation given to exactly one of forward / loss");
-        return MIMO_ERR_INVALID;
-      }
-      MIMO_HIP_CHECK(hipMemcpyAsync(g_label, label_, (size_t)g_rows * (Co / 2) * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
-      if (mask_) MIMO_HIP_CHECK(hipMemcpyAsync(g_lmask, mask_, (size_t)g_rows * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
-      label_ = g_label;
-      mask_ = mask_ ? g_lmask : nullptr;
-      perm_ = perm_ ? g_perm : nullptr;
     }
     int blocks = 0;
     MIMO_TRY(loss_fwd_launch(out, label_, mask_, perm_, N, S, Co, H * W, cfg.loss_kind, cfg.eps_min, cfg.eps_max,
@@ -1294,8 +1074,8 @@ struct mimo_plan {
     // (with the profiler armed everything runs on the caller's stream: per-kernel times, not overlapped times)
     const bool async = wg_async && !prof_on;
     const int b = dz_idx;
-    float* dz = (wg_deferred && L.dz_own) ? L.dz_own : s_dz2[b];
-    if (async && !wg_deferred) {
+    float* dz = s_dz2[b];
+    if (async) {
       dz_idx = (dz_idx + 1) % wg_bufs;
       if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
     }
@@ -1308,13 +1088,12 @@ struct mimo_plan {
     // gradient is too); fp32 otherwise, with a split copy for a bf16-pair weight gradient
     const float* dz_wg = dz;
     if (L.wg_split && !L.dg_split) {
-      float* dzs = (wg_deferred && L.dzs_own) ? L.dzs_own : s_dzs2[b];
+      float* dzs = s_dzs2[b];
       MIMO_TRY(split_pairs_launch(dz, dzs, P, L.cout_p, st));
       dz_wg = dzs;
     }
-    // wgrad(L) may start as soon as dz exists, next to dgrad(L) (releasing it only after dgrad(L), i.e. next
-    // to the bandwidth-bound kernels of the layer below, measured the same step time)
-    if (async && !wg_release_after_dgrad) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
+    // wgrad(L) may start as soon as dz exists, next to dgrad(L)
+    if (async) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
     // conv bias gradient: exactly zero in front of a training-mode BatchNorm (written by bn_bwd_stats above);
     // a real column sum of dz only after an eval-mode forward (running statistics: dz = scale * dy)
     if (!fwd_training) MIMO_TRY(colsum_vec_launch(s_partial, rows, L.cout_p, L.Cout, grads + L.off_b, colsum(), st));
@@ -1346,7 +1125,6 @@ struct mimo_plan {
         MIMO_TRY(conv3x3_launch(a, nullptr, st));
       prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
     }
-    if (async && wg_release_after_dgrad) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));  // behind this layer's data gradient
     hipStream_t ws = st;
     if (async) {
       MIMO_HIP_CHECK(hipStreamWaitEvent(wg_stream, ev_dz[b], 0));  // (a wait refers to the record made just above)
@@ -1355,7 +1133,7 @@ struct mimo_plan {
     WgradLaunch wg;
     wg.x = L.in;
     wg.dz = dz_wg;
-    wg.partial = wg_batched ? L.wslab : s_wslab;
+    wg.partial = s_wslab;
     wg.N = L.N;
     wg.H = L.H;
     wg.W = L.W;
@@ -1379,20 +1157,9 @@ struct mimo_plan {
       MIMO_HIP_CHECK(hipEventRecord(ev_wg[b], wg_stream));
       wg_pending[b] = true;
     }
-    if (!wg_batched)  // else: one batched reduction per backward stage (stage_reduce)
-      MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
-                                   grads + L.off_w, ws));
+    MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
+                                 grads + L.off_w, ws));
     return MIMO_OK;
-  }
-
-  // slabs of all layers of a backward stage -> their OIHW gradients, on the stream the weight gradients ran on
-  int stage_reduce(int stage, hipStream_t st) {
-    if (!wg_batched) return MIMO_OK;
-    hipStream_t ws = (wg_async && !prof_on) ? wg_stream : st;
-    const StageReduce& sr = stage_reduce_tab[stage];
-    for (size_t l = 0; l < sr.group_jobs.size(); ++l)
-      MIMO_TRY(wgrad_group_jobs_launch(sr.group_jobs[l], sr.group_count[l], sr.group_max_slab4[l], ws));
-    return wgrad_reduce_jobs_launch(sr.reduce_jobs, sr.reduce_count, sr.reduce_blocks, grads, ws);
   }
 
   // the caller's stream waits for every weight gradient issued so far
@@ -1448,7 +1215,7 @@ struct mimo_plan {
   // flat gradient buffer (laid out encoder | core down2..up3 | decoder | heads), final when the stage returns, so a
   // data-parallel caller can start that range's all-reduce while the later stages run:
   //   0 heads + decoders (up4)   1 up3   2 up2   3 up1   4 down4   5 down3   6 down2   7 encoders (+ dx)
-  static constexpr int kBwdStages = kBwdStagesDecl;
+  static constexpr int kBwdStages = 8;
   void stage_range(int stage, int64_t* b, int64_t* e) const {
     DoubleConv* core[6] = {up3, up2, up1, down4, down3, down2};
     if (stage == 0) {
@@ -1496,41 +1263,7 @@ struct mimo_plan {
       set_error("mimo_backward: stage %d requested, stage %d is next", stage_first, bwd_next_stage);
       return MIMO_ERR_STATE;
     }
-    const bool tgraph = staged_train && train_graph && !prof_on && dloss && !dout && !dx && loss_done;
-    if (tgraph) {
-      if (stage_first == 0)
-        MIMO_HIP_CHECK(hipMemcpyAsync(g_dloss, dloss, (size_t)S * sizeof(float), hipMemcpyDeviceToDevice, st));
-      const uint64_t key = staged_key | (lmask ? 1ull << 40 : 0);
-      // the stages are captured together, in order: the host-side bookkeeping that shapes the kernel arguments
-      // (first-writer / accumulate flags, skip-gradient hand-over) runs at capture time only
-      if (stage_first == 0 && (!tg_bwd[0].exec || tg_bwd[0].key != key))
-        for (GraphSlot& g : tg_bwd) {
-          if (g.exec) (void)hipGraphExecDestroy(g.exec);
-          g.exec = nullptr;
-        }
-      for (int stage = stage_first; stage <= stage_last; ++stage) {
-        GraphSlot& g = tg_bwd[stage];
-        if (!g.exec || g.key != key) {
-          if (g.exec) {
-            (void)hipGraphExecDestroy(g.exec);
-            g.exec = nullptr;
-          }
-          MIMO_TRY(capture(
-              [&](hipStream_t cs) {
-                MIMO_TRY(backward_stage(stage, nullptr, g_dloss, nullptr, cs));
-                return stage_reduce(stage, cs);
-              },
-              &g.exec));
-          g.key = key;
-        }
-        MIMO_HIP_CHECK(hipGraphLaunch(g.exec, st));
-      }
-    } else {
-      for (int stage = stage_first; stage <= stage_last; ++stage) {
-        MIMO_TRY(backward_stage(stage, dout, dloss, dx, st));
-        MIMO_TRY(stage_reduce(stage, st));
-      }
-    }
+    for (int stage = stage_first; stage <= stage_last; ++stage) MIMO_TRY(backward_stage(stage, dout, dloss, dx, st));
     bwd_next_stage = stage_last + 1 < kBwdStages ? stage_last + 1 : 0;
     return wg_join(st);  // the gradients of the stages run so far are final for the caller (all-reduce)
   }

@@ -3,16 +3,22 @@
 // g++ -fsanitize=address,undefined and sweeps every function over its whole argument range (tests/test_sched_cpu.py).
 #pragma once
 
+#if defined(__HIPCC__)
+#define MIMO_SCHED_HD __host__ __device__
+#else
+#define MIMO_SCHED_HD
+#endif
+
 namespace mimo {
 namespace sched {
 
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-static inline int rup(int a, int b) { return cdiv(a, b) * b; }
+MIMO_SCHED_HD static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+MIMO_SCHED_HD static inline int rup(int a, int b) { return cdiv(a, b) * b; }
 
 // Workgroups are dealt round-robin to the 8 XCDs in linear-id order; this maps a linear id to a virtual index such
 // that every XCD owns one CONTIGUOUS range of virtual indices.  Bijective on [0, total) for any total >= 1.
-// (device copy: xcd_virtual_index in common.h — same formula, kept in step by tests/test_sched_cpu.py)
-static inline int xcd_virtual_index(int linear, int total) {
+// (the kernels call this same function: common.h xcd_virtual_index)
+MIMO_SCHED_HD static inline int xcd_virtual_index(int linear, int total) {
   const int k = linear & 7, slot = linear >> 3;
   const int base = total >> 3, rem = total & 7;
   return k * base + (k < rem ? k : rem) + slot;
@@ -43,6 +49,70 @@ static inline void pick_tile_n(int Ho, int Wo, int npix, int maxpix, int* TR, in
   }
   *TR = best_tr;
   *TC = best_tc;
+}
+
+// ---- 256-pixel convolutions (conv3x3.hip fp32-MFMA kernel, conv_bf16x3.hip) ---------------------------------------
+// fragments of 16 output channels per workgroup: the width in 2..4 that pads the channel count least (ties -> wider)
+static inline int conv_pick_nfrag(int cout) {
+  const int nfr = cdiv(cout, 16);
+  if (nfr <= 1) return 1;
+  int best = 2, best_cost = 1 << 30;
+  for (int nf = 4; nf >= 2; --nf) {
+    const int cost = rup(nfr, nf);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = nf;
+    }
+  }
+  return best;
+}
+static inline int conv_cout_pad(int cout) { return rup(cdiv(cout, 16), conv_pick_nfrag(cout)) * 16; }
+
+// ---- split weight gradient (wgrad_split.hip) --------------------------------------------------------------------
+constexpr int kWgTC = 32;  // pixel-tile width of the weight-gradient kernels
+// channel tile (32 / 48 / 64) that pads least; 48 only where it saves >= 30 % of padded work
+static inline int wg_pick_ctile(int c_p) {
+  if (c_p <= 32) return 32;
+  const int p64 = rup(c_p, 64), p48 = rup(c_p, 48);
+  return double(p48) <= 0.70 * p64 ? 48 : 64;
+}
+static inline void wg_tiles(int cin_p, int cout_p, bool ws_enabled, int* CI, int* CO) {
+  *CI = wg_pick_ctile(cin_p);
+  *CO = wg_pick_ctile(cout_p);
+  // the wave-specialised kernel (64 input channels per workgroup) also comes 32 and 48 output channels wide and keeps
+  // its efficiency there: take the 48-wide tile whenever it saves >= 15 % of padded work
+  if (*CI == 64 && ws_enabled && cout_p > 32 && rup(cout_p, 48) <= 0.85 * rup(cout_p, 64)) *CO = 48;
+}
+static inline bool wg_use_ws(int CI, int CO, bool ws_enabled) {
+  return ws_enabled && (CI == 64 || CI == 32) && (CO == 32 || CO == 48 || CO == 64);
+}
+static inline int wg_ws_tr(int CI) { return CI == 32 ? 4 : 2; }  // tile rows of the wave-specialised kernel
+static inline int wg_num_tiles(int N, int H, int W, int tr) { return N * cdiv(H, tr) * cdiv(W, kWgTC); }
+// pixel splits (slabs) of a layer's weight gradient: >= 1, <= min(tiles, 1024)
+static inline int wg_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO, bool ws_enabled, int mode) {
+  const int wtiles = (cin_pad / CI) * (cout_pad / CO);
+  const bool ws = wg_use_ws(CI, CO, ws_enabled);
+  const int tiles = wg_num_tiles(N, H, W, ws ? wg_ws_tr(CI) : 4);
+  if (!ws || mode == 0) {
+    int splits = cdiv(512, wtiles);  // one 4-wave workgroup per CU: ~2 rounds of workgroups
+    if (splits > tiles) splits = tiles;
+    if (splits > 1024) splits = 1024;
+    if (splits < 1) splits = 1;
+    return splits;
+  }
+  // wave-specialised kernel: one workgroup per CU (128 KB of LDS), all workgroups of a launch do the same work, so
+  // time ~ rounds x (pixel tiles per workgroup + fixed cost); the fixed cost (147 KB slab written per workgroup and
+  // re-read by the reduction, pipeline fill) is worth about `kFixed` pixel tiles.
+  const int kCUs = 256;
+  const int kFixed = 16 / wg_ws_tr(CI);
+  int best = 1;
+  long bestCost = -1;
+  for (int s = 1; s <= tiles && s <= 1024; ++s) {
+    const long rounds = cdiv(wtiles * s, kCUs);
+    const long cost = rounds * (cdiv(tiles, s) + kFixed);
+    if (bestCost < 0 || cost < bestCost) bestCost = cost, best = s;
+  }
+  return best;
 }
 
 // ---- wide convolution (conv_wide.hip): 512-pixel tiles, 16-channel K chunks, 32x32x16 MFMA ----------------------

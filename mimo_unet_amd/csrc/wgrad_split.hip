@@ -568,58 +568,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       }
 }
 
-// (ci tile, co tile) of the split kernel for a layer: 32, 48 or 64 channels, whichever pads least
-// (ties -> the larger tile: fewer re-reads of the other operand)
-static int pick_ctile(int c_p) {
-  if (c_p <= 32) return 32;
-  // 48-wide tiles only where they save >= 30 % of padded work (measured: the wave-specialised 64x64
-  // kernel with 25 % padding beats the 48-wide configuration on the 96->48 decoder layer): they hold
-  // more accumulators per wave and run a little slower per MFMA than the 64-wide configuration
-  const int p64 = round_up(c_p, 64), p48 = round_up(c_p, 48);
-  return (double)p48 <= 0.70 * p64 ? 48 : 64;
-}
+// host-side choices (channel tiles, split counts): sched.h, host-testable
 static bool wgrad_ws_enabled() {
   static const bool on = !(getenv("MIMO_WGRAD_WS") && atoi(getenv("MIMO_WGRAD_WS")) == 0);
   return on;
 }
-void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO) {
-  *CI = pick_ctile(cin_p);
-  *CO = pick_ctile(cout_p);
-  // the wave-specialised kernel (64 input channels per workgroup) also comes 32 and 48 output channels wide
-  // and keeps its efficiency there: take the 48-wide tile whenever it saves >= 15 % of padded work
-  if (*CI == 64 && wgrad_ws_enabled() && cout_p > 32 && round_up(cout_p, 48) <= 0.85 * round_up(cout_p, 64)) *CO = 48;
-}
-
-static bool wgrad_use_ws(int CI, int CO) {
-  return wgrad_ws_enabled() && (CI == 64 || CI == 32) && (CO == 32 || CO == 48 || CO == 64);
-}
-
-int wgrad_split_num_tiles(int N, int H, int W, int tr) { return N * ceil_div(H, tr) * ceil_div(W, kWgTC); }
-
+void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO) { sched::wg_tiles(cin_p, cout_p, wgrad_ws_enabled(), CI, CO); }
+static bool wgrad_use_ws(int CI, int CO) { return sched::wg_use_ws(CI, CO, wgrad_ws_enabled()); }
 int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO) {
-  const int wtiles = (cin_pad / CI) * (cout_pad / CO);
-  const int tiles = wgrad_split_num_tiles(N, H, W, wgrad_use_ws(CI, CO) ? wgrad_ws_tr(CI) : kWgTR);
   static const int mode = [] { const char* e = getenv("MIMO_WGRAD_SPLIT_MODE"); return e ? atoi(e) : 1; }();
-  if (!wgrad_use_ws(CI, CO) || mode == 0) {
-    int splits = ceil_div(512, wtiles);  // one 4-wave workgroup per CU: ~2 rounds of workgroups
-    if (splits > tiles) splits = tiles;
-    if (splits > 1024) splits = 1024;
-    if (splits < 1) splits = 1;
-    return splits;
-  }
-  // wave-specialised kernel: one workgroup per CU (128 KB of LDS), all workgroups of a launch do the same
-  // work, so time ~ rounds x (pixel tiles per workgroup + fixed cost); the fixed cost (147 KB slab written
-  // per workgroup and re-read by the reduction, pipeline fill) is worth about `kFixed` pixel tiles.
-  constexpr int kCUs = 256;
-  const int kFixed = 16 / wgrad_ws_tr(CI);  // in pixel tiles of this kernel
-  int best = 1;
-  long bestCost = -1;
-  for (int s = 1; s <= tiles && s <= 1024; ++s) {
-    const long rounds = ceil_div(wtiles * s, kCUs);
-    const long cost = rounds * (ceil_div(tiles, s) + kFixed);
-    if (bestCost < 0 || cost < bestCost) bestCost = cost, best = s;
-  }
-  return best;
+  return sched::wg_pick_splits(N, H, W, cin_pad, cout_pad, CI, CO, wgrad_ws_enabled(), mode);
 }
 
 int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {

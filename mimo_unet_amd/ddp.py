@@ -10,6 +10,7 @@ backward — one slice per core block as it becomes final (RCCL runs them on its
 waited for right before the optimiser."""
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional
 
 import torch
@@ -48,6 +49,7 @@ class FlatGradientAllReducer:
         self.min_floats = max(1, min(min_bucket_bytes, bucket_bytes) // 4)
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.always = False  # issue the collectives even with one rank (functional check of the RCCL path)
+        self.enabled = True  # False inside no_sync(): ranges announced by the backward are not reduced
         self._pending: List = []
         self._held = None  # (flat, begin, end): announced, not yet issued
         self.issued: List = []  # [(begin, end)] of the collectives of the current step (diagnostics / tests)
@@ -68,9 +70,26 @@ class FlatGradientAllReducer:
             self._held = None
             self._issue(flat, b, e)
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation (the counterpart of DistributedDataParallel.no_sync): run every micro-batch but the
+        LAST one inside this context.  Their backward passes only accumulate locally; the last micro-batch's backward
+        then announces — and all-reduces — the accumulated sum once.  Without it micro-batch 1 would be summed over the
+        ranks when its ranges become final and again with micro-batch 2 (MimoUNet refuses that: it raises)."""
+        prev, self.enabled = self.enabled, False
+        try:
+            yield self
+        finally:
+            self.enabled = prev
+
+    @property
+    def busy(self) -> bool:
+        """collectives in flight or a range held for merging"""
+        return bool(self._pending) or self._held is not None
+
     def start(self, flat: torch.Tensor, begin: int = 0, end: Optional[int] = None) -> None:
         """flat[begin:end] is final: issue its async all-reduce, or hold it to merge with an adjacent range."""
-        if self.world_size == 1 and not self.always:
+        if not self.enabled or (self.world_size == 1 and not self.always):
             return
         end = flat.numel() if end is None else end
         if self._held is not None:
@@ -101,3 +120,4 @@ class FlatGradientAllReducer:
         gradient buffer is final (after each backward stage, include/mimo_hip.h); call `finish()` before
         the optimiser step."""
         net.grad_ready_hook = self.start
+        net.grad_sync = self  # lets the backward drain in-flight collectives before it rewrites the buffer, and see no_sync()

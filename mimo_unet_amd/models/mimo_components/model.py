@@ -292,7 +292,10 @@ class MimoUNet(nn.Module):
                 slot += 1
         if plan is None:
             while len(self._plans) >= self._plan_cache_size:
-                self._plans.popitem(last=False)  # a pending autograd node keeps its own reference to its plan
+                # a pending autograd node keeps its own reference to its plan.  What the evicted plan recorded in its
+                # numerics status word (a NaN on a ragged last batch, say) outlives it: numerics_status() ORs it in
+                _, old = self._plans.popitem(last=False)
+                self._evicted_status = getattr(self, "_evicted_status", 0) | old.status(True)
             plan = Plan(self._geom, n, x.shape[-2], x.shape[-1], x.device, inference_only=inference)
             plan.generation = 0
             plan.pending = None
@@ -433,12 +436,24 @@ class MimoUNet(nn.Module):
         # torch semantics: gradients accumulate until zero_grad().  The engine overwrites the flat
         # buffer, so keep a copy when a live .grad still aliases it.
         aliased = any(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in views)
+        hook = self.grad_ready_hook
+        sync = getattr(self, "grad_sync", None)  # the reducer behind the hook (FlatGradientAllReducer.attach), if any
+        announcing = hook is not None and (sync is None or sync.enabled)
+        if not aliased:
+            self._reduced_in_window = False  # a fresh accumulation window (zero_grad() dropped the gradients)
+        elif announcing and sync is not None and getattr(self, "_reduced_in_window", False):
+            # data-parallel gradient accumulation done wrong: the gradients of an earlier micro-batch were already
+            # summed over the ranks in place; adding them to this micro-batch and reducing again would count them
+            # world_size times
+            raise RuntimeError("MimoUNet: a second backward accumulates into gradients that were already all-reduced; run "
+                               "every micro-batch but the last under FlatGradientAllReducer.no_sync() (mimo_unet_amd.ddp)")
+        if aliased and sync is not None and sync.busy:
+            sync.finish()  # nothing may still be reducing the buffer the clone below reads and the backward rewrites
         saved = g.clone() if aliased else None
         plan.bind(self._flat_params, g, self._flat_buffers)
-        hook = self.grad_ready_hook
         if hook is None:
             plan.backward(dout, dloss, dx)
-        elif aliased:
+        elif aliased or not announcing:
             # gradient accumulation (a live .grad aliases the flat buffer): the fix-up below adds the saved
             # gradients into the same memory an in-flight all-reduce would be reducing, so the ranges are only
             # announced once they are final — no overlap on accumulating micro-batches
@@ -450,6 +465,7 @@ class MimoUNet(nn.Module):
             for st, (b, e) in enumerate(plan.backward_stages):
                 plan.backward(dout, dloss, dx, stage=st)
                 hook(g, b, e)
+            self._reduced_in_window = True
         for p, v in views:
             if p.grad is None:
                 p.grad = v
@@ -458,9 +474,10 @@ class MimoUNet(nn.Module):
                 v.add_(saved[off: off + v.numel()].view(v.shape))
             else:
                 p.grad.add_(v)
-        if hook is not None and aliased:
+        if announcing and aliased:
             for b, e in plan.backward_stages:
                 hook(g, b, e)
+            self._reduced_in_window = True
 
     def numerics_status(self, clear: bool = True) -> int:
         """OR of the numerics status words of the live plans (`Plan.status`; one device synchronisation per plan).
@@ -468,7 +485,9 @@ class MimoUNet(nn.Module):
         clear — a diverged run, or a value outside what the precision mode represents: the default "split16" forward
         carries activations as fp16 (hi, lo) pairs and weights as fp16 pairs x 2^8, so |activation| >= 65520 or
         |weight| >= 256 overflows there where the reference's fp32 path does not ("fp32" mode has fp32 range)."""
-        flags = 0
+        flags = getattr(self, "_evicted_status", 0)  # recorded by plans the LRU cache has dropped since
+        if clear:
+            self._evicted_status = 0
         for plan in list(self._plans.values()):
             flags |= plan.status(clear)
         return flags

@@ -121,3 +121,4 @@ class FlatAdam(torch.optim.Optimizer):
                                         "exp_avg_sq": v["exp_avg_sq"].detach().clone()} for k, v in per_param.items()}
             self._m = self._v = None
             self._step = 0
+            self._step_dev = None  # a device-side step count of earlier GradScaler steps must not survive the load

@@ -18,6 +18,4 @@ for P in bf16 bf16-mixed 16-mixed; do
 done
 runp fp32 python bench.py --steps 10 --warmup 3 --no-cpu-baseline
 run python bench.py --batch 4 --steps 30 --warmup 8 --no-cpu-baseline --profile-steps 0
-echo "CMD MIMO_TRAIN_GRAPH=1 python bench.py --batch 4 --steps 30 --warmup 8 --no-cpu-baseline --profile-steps 0" >> $O
-MIMO_TRAIN_GRAPH=1 python bench.py --batch 4 --steps 30 --warmup 8 --no-cpu-baseline --profile-steps 0 2>/dev/null | tail -n 1 >> $O
 cat $O | cut -c1-200

@@ -23,7 +23,6 @@ for cmd, res in zip(lines[0::2], lines[1::2]):
                  "bf16 MFMA operands / fp32 accumulate and storage (reduced precision)" if "bf16" in cmd else
                  "fp32 MFMA" if "fp32" in cmd else "default split16 arithmetic")
         extra = ", batch 4 per GPU (the per-GPU batch of an 8-way strong-scaling run)" if "--batch 4" in cmd else ""
-        extra += ", training-step hipGraph replay" if "MIMO_TRAIN_GRAPH=1" in cmd else ""
         e = {"what": f"{WHAT[cfg]}{extra}, {arith}", "images_per_s": d["value"], "ms_per_step": d["ms_per_step"],
              "hbm_frac_step": d.get("hbm_frac_step")}
         if "roofline" in d:

@@ -1,0 +1,159 @@
+// Host-only sweep of the schedulers in mimo_unet_amd/csrc/sched.h, built with -fsanitize=address,undefined by
+// tests/test_sched_cpu.py (race / memory tooling of the host side).
+//   * xcd_virtual_index: a bijection on [0, total) for every grid size 1 .. 4096, every XCD a contiguous range
+//   * pick_tile_n: for every H, W in 1 .. 300 and both tile sizes, the tiles cover every pixel exactly once, fit the
+//     pixel budget and the LDS halo budget
+//   * wide_config / wide_grid_x: geometry invariants for every BASELINE layer at N in {1, 2, 4, 16, 32, 64}
+//   * weight-gradient channel tiles / split counts: >= 1, slabs within the plan's scratch formula
+//   * conv_cout_pad: covers the channels, multiple of the fragment width
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../mimo_unet_amd/csrc/sched.h"
+
+using namespace mimo::sched;
+
+static int failures = 0;
+#define CHECK(cond, ...)                      \
+  do {                                        \
+    if (!(cond)) {                            \
+      if (failures < 20) {                    \
+        std::printf("FAIL %s: ", #cond);      \
+        std::printf(__VA_ARGS__);             \
+        std::printf("\n");                    \
+      }                                       \
+      ++failures;                             \
+    }                                         \
+  } while (0)
+
+static void test_xcd() {
+  std::vector<int> seen;
+  for (int total = 1; total <= 4096; ++total) {
+    seen.assign(total, 0);
+    for (int lin = 0; lin < total; ++lin) {
+      const int v = xcd_virtual_index(lin, total);
+      CHECK(v >= 0 && v < total, "total %d linear %d -> %d", total, lin, v);
+      if (v >= 0 && v < total) ++seen[v];
+    }
+    for (int v = 0; v < total; ++v) CHECK(seen[v] == 1, "total %d: virtual index %d hit %d times", total, v, seen[v]);
+    // every XCD (linear % 8) owns one contiguous, increasing range
+    for (int k = 0; k < 8 && k < total; ++k) {
+      int prev = -1;
+      for (int lin = k; lin < total; lin += 8) {
+        const int v = xcd_virtual_index(lin, total);
+        CHECK(prev < 0 || v == prev + 1, "total %d xcd %d: %d after %d", total, k, v, prev);
+        prev = v;
+      }
+    }
+  }
+}
+
+static void test_tiles() {
+  const int cfgs[3][2] = {{256, 360}, {512, 640}, {128, 180}};
+  std::vector<unsigned char> cover;
+  for (auto& c : cfgs)
+    for (int H = 1; H <= 300; ++H)
+      for (int W = 1; W <= 300; ++W) {
+        int TR = 0, TC = 0;
+        pick_tile_n(H, W, c[0], c[1], &TR, &TC);
+        CHECK(TR >= 1 && TC >= 1 && TR * TC <= c[0], "%dx%d npix %d: tile %dx%d", H, W, c[0], TR, TC);
+        CHECK((TR + 2) * (TC + 2) <= c[1], "%dx%d: halo %d > %d", H, W, (TR + 2) * (TC + 2), c[1]);
+        if (TR < 1 || TC < 1) continue;
+        if ((H * 7 + W) % 5 != 0 && !(H <= 40 && W <= 40)) continue;  // full cover check on a fifth of the sizes
+        cover.assign((size_t)H * W, 0);
+        const int ty = cdiv(H, TR), tx = cdiv(W, TC);
+        for (int a = 0; a < ty; ++a)
+          for (int b = 0; b < tx; ++b)
+            for (int i = 0; i < TR * TC; ++i) {
+              const int y = a * TR + i / TC, x = b * TC + i % TC;
+              if (y < H && x < W) ++cover[(size_t)y * W + x];
+            }
+        for (size_t i = 0; i < cover.size(); ++i)
+          if (cover[i] != 1) {
+            CHECK(false, "%dx%d tile %dx%d: pixel %zu covered %d times", H, W, TR, TC, i, cover[i]);
+            break;
+          }
+      }
+}
+
+struct Layer {
+  int cin, cout, h;
+};
+static std::vector<Layer> baseline_layers() {
+  std::vector<Layer> v;
+  // BASELINE configs 2-5 at 256x256: (S, f) = (2, 21), (2, 30), (4, 30), (1, 30); Ci = 3 / 2
+  const int sf[4][3] = {{2, 21, 3}, {2, 30, 2}, {4, 30, 2}, {1, 30, 2}};
+  for (auto& c : sf) {
+    const int S = c[0], f = c[1], Ci = c[2], fs = f * S;
+    const Layer l[] = {{Ci, f, 256}, {f, f, 256}, {f, 2 * f, 128}, {2 * f, 2 * f, 128}, {2 * fs, 4 * fs, 64},
+                       {4 * fs, 4 * fs, 64}, {4 * fs, 8 * fs, 32}, {8 * fs, 8 * fs, 32}, {8 * fs, 8 * fs, 16},
+                       {16 * fs, 8 * fs, 32}, {8 * fs, 4 * fs, 32}, {8 * fs, 4 * fs, 64}, {4 * fs, 2 * fs, 64},
+                       {4 * fs, 2 * fs, 128}, {2 * fs, fs, 128}, {f * (S + 1), f * (S + 1) / 2, 256},
+                       {f * (S + 1) / 2, f, 256}};
+    for (auto& x : l) v.push_back(x);
+  }
+  return v;
+}
+static int pad8(int c) { return rup(c, 8); }
+
+static void test_layers() {
+  const int batches[6] = {1, 2, 4, 16, 32, 64};
+  for (const Layer& L : baseline_layers())
+    for (int N : batches) {
+      const int cin_p = L.cin <= 4 ? rup(L.cin, 4) : pad8(L.cin), cout_p = pad8(L.cout);
+      // --- channel padding of the 256-pixel kernels
+      const int cp = conv_cout_pad(L.cout), nf = conv_pick_nfrag(L.cout);
+      CHECK(cp >= L.cout && cp % (16 * nf) == 0 && cp < L.cout + 16 * nf, "cout %d: pad %d nfrag %d", L.cout, cp, nf);
+      // --- wide convolution: forward (mode 1) and data gradient (mode 0), rule and forced, split16 and 16-bit storage
+      const int modes[4] = {1, 0, 4, 5};
+      for (int mode : modes)
+        for (int force = 0; force <= 1; ++force) {
+          const bool fwd = mode == 1 || mode == 4;
+          const int K = fwd ? cin_p : cout_p, R = fwd ? cout_p : cin_p, Ho = fwd ? L.h : L.h + 2;
+          const WideCfg c = wide_config(mode, N, K, R, Ho, Ho, force);
+          if (c.nf == 0) continue;
+          CHECK((c.nf == 1 || c.nf == 2) && c.rows_pad >= R && c.rows_pad % (32 * c.nf) == 0 && c.rows_pad < R + 64,
+                "wide rows: %d->%d nf %d rows_pad %d", K, R, c.nf, c.rows_pad);
+          CHECK(c.TR * c.TC <= kWideNPix && (c.TR + 2) * (c.TC + 2) <= kWideMaxPix, "wide tile %dx%d", c.TR, c.TC);
+          const int tiles = N * cdiv(Ho, c.TR) * cdiv(Ho, c.TC), cot = c.rows_pad / (32 * c.nf);
+          const int gx = wide_grid_x(tiles, cot);
+          CHECK(gx >= 1 && gx <= tiles && (gx * cot <= 256 || gx == 1), "wide grid: tiles %d cot %d gx %d", tiles, cot, gx);
+          // every workgroup column walks ceil or floor(tiles / gx) tiles, at least one
+          CHECK((tiles - 1 - (gx - 1)) / gx + 1 >= 1, "wide grid: last column without a tile");
+          // the launch recomputes the configuration from (mode, geometry) alone with force = 1: same rows
+          const WideCfg c2 = wide_config(mode, N, K, R, Ho, Ho, 1);
+          CHECK(c2.rows_pad == c.rows_pad && c2.nf == c.nf, "wide: launch sees %d rows, packer %d", c2.rows_pad, c.rows_pad);
+        }
+      // --- weight gradient
+      for (int ws = 0; ws <= 1; ++ws)
+        for (int mode = 0; mode <= 1; ++mode) {
+          int CI = 0, CO = 0;
+          wg_tiles(cin_p, cout_p, ws != 0, &CI, &CO);
+          CHECK((CI == 32 || CI == 48 || CI == 64) && (CO == 32 || CO == 48 || CO == 64), "wg tiles %d %d", CI, CO);
+          const int cin_pad = rup(cin_p, CI), cout_pad = rup(cout_p, CO);
+          const int s = wg_pick_splits(N, L.h, L.h, cin_pad, cout_pad, CI, CO, ws != 0, mode);
+          const int tiles = wg_num_tiles(N, L.h, L.h, wg_use_ws(CI, CO, ws != 0) ? wg_ws_tr(CI) : 4);
+          CHECK(s >= 1 && s <= 1024 && s <= tiles, "wg splits %d (tiles %d) for %d->%d @%d N %d", s, tiles, L.cin, L.cout, L.h, N);
+          // slabs + group-sum levels fit the plan's scratch formula (plan.hip cap_slab: splits + splits / 8 + 2 slabs)
+          int extra = 0;
+          for (int n = s; n > 1;) {
+            n = cdiv(n, 16);
+            extra += n;
+          }
+          CHECK(extra <= s / 8 + 2, "wg reduce levels %d > %d for %d splits", extra, s / 8 + 2, s);
+        }
+    }
+}
+
+int main() {
+  test_xcd();
+  test_tiles();
+  test_layers();
+  if (failures) {
+    std::printf("%d check(s) failed\n", failures);
+    return 1;
+  }
+  std::printf("sched_test: all checks passed\n");
+  return 0;
+}

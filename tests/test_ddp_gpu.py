@@ -73,6 +73,70 @@ def test_two_rank_training_step_gloo_on_gpu():
     assert all(c0[i][0] == c0[i + 1][1] for i in range(7))
 
 
+def _accum_worker(rank, world, port, q):
+    """Two micro-batches per optimiser step: the first under no_sync(), the second announces the accumulated sum."""
+    import torch.distributed as dist
+    from mimo_unet_amd.ddp import FlatGradientAllReducer
+    from tests.test_network_gpu import build_model
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    g = torch.Generator().manual_seed(11 + rank)
+    micro = [(torch.rand(2, 2, 32, 32, generator=g).cuda(), torch.rand(2, 1, 32, 32, generator=g).cuda()) for _ in range(2)]
+    perms = torch.stack([torch.arange(2), torch.tensor([1, 0])]).cuda()
+    ones = lambda: torch.ones(cfg.num_subnetworks, device="cuda")
+    local = []
+    for im, lb in micro:  # local gradients of each micro-batch, no reducer
+        m = build_model(cfg, state_from(fx, "init/"))
+        m.train()
+        m.loss_buffer.get_weights = ones
+        m.training_step_with_perms(im, lb, None, perms)["loss"].backward()
+        local.append(m.model.flat_gradients().clone().cpu())
+    model = build_model(cfg, state_from(fx, "init/"))
+    model.train()
+    model.loss_buffer.get_weights = ones
+    red = FlatGradientAllReducer(bucket_bytes=1 << 18)
+    red.attach(model.model)
+    with red.no_sync():
+        model.training_step_with_perms(*micro[0], None, perms)["loss"].backward()
+    assert not red.busy and not red.issued
+    model.training_step_with_perms(*micro[1], None, perms)["loss"].backward()
+    red.finish()
+    reduced = model.model.flat_gradients().clone().cpu()
+    # the mistake the guard catches: a third backward into already-reduced gradients
+    refused = False
+    try:
+        model.training_step_with_perms(*micro[0], None, perms)["loss"].backward()
+    except RuntimeError as e:
+        refused = "no_sync" in str(e)
+    torch.cuda.synchronize()
+    q.put((rank, (local[0] + local[1]).numpy(), reduced.numpy(), refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_under_the_reducer_sums_each_micro_batch_once():
+    """with the reducer attached, micro-batch 1 used to be all-reduced when its ranges became final and again
+    together with micro-batch 2.  no_sync() defers the exchange to the last micro-batch; a backward into gradients that
+    were already reduced is refused."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_accum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, s0, r0, f0), (_, s1, r1, f1) = [(r, torch.from_numpy(a), torch.from_numpy(b), c) for r, a, b, c in res]
+    assert torch.equal(r0, r1) and torch.allclose(r0, s0 + s1, rtol=1e-5, atol=1e-8)
+    assert f0 and f1
+
+
 def _run_bench(extra_env, *argv):
     import json
     import subprocess
@@ -96,9 +160,13 @@ def test_bench_spawns_its_own_ranks_gloo_sharing_the_gpu():
                       "--scaling", "strong", "--profile-steps", "0", "--no-cpu-baseline")
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
     cfg = line["config"]
-    assert cfg["global_batch"] == 4 and cfg["per_gpu_batch"] == 2 and cfg["rccl_ranks"] == 2
+    assert cfg["global_batch"] == 4 and cfg["per_gpu_batch"] == 2
+    assert cfg["world_size"] == 2 and cfg["backend"] == "gloo" and cfg["rccl_ranks"] is None  # RCCL did not run
     assert cfg["params_bit_identical_across_ranks"] is True
     assert line["value"] > 0 and "roofline" not in line
+    # both regimes in the one line: the timed one (strong: 4 global) and the other from a second timed pass
+    assert cfg["strong_images_per_s"] == line["value"] and cfg["weak_images_per_s"] > 0
+    assert cfg["weak_per_gpu_batch"] == 4 and cfg["strong_global_batch"] == 4
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
@@ -106,4 +174,6 @@ def test_bench_two_ranks_rccl():
     line = _run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4", "--profile-steps", "0",
                       "--no-cpu-baseline")
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 8
-    assert line["config"]["rccl_ranks"] == 2 and line["config"]["params_bit_identical_across_ranks"] is True
+    assert line["config"]["rccl_ranks"] == 2 and line["config"]["backend"] == "nccl"
+    assert line["config"]["params_bit_identical_across_ranks"] is True
+    assert len(set(line["config"]["rank_devices"])) == 2  # one GPU per rank

@@ -151,8 +151,14 @@ def test_fp16_mixed_training_under_torch_grad_scaler():
     a, b = model.model.flat_parameters(), ref_model.model.flat_parameters()
     d = float((a - b).abs().max())
     report(f"16-mixed + GradScaler, 3 Adam steps on mini_s2: max |param - split16 param| {d:.2e} (lr 1e-3: 3 steps move a parameter by <= 3e-3)")
-    assert d <= 2.02 * 3 * 1e-3  # Adam: sign-level differences of noisy gradients, bounded by the step budget
-    assert float((a - b).pow(2).mean().sqrt()) < 0.5 * 3e-3
+    # Adam turns a pure-noise gradient (a conv bias in front of BatchNorm) into +-lr steps: two arithmetics can walk such
+    # a parameter in opposite directions on every step, so the MAXIMUM sits at the step budget 2 x 3 x lr by construction
+    # (observed 5.96e-3).  The bound on it therefore carries a real margin (10 %), and the test is carried by the bulk:
+    # the rms difference and the share of parameters that moved apart by more than one step budget
+    frac_far = float(((a - b).abs() > 3e-3).float().mean())
+    report(f"16-mixed + GradScaler: rms difference {float((a - b).pow(2).mean().sqrt()):.2e}, share beyond 3e-3: {frac_far:.4f}")
+    assert d <= 2.2 * 3 * 1e-3
+    assert float((a - b).pow(2).mean().sqrt()) < 0.5 * 3e-3 and frac_far < 0.02
     # overflow: a scale of 2^40 pushes the scaled gradients out of fp16's range
     before, steps_before = a.clone(), opt.step_count
     big = torch.amp.GradScaler("cuda", init_scale=2.0 ** 40)

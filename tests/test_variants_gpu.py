@@ -11,15 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = {
     "conv_ws_off": {"MIMO_CONV_WS": "0"},               # non-specialised split convolution on every image size
-    "conv_ws_swizzle": {"MIMO_CONV_WS_SWIZZLE": "1"},   # XOR-swizzled 128-byte LDS rows
     "wgrad_ws_off": {"MIMO_WGRAD_WS": "0"},             # 4-wave weight gradient for 64x64 tiles too
     "wgrad_split_mode0": {"MIMO_WGRAD_SPLIT_MODE": "0"},
     "side_stream_off": {"MIMO_WGRAD_STREAM": "0"},      # weight gradients on the caller's stream (the default is the side stream)
-    "side_stream_3_buffers": {"MIMO_WGRAD_STREAM": "1", "MIMO_WGRAD_BUFFERS": "3"},
-    "side_stream_deferred": {"MIMO_WGRAD_STREAM": "2"},  # per-layer dz buffers: weight gradients queue without back-pressure
     "no_graph": {"MIMO_HIP_GRAPH": "0"},
-    "wgrad_reduce_batched": {"MIMO_WGRAD_BATCHED_REDUCE": "1"},  # one reduction launch sequence per backward stage
-    "subnet_streams": {"MIMO_SUBNET_STREAMS": "1"},     # encoder / decoder chains of the S subnetworks on S streams
     "skip_copy": {"MIMO_SKIP_IN_PLACE": "0"},           # skip tensors copied into the concat buffers
     "skip_grad_copy": {"MIMO_SKIP_GRAD_IN_PLACE": "0"},  # skip-connection gradients copied out by fold_slice
     "pool_fused_off": {"MIMO_POOL_FUSED": "0"},         # separate MaxPool2d pass after BatchNorm + ReLU
