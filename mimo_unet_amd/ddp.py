@@ -32,6 +32,26 @@ def shard_batch(batch: Dict[str, Optional[torch.Tensor]], rank: int, world_size:
     return out
 
 
+def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """BatchNorm running statistics under data parallelism.  Every rank normalises with the statistics of its OWN shard
+    (no SyncBatchNorm — what Lightning DDP does with the reference module) and so keeps its own running_mean /
+    running_var; parameters stay bit-identical across ranks, these buffers do not.  The checkpoint semantics are
+    "rank 0's buffers" (Lightning saves on rank 0 only): before a checkpoint — and before any evaluation whose result
+    must not depend on the rank — every rank takes rank `src`'s buffers.  MimoUnetModel / EvidentialUnetModel call this
+    from `on_save_checkpoint` and `on_validation_epoch_start`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    flat = getattr(module, "_flat_buffers", None)
+    if flat is not None:
+        dist.broadcast(flat, src, group=group)  # the engine keeps all of them in one flat tensor
+        mark = getattr(module, "mark_parameters_changed", None)
+        if mark is not None:
+            mark()  # written through .data semantics: cached inference weights / eval constants are stale
+        return
+    for b in module.buffers():
+        dist.broadcast(b.data, src, group=group)
+
+
 class FlatGradientAllReducer:
     """Sum all-reduce of a flat gradient buffer, started range by range while the backward is still running;
     `scale` is what the optimiser must multiply gradients by afterwards (1/world: FlatAdam.reduce_scale).

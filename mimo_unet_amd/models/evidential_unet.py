@@ -97,6 +97,14 @@ class EvidentialUnetModel(LightningModule):
     def on_validation_epoch_end(self) -> None:
         self.model.check_numerics()
 
+    def on_save_checkpoint(self, checkpoint) -> None:  # see MimoUnetModel: rank 0's BatchNorm buffers
+        from ..ddp import broadcast_buffers
+        broadcast_buffers(self.model)
+
+    def on_validation_epoch_start(self) -> None:
+        from ..ddp import broadcast_buffers
+        broadcast_buffers(self.model)
+
     def configure_optimizers(self) -> Dict[str, Any]:
         if self.use_fused_optimizer:
             optimizer = FlatAdam(self.model, lr=self.learning_rate, weight_decay=self.weight_decay)

@@ -194,6 +194,15 @@ class MimoUnetModel(LightningModule):
     def on_validation_epoch_end(self) -> None:
         self.model.check_numerics()
 
+    # data parallel: BatchNorm running statistics are per rank; checkpoints and validation use rank 0's (ddp.py)
+    def on_save_checkpoint(self, checkpoint) -> None:
+        from ..ddp import broadcast_buffers
+        broadcast_buffers(self.model)
+
+    def on_validation_epoch_start(self) -> None:
+        from ..ddp import broadcast_buffers
+        broadcast_buffers(self.model)
+
     def configure_optimizers(self) -> Dict[str, Any]:
         if self.use_fused_optimizer:
             optimizer = FlatAdam(self.model, lr=self.learning_rate, weight_decay=self.weight_decay)

@@ -165,6 +165,16 @@ def _ddp_worker(rank, world, port, q):
     red.start(flat, 0, 500)      # issued as 256 + 244
     assert red.issued == [(500, 756), (756, 1000), (0, 256), (256, 500)], red.issued
     red.finish()
+    # no_sync(): announcements inside are dropped (gradient accumulation), the reducer stays idle
+    with red.no_sync():
+        red.start(flat, 0, 1000)
+    assert not red.busy and red.issued == []
+    # BatchNorm running buffers: per rank while training, rank 0's at a checkpoint (ddp.broadcast_buffers)
+    from mimo_unet_amd.ddp import broadcast_buffers
+    bn = torch.nn.BatchNorm2d(3)
+    bn.running_mean.fill_(float(rank + 1))
+    broadcast_buffers(bn)
+    assert float(bn.running_mean[0]) == 1.0 and int(bn.num_batches_tracked) == 0
     q.put((rank, local.numpy(), flat.clone().numpy(), red.scale, shard["image"].shape[0]))  # by value
     dist.barrier()
     dist.destroy_process_group()
