@@ -131,6 +131,7 @@ def init_state(cfg: NetConfig, seed: int) -> Dict[str, Tensor]:
 # --------------------------------------------------------------------------
 _CONV_OPERANDS = "fp32"
 _STORE16 = None  # None | torch.bfloat16 | torch.float16: 16-bit STORAGE of conv outputs and activations
+_STORE_GRADS = False  # ... and of their gradients (da, dz, the padded-domain data gradient) in the backward
 
 
 class conv_operands:
@@ -144,34 +145,41 @@ class conv_operands:
     autocast precisions): operands rounded to bf16 / fp16 in every convolution but the image convolution, and the
     FORWARD storage roundings of the engine inserted — convolution outputs and activations are stored in that type
     (BatchNorm statistics come from the unrounded fp32 accumulators; the 1x1 head reads the stored activation and
-    produces fp32 logits).  The backward of this emulation keeps fp32 gradients (the engine also stores those in 16
-    bits): gradients are compared against the fp32 run at mixed-precision tolerance, not against this emulation."""
+    produces fp32 logits).  By default the backward of this emulation keeps fp32 gradients; ``grad_storage=True``
+    also rounds the gradients where the engine stores them in 16 bits — the gradient of every stored activation (da),
+    of every stored convolution output (dz) and the data gradient of a convolution on the padded domain — which is
+    what the per-tensor gradient checks of the storage modes anchor on (round 3; under "16-mixed" run it with the same
+    loss scale as the engine: fp16 rounding is not scale-invariant near the subnormals)."""
 
-    def __init__(self, kind: str):
+    def __init__(self, kind: str, grad_storage: bool = False):
         assert kind in ("fp32", "bf16", "bf16-mixed", "16-mixed")
         self.kind = kind
+        self.grad_storage = grad_storage
 
     def __enter__(self):
-        global _CONV_OPERANDS, _STORE16
-        self.prev = (_CONV_OPERANDS, _STORE16)
+        global _CONV_OPERANDS, _STORE16, _STORE_GRADS
+        self.prev = (_CONV_OPERANDS, _STORE16, _STORE_GRADS)
         _CONV_OPERANDS = self.kind
         _STORE16 = {"bf16-mixed": torch.bfloat16, "16-mixed": torch.float16}.get(self.kind)
+        _STORE_GRADS = self.grad_storage and _STORE16 is not None
 
     def __exit__(self, *exc):
-        global _CONV_OPERANDS, _STORE16
-        _CONV_OPERANDS, _STORE16 = self.prev
+        global _CONV_OPERANDS, _STORE16, _STORE_GRADS
+        _CONV_OPERANDS, _STORE16, _STORE_GRADS = self.prev
 
 
 class _StoreRound(torch.autograd.Function):
-    """Round to the 16-bit storage type in the forward, identity in the backward."""
+    """Round to the 16-bit storage type in the forward; in the backward identity, or (conv_operands(grad_storage=True))
+    the same rounding of the gradient: the engine stores the gradient of a stored tensor in the same type."""
 
     @staticmethod
     def forward(ctx, t, dtype):
+        ctx.dtype, ctx.round_grad = dtype, _STORE_GRADS
         return t.to(dtype).float()
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        return (g.to(ctx.dtype).float() if ctx.round_grad else g), None
 
 
 def _stored(t: Tensor) -> Tensor:
@@ -188,7 +196,7 @@ class _RoundedConv(torch.autograd.Function):
         dt = _STORE16 or torch.bfloat16
         r = lambda t: t.to(dt).float()
         ctx.save_for_backward(xp, w)
-        ctx.dt, ctx.mixed = dt, _STORE16 is not None
+        ctx.dt, ctx.mixed, ctx.round_grad = dt, _STORE16 is not None, _STORE_GRADS
         # MIMO_PREC_BF16: 16-bit forward when the padded input has >= 16 channels; mixed storage modes: every layer
         # but the image convolution (C_in <= 4)
         low = w.shape[1] > 4 if ctx.mixed else w.shape[1] > 8
@@ -200,6 +208,8 @@ class _RoundedConv(torch.autograd.Function):
         xp, w = ctx.saved_tensors
         low = ctx.mixed or w.shape[0] > 8
         dx = torch.nn.grad.conv2d_input(xp.shape, r(w), r(dz)) if low else torch.nn.grad.conv2d_input(xp.shape, w, dz)
+        if ctx.round_grad and low:
+            dx = r(dx)  # the padded-domain data gradient is a 16-bit tensor in HBM
         xin = r(xp) if (not ctx.mixed or w.shape[1] > 4) else xp.to(ctx.dt).float()  # the fp32 image is rounded on load
         return dx, torch.nn.grad.conv2d_weight(xin, w.shape, r(dz))
 
@@ -490,8 +500,10 @@ class TrainState:
 
 def train_step(ts: TrainState, image: Tensor, label: Tensor, mask: Optional[Tensor], perms: Tensor,
                masks: Optional[Dict[str, Tensor]] = None, apply_optimizer: bool = True,
-               want_input_grad: bool = False) -> Dict[str, Tensor]:
-    """training_step + backward + Adam.  Returns losses, weights, grads, outputs."""
+               want_input_grad: bool = False, loss_scale: float = 1.0) -> Dict[str, Tensor]:
+    """training_step + backward + Adam.  Returns losses, weights, grads, outputs.  loss_scale: the backward runs on
+    loss_scale * total and the gradients are divided by it (what a GradScaler does; matters only with the 16-bit
+    gradient-storage emulation)."""
     cfg = ts.cfg
     names = ts.param_names()
     leaves = {n: ts.st[n].detach().clone().requires_grad_(True) for n in names}
@@ -512,11 +524,11 @@ def train_step(ts: TrainState, image: Tensor, label: Tensor, mask: Optional[Tens
     weights = ts.loss_buffer.get_weights()                      # read BEFORE add (:243-245)
     ts.loss_buffer.add(loss.detach())
     total = (loss * weights).mean()                             # :138
-    total.backward()
-    grads = {n: leaves[n].grad for n in names}
+    (total * loss_scale).backward()
+    grads = {n: leaves[n].grad / loss_scale for n in names}
     res = {"out": out.detach(), "loss": loss.detach(), "weights": weights, "total": total.detach(), "grads": grads}
     if want_input_grad:
-        res["dx"] = x.grad
+        res["dx"] = x.grad / loss_scale
     if apply_optimizer:
         ts.step += 1
         for n in names:

@@ -97,7 +97,7 @@ def test_cfg4_geometry_bf16_vs_oracle():
     assert t32 < BF16_TRAIN_OUT and e_loss < 2e-2 and cos > BF16_GRAD_COS
 
 
-@pytest.mark.parametrize("precision", ["split16", "bf16"])
+@pytest.mark.parametrize("precision", ["split16", "bf16", "bf16-mixed"])  # bf16-mixed = BASELINE config 4's precision
 def test_cfg4_batch16_properties(precision):
     """cfg4's per-GPU batch (16) through size-independent properties: a training step is bit-reproducible and
     finite, eval mode is equivariant under batch permutation, and the split16 / bf16 losses agree to bf16 tolerance."""
