@@ -366,11 +366,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       a_tc[k] = pix % kWgTCP - 1;
       constexpr int kChU = X16 ? 8 : 4;  // channels per unit; its hi-plane bytes = 2 * kChU
       a_ch[k] = ci0 + kChU * qq < a.cin_p ? ci0 + kChU * qq : -1;
-      a_dst[k] = u < kWsAPix * QA ? pix * PA + ((pix >> 3) & 1) * 32 + qq * 2 * kChU : -1;
+      // units past the tile (XA rounds up) repeat the LAST unit — same source (uc), same destination, same bytes: every
+      // store below is unconditional.  A store skipped by a branch leaves its load un-waited on that path and hipcc then
+      // drains the whole queue (vmcnt(0)) before the registers are reused, which cut the prefetch from two tiles to one
+      // (found in the ISA in round 3, as in conv_wide.hip).
+      a_dst[k] = pix * PA + ((pix >> 3) & 1) * 32 + qq * 2 * kChU;
     }
 #pragma unroll
     for (int k = 0; k < XD; ++k) {
-      const int u = ptid + k * 256;
+      const int u = min(ptid + k * 256, kWsDPix * QD - 1);  // units past the tile repeat its last unit (see a_dst)
       const int pix = u / QD, qq = u - pix * QD;
       const int half = D16 ? 0 : qq / (CO / 8), c8 = qq - half * (CO / 8);  // pre-split dz: 8 channels of the hi or lo plane
       d_r[k] = pix / kWgTC;
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       d_ch[k] = (pix < kWsDPix && ch < a.cout_p && (NP == 3 || half == 0))
                     ? (D16 ? ch : (ch >> 5) * 64 + half * rc + (ch & 31))  // plain NHWC / pair records, in 16-bit units
                     : -1;
-      d_dst[k] = pix < kWsDPix ? ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + half * 2 * CO + c8 * 16 : -1;
+      d_dst[k] = ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + half * 2 * CO + c8 * 16;
     }
     const int H2 = 2 * a.H - 2, W2 = 2 * a.W - 2;
 #define WS_LOAD(XA_, XD_, TILE)                                                                     \
@@ -436,38 +440,34 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   {                                                                                                 \
     unsigned char* base_ = smem + (BUF) * BUFBYTES;                                                 \
     _Pragma("unroll") for (int k_ = 0; k_ < XA; ++k_) {                                             \
-      if (a_dst[k_] >= 0) {                                                                         \
-        unsigned char* d_ = base_ + a_dst[k_];                                                      \
-        WS_SPLIT_STORE(XA_[k_], d_, CI)                                                             \
-      }                                                                                             \
+      unsigned char* d_ = base_ + a_dst[k_];                                                        \
+      WS_SPLIT_STORE(XA_[k_], d_, CI)                                                               \
     }                                                                                               \
     _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
-      if (d_dst[k_] >= 0) *reinterpret_cast<f32x4*>(base_ + d_dst[k_]) = XD_[k_]; /* plain copy */ \
+      *reinterpret_cast<f32x4*>(base_ + d_dst[k_]) = XD_[k_]; /* plain copy */                      \
     }                                                                                               \
   }
     // register set s (0/1) carries tile j with j&1 == s; loads are issued two tiles (= two barriers) ahead
-    const int T0 = bsplit, TS = a.splits;
-    if (ntiles_mine > 0) {
-      WS_LOAD(xa0, xd0, T0)
-      if (ntiles_mine > 1) WS_LOAD(xa1, xd1, T0 + TS)
-      WS_STORE(xa0, xd0, 0)
-      if (ntiles_mine > 2) WS_LOAD(xa0, xd0, T0 + 2 * TS)
-    }
+    // Straight-line, unconditional: past the end the loads re-read the last tile and the stores go to a buffer nobody
+    // reads any more (a conditional load or store makes hipcc wait vmcnt(0) where the paths join).  The loop always
+    // runs an even number of phases; the consumers add a barrier when their tile count is odd.
+    const int T0 = bsplit, TS = a.splits, last = max(ntiles_mine - 1, 0);
+#define WS_TILE(J) (T0 + min((J), last) * TS)
+    WS_LOAD(xa0, xd0, WS_TILE(0))
+    WS_LOAD(xa1, xd1, WS_TILE(1))
+    WS_STORE(xa0, xd0, 0)
+    WS_LOAD(xa0, xd0, WS_TILE(2))
     __syncthreads();  // tile 0 is in LDS
     for (int i = 0; i < ntiles_mine; i += 2) {
       // consumers multiply tile i from buffer i&1; the other buffer was released by the previous barrier
-      if (i + 1 < ntiles_mine) {
-        WS_STORE(xa1, xd1, 1)
-        if (i + 3 < ntiles_mine) WS_LOAD(xa1, xd1, T0 + (i + 3) * TS)
-      }
+      WS_STORE(xa1, xd1, 1)
+      WS_LOAD(xa1, xd1, WS_TILE(i + 3))
       __syncthreads();
-      if (i + 1 >= ntiles_mine) break;
-      if (i + 2 < ntiles_mine) {
-        WS_STORE(xa0, xd0, 0)
-        if (i + 4 < ntiles_mine) WS_LOAD(xa0, xd0, T0 + (i + 4) * TS)
-      }
+      WS_STORE(xa0, xd0, 0)
+      WS_LOAD(xa0, xd0, WS_TILE(i + 4))
       __syncthreads();
     }
+#undef WS_TILE
 #undef WS_LOAD
 #undef WS_STORE
 #undef WS_SPLIT_STORE
@@ -551,6 +551,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     }
     __syncthreads();
   }
+  if (ntiles_mine & 1) __syncthreads();  // the producers' loop runs an even number of phases
   float* out = a.partial + (size_t)bsplit * 9 * a.cin_pad * a.cout_pad;
   const int t0 = tset ? 5 : 0, nt = TSPLIT ? (tset ? 4 : 5) : 9;
 #pragma unroll

@@ -49,6 +49,7 @@ def run(reps):
         dz[..., Co:] = 0
         dx = torch.empty(N, H, W, cip, device="cuda")
         stats = torch.zeros(2, Co, dtype=torch.float64, device="cuda")
+        dw, db = torch.empty(Co, Ci, 3, 3, device="cuda"), torch.empty(Co, device="cuda")
         for _ in range(reps):
             L.check(lib.mimo_op_conv3x3_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), z.data_ptr(), stats.data_ptr(),
                                                 N, H, W, Ci, cip, Co, cop, prec, st), "fwd")
@@ -56,6 +57,10 @@ def run(reps):
             L.check(lib.mimo_op_conv3x3_dgrad(dz.data_ptr(), w.data_ptr(), dx.data_ptr(), N, H, W, Ci, cip, Co, cop, prec, st),
                     "dgrad")
             labels.append(f"dgrad {Ci}->{Co}@{H} {N}")
+            if os.environ.get("MIMO_LAYER_BENCH_WGRAD", "1") != "0":
+                L.check(lib.mimo_op_conv3x3_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), db.data_ptr(), N, H, W, Ci, cip,
+                                                  Co, cop, prec, st), "wgrad")
+                labels.append(f"wgrad {Ci}->{Co}@{H} {N}")
         torch.cuda.synchronize()
         del x, w, b, z, dz, dx
     with open(os.environ.get("MIMO_LAYER_BENCH_LABELS", "/tmp/layer_bench_labels.txt"), "w") as fh:
@@ -66,7 +71,8 @@ def report(d):
     fn = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[0]
     rows = list(csv.DictReader(open(fn)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    convs = [r for r in rows if "conv3x3_" in r["Kernel_Name"] and "pack" not in r["Kernel_Name"]]
+    convs = [r for r in rows if ("conv3x3_" in r["Kernel_Name"] or "wgrad_split" in r["Kernel_Name"] or "wgrad_mfma" in r["Kernel_Name"])
+             and "pack" not in r["Kernel_Name"]]
     labels = open(os.path.join(d, "labels.txt")).read().split("\n")[:-1]
     assert len(convs) == len(labels), (len(convs), len(labels))
     best = {}

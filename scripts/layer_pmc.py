@@ -19,7 +19,8 @@ ctr = collections.defaultdict(dict)
 for r in csv.DictReader(open(cc)):
     ctr[r["Dispatch_Id"]][r["Counter_Name"]] = ctr[r["Dispatch_Id"]].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 labels = open(d + "/labels.txt").read().split("\n")[:-1]
-ids = sorted((i for i in dur if "conv3x3_" in dur[i][1] and "pack" not in dur[i][1]), key=int)
+ids = sorted((i for i in dur if ("conv3x3_" in dur[i][1] or "wgrad_split" in dur[i][1] or "wgrad_mfma" in dur[i][1])
+              and "pack" not in dur[i][1]), key=int)
 assert len(ids) == len(labels), (len(ids), len(labels))
 seen = set()
 for lab, i in zip(labels, ids):
