@@ -1063,8 +1063,7 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
     }
   }
   // NF <= 2: little MFMA work per tile -> 256-pixel tiles so that two workgroups share a CU and
-  // one's loads / stores overlap the other's MFMAs (MIMO_CONV_BIGTILE_NF2=1 restores 512-pixel tiles)
-  static const bool big_nf2 = getenv("MIMO_CONV_BIGTILE_NF2") && atoi(getenv("MIMO_CONV_BIGTILE_NF2")) != 0;
+  // one's loads / stores overlap the other's MFMAs
   if (conv_ws_enabled() && a.Ho * a.Wo >= 256) {
     // 128-pixel tiles / two workgroups per CU: forward only (measured per layer on one box: forward 30->30 at
     // 256x256 169 -> 147 us, 45->30 282 -> 253 us; the data gradient of the same shapes 132 -> 145 us)
@@ -1081,7 +1080,7 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
     set_error("conv3x3 split: weights packed for tap pairing, launch is not");
     return MIMO_ERR_INVALID;
   }
-  if (use_big_tile(a.Ho, a.Wo) && (nf >= 3 || big_nf2)) {
+  if (use_big_tile(a.Ho, a.Wo) && nf >= 3) {
     switch (nf) {
       case 4: return launch_bf16x3<4, 4, MODE>(a, rows, stream);
       case 3: return launch_bf16x3<4, 3, MODE>(a, rows, stream);

@@ -637,25 +637,16 @@ static int wide_force() {
   return f;
 }
 
-static int wide_nf_force() {  // experiments: MIMO_CONV_WIDE_NF=1|2 fixes the channel-tile width
-  static const int f = [] {
-    const char* e = getenv("MIMO_CONV_WIDE_NF");
-    const int v = e ? atoi(e) : 0;
-    return v == 1 || v == 2 ? v : 0;
-  }();
-  return f;
-}
-
 // 0 = the layer runs on conv_bf16x3.hip; else the packed weight rows of the wide layout (ConvLaunch::wide)
 int conv3x3_wide_rows(int mode, int N, int cin_p, int rows, int Ho, int Wo) {
-  return sched::wide_config(mode, N, cin_p, rows, Ho, Wo, wide_force(), wide_nf_force()).rows_pad;
+  return sched::wide_config(mode, N, cin_p, rows, Ho, Wo, wide_force()).rows_pad;
 }
 // 16-bit elements of the packed wide weight image
 size_t conv3x3_wide_weight_elems(int cin_p, int rows_pad) { return (size_t)ceil_div(cin_p, 16) * 9 * rows_pad * 32; }
 int conv3x3_wide_stat_rows() { return 256; }  // one row per persistent workgroup column
 
 int conv3x3_wide_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t stream) {
-  const sched::WideCfg c = sched::wide_config(mode, a.N, a.cin_p, a.cout_store, a.Ho, a.Wo, 1, wide_nf_force());
+  const sched::WideCfg c = sched::wide_config(mode, a.N, a.cin_p, a.cout_store, a.Ho, a.Wo, 1);
   if (!a.wpk || c.nf == 0 || c.rows_pad != a.wide || a.ldx % 4 != 0 || a.ldy % 4 != 0 || a.Hi < 2 || a.Wi < 2) {
     set_error("conv3x3 wide: weights packed for %d rows, launch geometry gives %d (nf %d)", a.wide, c.rows_pad, c.nf);
     return MIMO_ERR_INVALID;

@@ -128,7 +128,7 @@ struct WideCfg {
 // Which decomposition a split16 3x3 convolution runs on.  `rows` = output channels of the launch (forward: Cout;
 // data gradient: the layer's padded input channels), Ho x Wo its output domain.
 // force: -1 = never, 0 = by the cost rule, 1 = whenever the geometry is supported.
-static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, int Wo, int force, int nf_force = 0) {
+static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, int Wo, int force) {
   WideCfg c{0, 0, 0, 0};
   const bool s16 = mode >= 4 && mode <= 7;  // 16-bit storage modes: 32-channel chunks, one MFMA per product
   if (force < 0 || !(mode == 0 || mode == 1 || s16) || rows < 1 || cin_p < 16 || Ho < 2 || Wo < 2) return c;
@@ -141,7 +141,7 @@ static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, 
   const int r32 = cdiv(rows, 32);
   // channel-tile width: two 32-channel tiles per workgroup unless the padding that costs exceeds what the second tile's
   // reuse of the staged input is worth (~10 %)
-  const int nf = nf_force ? nf_force : (r32 >= 2 && double(rup(r32, 2)) / r32 <= 1.10 + 1e-9) ? 2 : 1;
+  const int nf = (r32 >= 2 && double(rup(r32, 2)) / r32 <= 1.10 + 1e-9) ? 2 : 1;
   const int cotiles = cdiv(r32, nf);
   if (force == 0) {
     // Cost of both decompositions in padded-MFMA units, constants fitted to per-layer timings of cfg3 at batch 32

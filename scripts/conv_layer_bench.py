@@ -34,6 +34,8 @@ def run(reps):
     lib = L.load()
     only = os.environ.get("MIMO_LAYER_BENCH_ONLY")
     shapes = [s for i, s in enumerate(SHAPES) if only is None or str(i) in only.split(",")]
+    if os.environ.get("MIMO_LAYER_BENCH_SHAPES"):  # "N,H,W,Cin,Cout;..." instead of the cfg3 table
+        shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["MIMO_LAYER_BENCH_SHAPES"].split(";")]
     labels = []
     st = L.current_stream()
     prec = int(os.environ.get("MIMO_LAYER_BENCH_PREC", "1"))  # mimo_precision: 1 split16, 3 bf16-mixed, 4 16-mixed
