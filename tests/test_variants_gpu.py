@@ -26,8 +26,7 @@ VARIANTS = {
 }
 
 
-@pytest.mark.parametrize("name", sorted(VARIANTS))
-def test_kernel_variant(name):
+def _run_variant(name):
     env = dict(os.environ, **VARIANTS[name])
     env.pop("MIMO_PARITY_LOG", None)  # the default-path run of the same tests writes the committed error log
     sel = ("tests/test_ops_gpu.py::test_conv3x3_forward_dgrad_wgrad "
@@ -35,6 +34,23 @@ def test_kernel_variant(name):
            "tests/test_network_gpu.py::test_mc_dropout_ensemble_golden").split()
     if name.startswith("conv_wide"):  # the wide kernel also serves the 16-bit storage modes
         sel.append("tests/test_ops_gpu.py::test_storage_mode_conv_kernels_against_rounded_reference")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "split16 or mc_dropout or storage_mode", *sel],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    return subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                           "-k", "split16 or mc_dropout or storage_mode", *sel],
+                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+
+
+@pytest.fixture(scope="module")
+def variant_runs():
+    """All variants start when the first one is asked for, four child processes at a time (they share the GPU; most of a
+    child's time is the interpreter and torch starting up), so the module costs about a quarter of the serial time."""
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=4)
+    futures = {name: pool.submit(_run_variant, name) for name in sorted(VARIANTS)}
+    yield futures
+    pool.shutdown(wait=True)
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_kernel_variant(name, variant_runs):
+    r = variant_runs[name].result()
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
