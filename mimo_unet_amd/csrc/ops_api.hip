@@ -287,7 +287,7 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
     wgrad_split_tiles(cin_p, cout_p, &CI, &CO);
     a.cin_pad = round_up(cin_p, CI);
     a.cout_pad = round_up(cout_p, CO);
-    a.splits = wgrad_split_pick_splits(n, h, wd, a.cin_pad, a.cout_pad, CI, CO);
+    a.splits = wgrad_split_pick_splits(n, h, wd, a.cin_pad, a.cout_pad, CI, CO, mixed ? (f16s ? 2 : 1) : 0);
   } else {
     a.cin_pad = round_up(cin_p, 32);
     a.cout_pad = round_up(cout_p, 32);

@@ -360,7 +360,9 @@ struct mimo_plan {
       wgrad_split_tiles(L.cin_p, L.cout_p, &CI, &CO);
       L.wg_cin_pad = round_up(L.cin_p, CI);
       L.wg_cout_pad = round_up(L.cout_p, CO);
-      L.wg_splits = wgrad_split_pick_splits(n, h, w, L.wg_cin_pad, L.wg_cout_pad, CI, CO);
+      // operand storage of this layer's weight gradient (= WgradLaunch::store in convbn_backward: fwd_split below)
+      const int wg_store = !mixed ? 0 : (L.cin_p >= 8 ? (f16 ? 2 : 1) : (f16 ? 4 : 3));
+      L.wg_splits = wgrad_split_pick_splits(n, h, w, L.wg_cin_pad, L.wg_cout_pad, CI, CO, wg_store);
     } else {
       L.wg_cin_pad = round_up(L.cin_p, 32);
       L.wg_cout_pad = round_up(L.cout_p, 32);

@@ -86,13 +86,16 @@ static inline void wg_tiles(int cin_p, int cout_p, bool ws_enabled, int* CI, int
 static inline bool wg_use_ws(int CI, int CO, bool ws_enabled) {
   return ws_enabled && (CI == 64 || CI == 32) && (CO == 32 || CO == 48 || CO == 64);
 }
-static inline int wg_ws_tr(int CI) { return CI == 32 ? 4 : 2; }  // tile rows of the wave-specialised kernel
+// tile rows of the wave-specialised kernel: 2 with 64 input channels of fp32 / pair-record operands (128 KB of LDS),
+// 4 with 32 input channels, and 4 when BOTH operands are 16-bit tensors (s16: half the LDS bytes per pixel)
+static inline int wg_ws_tr(int CI, bool s16 = false) { return (CI == 32 || s16) ? 4 : 2; }
 static inline int wg_num_tiles(int N, int H, int W, int tr) { return N * cdiv(H, tr) * cdiv(W, kWgTC); }
 // pixel splits (slabs) of a layer's weight gradient: >= 1, <= min(tiles, 1024)
-static inline int wg_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO, bool ws_enabled, int mode) {
+static inline int wg_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO, bool ws_enabled, int mode,
+                                 bool s16 = false) {
   const int wtiles = (cin_pad / CI) * (cout_pad / CO);
   const bool ws = wg_use_ws(CI, CO, ws_enabled);
-  const int tiles = wg_num_tiles(N, H, W, ws ? wg_ws_tr(CI) : 4);
+  const int tiles = wg_num_tiles(N, H, W, ws ? wg_ws_tr(CI, s16) : 4);
   if (!ws || mode == 0) {
     int splits = cdiv(512, wtiles);  // one 4-wave workgroup per CU: ~2 rounds of workgroups
     if (splits > tiles) splits = tiles;
@@ -104,7 +107,7 @@ static inline int wg_pick_splits(int N, int H, int W, int cin_pad, int cout_pad,
   // time ~ rounds x (pixel tiles per workgroup + fixed cost); the fixed cost (147 KB slab written per workgroup and
   // re-read by the reduction, pipeline fill) is worth about `kFixed` pixel tiles.
   const int kCUs = 256;
-  const int kFixed = 16 / wg_ws_tr(CI);
+  const int kFixed = 16 / wg_ws_tr(CI, s16);
   int best = 1;
   long bestCost = -1;
   for (int s = 1; s <= tiles && s <= 1024; ++s) {

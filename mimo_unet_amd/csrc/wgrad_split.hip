@@ -42,6 +42,12 @@ constexpr int wg_pitch(int C) {
   while (m % 4 != 2) ++m;
   return 32 * m;
 }
+// the same for an operand stored as ONE 16-bit plane (16-bit storage modes: no lo half): 2*C data bytes
+constexpr int wg_pitch16(int C) {
+  int m = (2 * C + 32 + 31) / 32;
+  while (m % 4 != 2) ++m;
+  return 32 * m;
+}
 
 // Operand storage of the weight-gradient kernels (template parameter WM):
 //   0  activations fp32 (split into bf16 pairs / rounded to bf16 on the way in), dz pre-split bf16 (hi, lo) records
@@ -315,8 +321,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
 // per tile; producers run one tile ahead in LDS and two tiles ahead in registers.
 // ---------------------------------------------------------------------------------------
 // pixel tile of the wave-specialised kernel: TR rows x 32 columns.  2 rows with 64 input channels per
-// workgroup (128 KB of LDS); 4 rows with 32 (the thin 256x256 layers: twice the MFMAs per barrier, 127-157 KB)
-static int wgrad_ws_tr(int CI) { return CI == 32 ? 4 : 2; }
+// workgroup (128 KB of LDS); 4 rows with 32 (the thin 256x256 layers: twice the MFMAs per barrier, 127-157 KB) and,
+// round 3, 4 rows when both operands are 16-bit tensors (rows of one 16-bit plane: 128 KB again; twice the MFMAs
+// per barrier, 1.5 x instead of 2 x halo rows of the activation operand)
+static bool wgrad_s16(int om) { return om == 1 || om == 2; }
+static int wgrad_ws_tr(int CI, int om) { return sched::wg_ws_tr(CI, wgrad_s16(om)); }
 
 template <int NP, int NI, int CI_, int TR_, int OM>
 __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   constexpr bool TSPLIT = CI == 32;
   static_assert(CI == 64 || CI == 32, "64 or 32 input channels per workgroup");
   constexpr int kWsTR = TR_, kWsAPix = (kWsTR + 2) * kWgTCP, kWsDPix = kWsTR * kWgTC;
-  constexpr int PA = wg_pitch(CI), PD = wg_pitch(CO);
+  constexpr int PA = X16 ? wg_pitch16(CI) : wg_pitch(CI), PD = D16 ? wg_pitch16(CO) : wg_pitch(CO);
   constexpr int QA = X16 ? CI / 8 : CI / 4, QD = D16 ? CO / 8 : CO / 4;  // 16-byte units per pixel
   constexpr int XA = (kWsAPix * QA + 255) / 256, XD = (kWsDPix * QD + 255) / 256;  // per producer thread
   constexpr int ABYTES = kWsAPix * PA, DBYTES = kWsDPix * PD, BUFBYTES = ABYTES + DBYTES;
@@ -576,9 +585,9 @@ static bool wgrad_ws_enabled() {
 }
 void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO) { sched::wg_tiles(cin_p, cout_p, wgrad_ws_enabled(), CI, CO); }
 static bool wgrad_use_ws(int CI, int CO) { return sched::wg_use_ws(CI, CO, wgrad_ws_enabled()); }
-int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO) {
+int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO, int store) {
   static const int mode = [] { const char* e = getenv("MIMO_WGRAD_SPLIT_MODE"); return e ? atoi(e) : 1; }();
-  return sched::wg_pick_splits(N, H, W, cin_pad, cout_pad, CI, CO, wgrad_ws_enabled(), mode);
+  return sched::wg_pick_splits(N, H, W, cin_pad, cout_pad, CI, CO, wgrad_ws_enabled(), mode, wgrad_s16(store));
 }
 
 int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
@@ -589,7 +598,7 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
     return MIMO_ERR_INVALID;
   }
   const bool ws = wgrad_use_ws(CI, CO);
-  const int tilesY = ceil_div(a.H, ws ? wgrad_ws_tr(CI) : kWgTR), tilesX = ceil_div(a.W, kWgTC);
+  const int tilesY = ceil_div(a.H, ws ? wgrad_ws_tr(CI, a.store) : kWgTR), tilesX = ceil_div(a.W, kWgTC);
   const int numTiles = a.N * tilesY * tilesX;
   dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
   const int om = a.store;  // operand storage (WgradLaunch::store), see wg_mfma
@@ -604,8 +613,8 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
   hipLaunchKernelGGL((wgrad_split_ws_kernel<NP_, NI_, CI_, TR_, OM_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles)
 #define WS_LAUNCH2(NI_, CI_, TR_)                \
   switch (om) {                                  \
-    case 1: WS_LAUNCH3(1, NI_, CI_, TR_, 1); break; \
-    case 2: WS_LAUNCH3(1, NI_, CI_, TR_, 2); break; \
+    case 1: WS_LAUNCH3(1, NI_, CI_, 4, 1); break; /* both operands 16-bit: 4-row tiles */ \
+    case 2: WS_LAUNCH3(1, NI_, CI_, 4, 2); break; \
     case 3: WS_LAUNCH3(1, NI_, CI_, TR_, 3); break; \
     case 4: WS_LAUNCH3(1, NI_, CI_, TR_, 4); break; \
     default:                                     \

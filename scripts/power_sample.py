@@ -17,8 +17,20 @@ import threading
 import time
 
 
-def find_sysfs():
+def our_pci_address():
+    """PCI address of the GPU a child process sees as device 0 (the box may hold other tenants' GPUs)."""
+    code = ("import torch; p = torch.cuda.get_device_properties(0); "
+            "print('%04x:%02x:%02x' % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id))")
+    try:
+        return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180).stdout.strip().splitlines()[-1]
+    except Exception:
+        return None
+
+
+def find_sysfs(pci=None):
     for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+        if pci and pci.lower() not in os.path.realpath(dev).lower():
+            continue
         hw = glob.glob(os.path.join(dev, "hwmon", "hwmon*"))
         if not hw:
             continue
@@ -55,7 +67,8 @@ def smi_sample():
 def main():
     out_path = sys.argv[1]
     cmd = sys.argv[sys.argv.index("--") + 1:]
-    fs = find_sysfs()
+    pci = our_pci_address()
+    fs = find_sysfs(pci) or find_sysfs()
     samples = []
     stop = threading.Event()
 
@@ -78,7 +91,7 @@ def main():
     stop.set()
     th.join(timeout=2)
     with open(out_path, "w") as f:
-        f.write(f"# command: {' '.join(cmd)}\n# source: {'sysfs ' + fs['power'] if fs else 'rocm-smi'}\n")
+        f.write(f"# command: {' '.join(cmd)}\n# device 0 at PCI {pci}; source: {'sysfs ' + os.path.realpath(fs['power']) if fs else 'rocm-smi'}\n")
         if fs:
             cap = read_num(fs["cap"])
             if cap:

@@ -127,13 +127,14 @@ static void test_layers() {
         }
       // --- weight gradient
       for (int ws = 0; ws <= 1; ++ws)
-        for (int mode = 0; mode <= 1; ++mode) {
+        for (int mode = 0; mode <= 3; ++mode) {  // bit 1: both operands 16-bit tensors (4-row tiles)
+          const bool s16 = (mode & 2) != 0;
           int CI = 0, CO = 0;
           wg_tiles(cin_p, cout_p, ws != 0, &CI, &CO);
           CHECK((CI == 32 || CI == 48 || CI == 64) && (CO == 32 || CO == 48 || CO == 64), "wg tiles %d %d", CI, CO);
           const int cin_pad = rup(cin_p, CI), cout_pad = rup(cout_p, CO);
-          const int s = wg_pick_splits(N, L.h, L.h, cin_pad, cout_pad, CI, CO, ws != 0, mode);
-          const int tiles = wg_num_tiles(N, L.h, L.h, wg_use_ws(CI, CO, ws != 0) ? wg_ws_tr(CI) : 4);
+          const int s = wg_pick_splits(N, L.h, L.h, cin_pad, cout_pad, CI, CO, ws != 0, mode & 1, s16);
+          const int tiles = wg_num_tiles(N, L.h, L.h, wg_use_ws(CI, CO, ws != 0) ? wg_ws_tr(CI, s16) : 4);
           CHECK(s >= 1 && s <= 1024 && s <= tiles, "wg splits %d (tiles %d) for %d->%d @%d N %d", s, tiles, L.cin, L.cout, L.h, N);
           // slabs + group-sum levels fit the plan's scratch formula (plan.hip cap_slab: splits + splits / 8 + 2 slabs)
           int extra = 0;
