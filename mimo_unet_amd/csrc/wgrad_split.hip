@@ -505,13 +505,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   for (int i = 0; i < ntiles_mine; ++i) {
     const unsigned char* as_ = smem + (i & 1) * BUFBYTES;
     const unsigned char* ds_ = as_ + ABYTES;
-    if constexpr (NP == 1) {
-      // One MFMA per product: a tap is NI MFMAs = 16 * NI cycles of matrix-pipe time, far below the ~130-cycle latency of
-      // a transposed LDS read, so the activation fragments are read kDepth (2) taps ahead and the pipeline runs across the
-      // tile's rows (the whole tile is one unrolled sequence of TR x taps steps); the dz fragments of row r + 1 are read
-      // under the first tap of row r.  (Round 3: with one tap ahead this path waited for LDS at every tap.)
-      constexpr int kDepth = 2;
-      bf16x8 bh[2][NI], ah[kDepth + 1][MI];
+    {
+      // The whole tile is one unrolled sequence of TR x taps steps: the activation fragments are read kDepth taps ahead
+      // and the pipeline runs across the tile's rows; the dz fragments of row r + 1 are read under the first tap of row
+      // r.  One MFMA per product (16-bit storage, bf16 mode): a tap is NI MFMAs = 16 * NI cycles of matrix-pipe time,
+      // far below the ~130-cycle latency of a transposed LDS read -> two taps ahead (round 3: with one tap ahead that
+      // path waited for LDS at every tap, 598 -> 789 TFLOP/s on the class).  Three MFMAs per product: one tap ahead.
+      constexpr int kDepth = NP == 3 ? 1 : 2;
+      bf16x8 bh[2][NI], bl[NP == 3 ? 2 : 1][NI], ah[kDepth + 1][MI], al[NP == 3 ? kDepth + 1 : 1][MI];
       // the fragment addresses of all TR x taps steps are loop-invariant; hoisted out of the tile loop they would take
       // ~45 registers (spills) — an opaque copy of the lane's row index per tile keeps them recomputed in place
       int rowk_ = rowk;
@@ -519,20 +520,25 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
 #define WS_READ_B(SLOT, R)                                                           \
   {                                                                                  \
     const unsigned char* d0_ = ds_ + ((R) * kWgTC + rowk_) * PD + dcol;              \
-    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                              \
       bh[SLOT][ni] = tr_read8(d0_ + ni * 32, d0_ + ni * 32 + 4 * PD);                \
+      if (NP == 3) bl[SLOT][ni] = tr_read8(d0_ + ni * 32 + 2 * CO, d0_ + ni * 32 + 2 * CO + 4 * PD); \
+    }                                                                                \
   }
 #define WS_READ_A1(SLOT, R, TAP)                                                     \
   {                                                                                  \
     const int row0_ = ((R) + (TAP) / 3) * kWgTCP + rowk_ + (TAP) % 3, row1_ = row0_ + 4; \
     const unsigned char* a0_ = as_ + row0_ * PA + ((row0_ >> 3) & 1) * 32 + acol;    \
     const unsigned char* a1_ = as_ + row1_ * PA + ((row1_ >> 3) & 1) * 32 + acol;    \
-    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                              \
       ah[SLOT][mi] = tr_read8(a0_ + mi * 32, a1_ + mi * 32);                         \
+      if (NP == 3) al[SLOT][mi] = tr_read8(a0_ + mi * 32 + 2 * CI, a1_ + mi * 32 + 2 * CI); \
+    }                                                                                \
   }
 #define WS_TILE1(T0, NT)                                                             \
   {                                                                                  \
     constexpr int kSteps = kWsTR * (NT);                                             \
+    constexpr int kRB = (NP == 3 ? 4 : 2) * NI, kRA = (NP == 3 ? 4 : 2) * MI;        \
     WS_READ_B(0, 0)                                                                  \
     _Pragma("unroll") for (int s_ = 0; s_ < kDepth; ++s_)                            \
       WS_READ_A1(s_ % (kDepth + 1), s_ / (NT), (T0) + s_ % (NT))                     \
@@ -542,16 +548,22 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       if (rb_) WS_READ_B((r_ + 1) & 1, r_ + 1)                                       \
       if (ra_) WS_READ_A1((s_ + kDepth) % (kDepth + 1), (s_ + kDepth) / (NT), (T0) + (s_ + kDepth) % (NT)) \
       _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                              \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                            \
-          acc[tt][mi][ni] = wg_mfma<OM>(ah[s_ % (kDepth + 1)][mi], bh[r_ & 1][ni], acc[tt][mi][ni]); \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                          \
+          f32x4 c = acc[tt][mi][ni];                                                 \
+          if (NP == 3) {                                                             \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s_ % (kDepth + 1)][mi], bh[r_ & 1][ni], c, 0, 0, 0); \
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s_ % (kDepth + 1)][mi], bl[r_ & 1][ni], c, 0, 0, 0); \
+          }                                                                          \
+          acc[tt][mi][ni] = wg_mfma<OM>(ah[s_ % (kDepth + 1)][mi], bh[r_ & 1][ni], c); \
+        }                                                                            \
       if (rb_ && ra_) {                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NI + 2 * MI, 0);             \
+        __builtin_amdgcn_sched_group_barrier(0x100, kRB + kRA, 0);                   \
       } else if (rb_) {                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NI, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, kRB, 0);                         \
       } else if (ra_) {                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * MI, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, kRA, 0);                         \
       }                                                                              \
-      __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);                       \
+      __builtin_amdgcn_sched_group_barrier(0x008, NP * MI * NI, 0);                  \
     }                                                                                \
   }
       if (!TSPLIT) {
@@ -564,58 +576,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
 #undef WS_TILE1
 #undef WS_READ_A1
 #undef WS_READ_B
-    } else {
-#pragma unroll 1
-    for (int r = 0; r < kWsTR; ++r) {
-      bf16x8 bh[NI], bl[NI];
-      const unsigned char* d0 = ds_ + (r * kWgTC + rowk) * PD + dcol;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        bh[ni] = tr_read8(d0 + ni * 32, d0 + ni * 32 + 4 * PD);
-        bl[ni] = tr_read8(d0 + ni * 32 + 2 * CO, d0 + ni * 32 + 2 * CO + 4 * PD);
-      }
-      // tap-level software pipeline: the 8 transposed reads of tap t+1 are issued before the 12 MFMAs of
-      // tap t (LDS latency ~130 cycles vs 192 cycles of MFMA per tap); the sched_group_barriers pin that
-      // order, otherwise the compiler schedules the reads just-in-time and the lone consumer wave stalls
-      bf16x8 ah[2][MI], al[2][MI];
-#define WS_READ_A(SLOT, TAP)                                                                  \
-  {                                                                                           \
-    const int row0_ = (r + (TAP) / 3) * kWgTCP + rowk + (TAP) % 3, row1_ = row0_ + 4;         \
-    const unsigned char* a0_ = as_ + row0_ * PA + ((row0_ >> 3) & 1) * 32 + acol;             \
-    const unsigned char* a1_ = as_ + row1_ * PA + ((row1_ >> 3) & 1) * 32 + acol;             \
-    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                       \
-      ah[SLOT][mi] = tr_read8(a0_ + mi * 32, a1_ + mi * 32);                                  \
-      al[SLOT][mi] = tr_read8(a0_ + mi * 32 + 2 * CI, a1_ + mi * 32 + 2 * CI);                \
-    }                                                                                         \
-  }
-      // taps T0 .. T0+NT-1 of this wave, accumulators indexed from 0
-#define WS_TAPS(T0, NT)                                                                       \
-  {                                                                                           \
-    WS_READ_A(0, (T0))                                                                        \
-    _Pragma("unroll") for (int tt = 0; tt < (NT); ++tt) {                                     \
-      if (tt + 1 < (NT)) WS_READ_A((tt + 1) & 1, (T0) + tt + 1)                               \
-      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                       \
-        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                   \
-          f32x4 c = acc[tt][mi][ni];                                                          \
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tt & 1][mi], bh[ni], c, 0, 0, 0);    \
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tt & 1][mi], bl[ni], c, 0, 0, 0);    \
-          c = wg_mfma<OM>(ah[tt & 1][mi], bh[ni], c);                                         \
-          acc[tt][mi][ni] = c;                                                                \
-        }                                                                                     \
-      if (tt + 1 < (NT)) __builtin_amdgcn_sched_group_barrier(0x100, 4 * MI, 0); /* DS reads of the next tap */ \
-      __builtin_amdgcn_sched_group_barrier(0x008, 3 * MI * NI, 0);               /* MFMAs of this tap */ \
-    }                                                                                         \
-  }
-      if (!TSPLIT) {
-        WS_TAPS(0, 9)
-      } else if (tset == 0) {
-        WS_TAPS(0, 5)
-      } else {
-        WS_TAPS(5, 4)
-      }
-#undef WS_TAPS
-#undef WS_READ_A
-    }
     }
     __syncthreads();
   }
