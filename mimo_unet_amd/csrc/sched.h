@@ -162,8 +162,11 @@ static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, 
     const double t_w = double(k16) * (cotiles * nf * 32) / eff * (1.0 + (nf == 2 ? 1.2 : 0.2) / (k16 / (s16 ? 32 : 16)));
     // (16-bit storage modes, one MFMA per product: the 256-pixel kernel is bound by its staging there, x 1.45)
     const double t_o = (s16 ? 1.45 : 1.15) * k_o * rup(rows, 16) / eff_o;
-    // the wide kernel is persistent with one workgroup per CU: it needs enough (pixel tile, channel tile) pairs
-    if (tiles * cotiles < 128 || t_w >= t_o) return c;
+    // the wide kernel is persistent with one workgroup per CU and nothing overlaps its pipeline fill: it needs a
+    // (pixel tile, channel tile) pair for every CU and >= 8 K chunks of work per workgroup (at 4 images per GPU the
+    // 64x64 layers have 128 pairs and 30->30 at 256x256 two 2-chunk tiles per workgroup: measured 4.5 % of the step)
+    const int gx = 256 / cotiles < tiles ? (256 / cotiles > 0 ? 256 / cotiles : 1) : tiles;
+    if (tiles * cotiles < 256 || cdiv(tiles, gx) * (k16 / (s16 ? 32 : 16)) < 8 || t_w >= t_o) return c;
   }
   c.nf = nf;
   c.rows_pad = cotiles * nf * 32;
