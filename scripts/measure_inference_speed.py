@@ -21,6 +21,28 @@ from mimo.models.ensemble import EnsembleModule  # noqa: E402
 from mimo.models.mimo_unet import MimoUnetModel  # noqa: E402
 
 
+def algorithmic_work(net, H, W):
+    """(conv flops, HBM bytes) of ONE forward pass of one image on the inference fast path: 2*9*Cin*Cout per output pixel of
+    every 3x3 convolution; bytes = every convolution reads its input and writes its (BatchNorm + ReLU fused) output once in
+    fp32, plus the MaxPool2d / up-sample + concat passes and the 1x1 head (materialised-tensor accounting, as SURVEY 8d)."""
+    div = {"in_convs": 1, "down1s": 2, "down2": 4, "down3": 8, "down4": 16, "up1": 8, "up2": 4, "up3": 2, "up4s": 1}
+    flops = byts = 0.0
+    for name, w in net.state_dict().items():
+        if w.dim() != 4:
+            continue
+        co, ci, kh, kw = w.shape
+        d = next((v for k, v in div.items() if f".{k}." in f".{name}"), 1)
+        px = (H // d) * (W // d)
+        if kh == 3:
+            flops += 2.0 * 9 * ci * co * px
+        byts += 4.0 * (ci + co) * px
+        if kh == 3 and ".double_conv.0." in name and d > 1 and "up" not in name:
+            byts += 4.0 * ci * px * 5  # its input came out of a 2x2 max-pool: read 4, write 1 per pooled element
+        if kh == 3 and ".double_conv.0." in name and "up" in name:
+            byts += 4.0 * ci * px * 1.25  # ... or out of up-sample + concat: read skip + quarter-size tensor, write concat
+    return flops, byts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model_checkpoint_paths", nargs="*", default=[])
@@ -59,7 +81,14 @@ def main():
             torch.cuda.synchronize()
             t[i] = starter.elapsed_time(ender)
     passes = max(1, args.monte_carlo_steps)
-    print(json.dumps({"what": "ensemble forward incl. uncertainty reduction, results left on device",
+    fl, by = algorithmic_work(model.models[0].model, args.height, args.width)
+    n_pass = args.batch * passes
+    sec = float(t.mean()) * 1e-3
+    # peaks: 2500 TFLOP/s dense 16-bit MFMA / 3 MFMAs per product (split16 default), HBM 8 TB/s (MI355X_MICROARCH.md)
+    roof = {"conv_gflop_per_pass": round(fl / 1e9, 3), "achieved_tflops": round(fl * n_pass / sec / 1e12, 1),
+            "mfma_frac": round(fl * n_pass / sec / 833.3e12, 4), "algorithmic_mb_per_pass": round(by / 1e6, 1),
+            "achieved_gbs": round(by * n_pass / sec / 1e9, 1), "hbm_frac": round(by * n_pass / sec / 8e12, 4)}
+    print(json.dumps({"roofline": roof, "what": "ensemble forward incl. uncertainty reduction, results left on device",
                       "batch": args.batch, "monte_carlo_steps": args.monte_carlo_steps, "image": [args.height, args.width],
                       "S": model.models[0].num_subnetworks, "fbc": args.filter_base_count,
                       "mean_ms": round(float(t.mean()), 3), "std_ms": round(float(t.std()), 3),
