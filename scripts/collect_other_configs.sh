@@ -10,6 +10,10 @@ runp() { P=$1; shift; echo "CMD MIMO_PRECISION=$P $*" >> $O; MIMO_PRECISION=$P "
 run python scripts/measure_inference_speed.py
 run python scripts/measure_inference_speed.py --batch 8
 run python scripts/measure_inference_speed.py --monte_carlo_steps 0 --dropout 0 --height 128 --width 160
+for P in bf16-mixed 16-mixed; do  # cfg5 in the 16-bit storage modes (16-mixed = the reference's production precision)
+  runp $P python scripts/measure_inference_speed.py
+  runp $P python scripts/measure_inference_speed.py --batch 8
+done
 run python bench.py --config cfg2 --steps 10 --warmup 3 --no-cpu-baseline
 run python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline
 for P in bf16 bf16-mixed 16-mixed; do
