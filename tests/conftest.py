@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # the CPU oracle on a many-core host: torch's default (one thread per core) is SLOWER than 16 threads on the
+    # 256-core GPU boxes (tests/tools/cpu_thread_scan.py: 16 thr 3.4, 64 thr 1.7 images/s) — the full-resolution
+    # configuration tests spend their time there
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
