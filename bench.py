@@ -235,8 +235,13 @@ def main():
             raise SystemExit(f"process group runs on {dist.get_backend()!r}, {backend!r} was requested")
         # one GPU per rank under RCCL (ranks may share a device only in the gloo functional check)
         devs = [None] * dist.get_world_size()
-        dist.all_gather_object(devs, f"{socket.gethostname()}:{torch.cuda.get_device_properties(dev).uuid}"
-                               if hasattr(torch.cuda.get_device_properties(dev), "uuid") else f"{socket.gethostname()}:{dev}")
+        # identity of the physical device: host + PCI address (+ uuid where torch exposes it) — not the device index,
+        # which is 0 on every rank when the launcher masks one GPU per rank
+        p = torch.cuda.get_device_properties(dev)
+        known = hasattr(p, "pci_bus_id") or hasattr(p, "uuid")  # else nothing tells two masked devices apart: no check
+        pci = ":".join(f"{getattr(p, a, -1):x}" for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        dist.all_gather_object(devs, f"{socket.gethostname()}:{pci}:{getattr(p, 'uuid', dev)}" if known
+                               else f"{socket.gethostname()}:rank{rank}")
         if backend == "nccl" and len(set(devs)) != len(devs):
             raise SystemExit(f"RCCL ranks share a GPU: {devs}")
 
