@@ -147,10 +147,38 @@ static void test_layers() {
     }
 }
 
+// Dispatch decisions the measurements stand on (profiles/r03/conv_layers_ab.txt): a change of the
+// cost rule that flips one of these is a deliberate act.  mode 1 = split16 forward, 0 = split16 data gradient
+// (rows = padded input channels, domain (H + 2) x (W + 2)), 4 / 5 = bf16-mixed forward / data gradient.
+static void test_pinned_decisions() {
+  struct D { int mode, N, K, rows, H; bool wide; int nf; };
+  const D pins[] = {
+      {1, 32, 960, 480, 32, true, 2},   // up1.c1 forward: the largest layer
+      {1, 32, 480, 480, 32, true, 2},
+      {1, 32, 240, 240, 64, true, 2},
+      {1, 32, 32, 30, 256, true, 1},    // 30->30 at 256x256: one 32-channel tile, a chunk per phase
+      {1, 32, 48, 30, 256, true, 1},    // 45->30
+      {1, 32, 480, 480, 16, false, 0},  // 16x16: the 128-pixel instances fill the chip better
+      {1, 32, 96, 45, 256, false, 0},   // 90->45 forward stays on the 256-pixel kernel (64-channel tiles pad 45 -> 64)
+      {0, 32, 480, 960, 34, false, 0},  // up1.c1 data gradient: the NF = 4 instance re-reads least
+      {0, 32, 32, 32, 258, true, 1},    // 30->30 data gradient
+      {1, 4, 32, 30, 256, false, 0},    // 4 images per GPU: two 2-chunk tiles per workgroup do not pay for a persistent kernel
+      {1, 4, 240, 240, 64, false, 0},   // ... and 32 pixel tiles x 4 channel tiles leave half the CUs idle
+      {4, 32, 960, 480, 32, true, 2},   // 16-bit storage: the wide kernel takes nearly everything
+      {5, 32, 480, 960, 34, true, 2},
+  };
+  for (const D& d : pins) {
+    const WideCfg c = wide_config(d.mode, d.N, d.K, d.rows, d.H, d.H, 0);
+    CHECK((c.nf != 0) == d.wide && (!d.wide || c.nf == d.nf), "pinned decision mode %d N %d %d->%d @%d: nf %d (expected %s nf %d)",
+          d.mode, d.N, d.K, d.rows, d.H, c.nf, d.wide ? "wide" : "256-pixel", d.nf);
+  }
+}
+
 int main() {
   test_xcd();
   test_tiles();
   test_layers();
+  test_pinned_decisions();
   if (failures) {
     std::printf("%d check(s) failed\n", failures);
     return 1;
