@@ -325,6 +325,15 @@ def main():
 
     # ---- timed region (the regime of --scaling): no instrumentation ----
     elapsed, final_loss = timed_pass()
+    # host time to ENQUEUE one step on an idle GPU (outside the timed region): the launch path's share of a step
+    host_ms = []
+    for i in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(i)
+        host_ms.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    host_enqueue_ms = min(host_ms)
     plan = next(p for p in model.model._plans.values() if not p.inference_only)
     # ---- second pass: HIP events on the launch stream around every kernel class / resolution tier ----
     prof, tiers, kind_tiers, psteps = {}, [], {}, max(0, args.profile_steps)
@@ -394,6 +403,8 @@ def main():
                    "strong_global_batch": c["batch"],
                    "params_bit_identical_across_ranks": identical,
                    "optimizer": "adam(lr=1e-3) fused", "final_loss": round(final_loss, 5),
+                   # host time to enqueue one step on an idle GPU (rank 0): well below ms_per_step = the GPU, not the launch path, bounds the step
+                   "host_enqueue_ms_per_step": None if host_enqueue_ms is None else round(host_enqueue_ms, 3),
                    "streams": ("weight gradients on the caller's stream" if os.environ.get("MIMO_WGRAD_STREAM") == "0" else
                                "weight gradients on a side stream beside the BatchNorm-backward kernels of the layer below "
                                "(MIMO_WGRAD_STREAM=1, default); the second pass that times the kernel classes serialises them")},
