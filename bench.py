@@ -326,14 +326,15 @@ def main():
     # ---- timed region (the regime of --scaling): no instrumentation ----
     elapsed, final_loss = timed_pass()
     # host time to ENQUEUE one step on an idle GPU (outside the timed region): the launch path's share of a step
+    # (a diagnostic like the second pass below: --profile-steps 0 skips both, so that traces hold exactly warmup + steps)
     host_ms = []
-    for i in range(3):
+    for i in range(3 if args.profile_steps > 0 else 0):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         step(i)
         host_ms.append((time.perf_counter() - t0) * 1e3)
     torch.cuda.synchronize()
-    host_enqueue_ms = min(host_ms)
+    host_enqueue_ms = min(host_ms) if host_ms else None
     plan = next(p for p in model.model._plans.values() if not p.inference_only)
     # ---- second pass: HIP events on the launch stream around every kernel class / resolution tier ----
     prof, tiers, kind_tiers, psteps = {}, [], {}, max(0, args.profile_steps)
