@@ -38,3 +38,15 @@ span = (iv[-1][1] - t0) / 1e3
 busy = sum(e - s for s, e, _, _ in iv) / 1e3
 print(f"# columns of the trace: {list(step[0].keys())}")
 print(f"# span {span / 1e3:.3f} ms, summed kernel time {busy / 1e3:.3f} ms, pairwise cross-queue overlap {tot_ov / 1e3:.3f} ms")
+
+# GPU idle inside the step: gaps of the union of all kernel intervals (both streams), the largest ones with what follows
+ivs = sorted((s, e, name) for s, e, _, name in iv)
+idle, cur_end, gaps = 0, ivs[0][1], []
+for s, e, name in ivs[1:]:
+    if s > cur_end:
+        idle += s - cur_end
+        gaps.append((s - cur_end, (cur_end - t0) / 1e3, name))
+    cur_end = max(cur_end, e)
+print(f"# GPU idle inside the step (no kernel of either stream running): {idle / 1e6:.3f} ms in {len(gaps)} gaps")
+for g, at, name in sorted(gaps, reverse=True)[:8]:
+    print(f"#   {g / 1e3:7.1f} us idle at +{at:9.1f} us, before {name}")
