@@ -34,7 +34,7 @@ def _cpu_randperm_on_device(k: int, device) -> torch.Tensor:
     torch.randperm(k, out=slot[0])
     dev = slot[0].to(device, non_blocking=True)
     slot[1] = torch.cuda.Event()
-    slot[1].record()
+    slot[1].record(torch.cuda.current_stream(device))  # the stream the upload was enqueued on
     return dev
 
 
