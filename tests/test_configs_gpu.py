@@ -29,6 +29,40 @@ def test_cfg3_full_resolution_batch16_vs_oracle():
     assert e_out < TOL
 
 
+def test_training_loop_runs_ahead_of_the_gpu():
+    """No host / GPU synchronisation inside a training step: with the GPU busy, the host must finish ENQUEUEING ten
+    steps long before the GPU has run them (cfg3 at batch 16: ~3 ms of launch path against ~14 ms of kernels per
+    step).  Round 3 found one — the reference's CPU-drawn shuffles reached the GPU through a blocking pageable copy
+    (models/utils.py::_cpu_randperm_on_device) — worth 2.4 % of the batch-32 step and 12 % at 4 images per GPU."""
+    import time
+    from mimo.models.mimo_unet import MimoUnetModel
+    torch.manual_seed(0)
+    m = MimoUnetModel(in_channels=2, out_channels=2, num_subnetworks=2, filter_base_count=30, center_dropout_rate=0.0,
+                      final_dropout_rate=0.0, encoder_dropout_rate=0.0, core_dropout_rate=0.0, decoder_dropout_rate=0.0,
+                      loss="laplace_nll", weight_decay=0.0, learning_rate=1e-3, seed=0, loss_buffer_size=10,
+                      loss_buffer_temperature=0.3).cuda()
+    m.train()
+    opt = m.configure_optimizers()["optimizer"]
+    batch = {"image": torch.rand(16, 2, 256, 256, device="cuda"), "label": torch.rand(16, 1, 256, 256, device="cuda")}
+
+    def step(i):
+        opt.zero_grad()
+        m.training_step(batch, i)["loss"].backward()
+        opt.step()
+
+    for i in range(4):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(10):
+        step(i)
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    report(f"training loop, cfg3 batch 16: host enqueued 10 steps in {host * 1e3:.1f} ms, the GPU ran them in {total * 1e3:.1f} ms")
+    assert host < 0.7 * total, (host, total)
+
+
 def test_cfg2_full_resolution_batch8_vs_oracle():
     e_out, worst = _oracle_vs_hip(O.NetConfig(3, 2, 2, 21), N=8, H=256, W=256, seed=22, with_mask=True)
     report(f"cfg2 256x256 N=8 [split16]: out err {e_out:.2e}; worst grad tensor {worst}")
