@@ -11,7 +11,7 @@ all: $(LIB)
 
 # every compile leaves hipcc's per-kernel resource remarks next to the object (csrc/*.res): scripts/check_resources.py
 # fails the build when a kernel that counts its vector-memory operations by hand (LDS-DMA) touches scratch
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/sched.h $(CSRC)/elementwise.h include/mimo_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/tile_sched.h $(CSRC)/elementwise.h include/mimo_hip.h
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(@:.o=.res) || (grep -v "remark:" $(@:.o=.res) >&2; false)
 	@grep -E "warning:|error:" -A3 $(@:.o=.res) >&2 || true
 

@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/mimo_hip.h"
-#include "sched.h"
+#include "tile_sched.h"
 
 namespace mimo {
 
@@ -45,7 +45,7 @@ static inline int store_bytes(int dt) { return dt == ST_F32 ? 4 : 2; }
 // operand tiles (the channel tiles of one pixel tile; neighbouring pixel tiles sharing halo rows) are
 // neighbours in virtual order and therefore meet in one L2 instead of eight.
 __device__ __forceinline__ int xcd_virtual_index(int linear, int total) {
-  return sched::xcd_virtual_index(linear, total);  // sched.h: host-testable
+  return sched::xcd_virtual_index(linear, total);  // tile_sched.h: host-testable
 }
 
 // ------------------------------------------------------------------ conv3x3 (conv3x3.hip)

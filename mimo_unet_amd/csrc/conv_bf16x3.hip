@@ -86,7 +86,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPitchB = 144;  // bytes per LDS row (pixel or weight row)
 
-using sched::pick_tile_n;  // sched.h (host-testable)
+using sched::pick_tile_n;  // tile_sched.h (host-testable)
 
 template <int MF>
 struct TileCfg {

@@ -29,14 +29,14 @@
 // persistent workgroups, one per CU, XCD-aware order (channel tiles of a pixel tile share an L2).
 // The 16-bit storage modes (MODE 4-7: bf16-mixed / 16-mixed forward and data gradient) run on the same kernel with one
 // MFMA per product: a K chunk is 32 channels of plain 16-bit data in the same 64-byte rows, the loaders are 16-byte copies.
-// Which layers run here: sched::wide_config (sched.h) — the packer lays the weights out for the decomposition the
+// Which layers run here: sched::wide_config (tile_sched.h) — the packer lays the weights out for the decomposition the
 // launch will use (ConvLaunch::wide).  Measured (profiles/r03/): matrix pipe 62-69 % busy on the
 // wide layers (256-pixel kernel 46-55 %), per-layer forward -7...-13 % in split16, -30...-40 % in the 16-bit modes.
 #include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
-#include "sched.h"
+#include "tile_sched.h"
 
 namespace mimo {
 

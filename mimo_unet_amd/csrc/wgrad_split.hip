@@ -597,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       }
 }
 
-// host-side choices (channel tiles, split counts): sched.h, host-testable
+// host-side choices (channel tiles, split counts): tile_sched.h, host-testable
 static bool wgrad_ws_enabled() {
   static const bool on = !(getenv("MIMO_WGRAD_WS") && atoi(getenv("MIMO_WGRAD_WS")) == 0);
   return on;

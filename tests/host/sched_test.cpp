@@ -1,4 +1,4 @@
-// Host-only sweep of the schedulers in mimo_unet_amd/csrc/sched.h, built with -fsanitize=address,undefined by
+// Host-only sweep of the schedulers in mimo_unet_amd/csrc/tile_sched.h, built with -fsanitize=address,undefined by
 // tests/test_sched_cpu.py (race / memory tooling of the host side).
 //   * xcd_virtual_index: a bijection on [0, total) for every grid size 1 .. 4096, every XCD a contiguous range
 //   * pick_tile_n: for every H, W in 1 .. 300 and both tile sizes, the tiles cover every pixel exactly once, fit the
@@ -10,7 +10,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../../mimo_unet_amd/csrc/sched.h"
+#include "../../mimo_unet_amd/csrc/tile_sched.h"
 
 using namespace mimo::sched;
 

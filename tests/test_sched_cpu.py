@@ -1,4 +1,4 @@
-"""Host-side schedulers (mimo_unet_amd/csrc/sched.h: XCD workgroup order, tile shapes, channel-tile widths, split
+"""Host-side schedulers (mimo_unet_amd/csrc/tile_sched.h: XCD workgroup order, tile shapes, channel-tile widths, split
 counts, the wide-convolution dispatch) compiled with g++ -fsanitize=address,undefined and swept over their argument
 ranges — the kernels consume exactly these functions (the .hip files include the same header)."""
 import os
