@@ -115,7 +115,10 @@ class _NetFunction(torch.autograd.Function):
         S, Co = net.num_subnetworks, net.out_channels
         out = torch.empty(n, S, Co, plan.height, plan.width, device=x.device, dtype=torch.float32)
         plan.bind(net._flat_params, net._flat_grads, net._flat_buffers)
-        plan.forward(x, out, training=bn_training, perm=perm, masks=masks, elem_masks=elem_masks, rng=rng)
+        plan.forward(x, out, training=bn_training, perm=perm, masks=masks, elem_masks=elem_masks, rng=rng,
+                     param_version=net._param_version())
+        if bn_training:
+            net._last_train_plan = weakref.ref(plan)  # FlatAdam.step() repacks its weights early (prepack_weights)
         if label is not None:
             loss = torch.empty(S, device=x.device, dtype=torch.float32)
             plan.loss_forward(label, lmask, perm, loss)
@@ -510,6 +513,20 @@ class MimoUNet(nn.Module):
     def mark_parameters_changed(self) -> None:
         """Call after writing the flat parameter / buffer storage through a raw pointer."""
         self._param_epoch += 1
+
+    def prepack_weights(self) -> None:
+        """After an optimiser step: repack the convolution weights of the plan the last training forward ran on NOW,
+        on the engine's side stream, so that the next training step does not start with the repack in front of its
+        first convolution (mimo_plan_prepack; the next forward uses it only if the parameters have not changed again)."""
+        if os.environ.get("MIMO_PREPACK", "1") == "0":  # A/B switch: repack at the start of the next forward, as before
+            return
+        ref = getattr(self, "_last_train_plan", None)
+        plan = ref() if ref is not None else None
+        # (not while a graph of that plan still waits for its backward: its data-gradient weights are the packed ones)
+        if (plan is not None and getattr(plan, "pending", None) is None and self._flat_params is not None
+                and any(p is plan for p in self._plans.values())):
+            plan.bind(self._flat_params, self._flat_grads, self._flat_buffers)
+            plan.prepack(self._param_version())
 
     def _param_version(self) -> int:
         """Changes whenever the parameters / BatchNorm buffers may have changed.  The nn.Parameters are views
