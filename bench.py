@@ -16,9 +16,10 @@ NLL's scale head collapse on single pixels after ~100 steps in every arithmetic,
 step, PyTorch default random init, fp32 storage (MIMO_PRECISION=bf16-mixed | 16-mixed select the 16-bit storage modes — reduced precision, never the
 headline metric).
 
-Scaling: "weak" (default) = the per-GPU batch is fixed at the config's batch (32: the reference README's
-SEN12TP batch size with Lightning-DDP semantics, batch_size = per device); "strong" = the config's batch is
-the GLOBAL batch, sharded over the ranks (32 global, 4 per GPU at 8).
+Scaling: "strong" (default) = the config's batch is the GLOBAL batch, sharded over the ranks (cfg3 = 32
+global, 4 per GPU at 8) — `value` at N > 1 is that regime; "weak" = the per-GPU batch is fixed at the config's batch
+(32: the reference README's SEN12TP batch size with Lightning-DDP semantics, batch_size = per device).  At N > 1 the
+line carries both (`config.strong_images_per_s`, `config.weak_images_per_s`), each from its own timed pass.
 
 The timed region runs WITHOUT instrumentation.  A second, shorter pass with HIP events recorded on the launch
 stream around every kernel class and every resolution tier gives the roofline numbers; at N=1 the CPU oracle
@@ -109,19 +110,38 @@ def make_model(c):
                          loss_buffer_size=10, loss_buffer_temperature=0.3)
 
 
+def csrc_hash():
+    """Content hash of the kernel sources (mimo_unet_amd/csrc/*.hip, *.h) — what ties a committed counter summary to
+    the build that runs (no git on the GPU box: hashed from the files themselves)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mimo_unet_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
     """HBM bytes from the committed counter passes of this same command (profiles/<round>/final/pmc_traffic.json,
     written from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs — counters cannot be collected from inside the
-    timed run).  None when no summary is committed."""
+    timed run).  Only a summary collected on THIS build's kernel sources counts (its "csrc_hash" == csrc_hash()):
+    (None, why) otherwise — a stale summary must not be reported as this run's traffic."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "final", "pmc_traffic.json")))
     if not files:
-        return None, None
+        return None, "no committed pmc_traffic.json"
     try:
         with open(files[-1]) as fh:
-            return json.load(fh), os.path.relpath(files[-1], ROOT)
+            pt = json.load(fh)
     except (ValueError, OSError):
-        return None, None
+        return None, "unreadable " + os.path.relpath(files[-1], ROOT)
+    rel = os.path.relpath(files[-1], ROOT)
+    if pt.get("csrc_hash") != csrc_hash():
+        return None, f"{rel} was collected on other kernel sources (csrc_hash {pt.get('csrc_hash')} != {csrc_hash()})"
+    return pt, rel
 
 
 def cpu_baseline(c, batch=8, warmup=2, steps=5, threads=None):
@@ -156,7 +176,7 @@ def visible_gpu_count(sysfs="/sys/class/kfd/kfd/topology/nodes"):
     initialise the GPU before it starts its children): KFD topology nodes with SIMDs, cut down by
     ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None when sysfs does not say."""
     if not os.path.isdir(os.path.dirname(os.path.dirname(sysfs))):
-        return 0  # no KFD driver at all: no AMD GPU on this host
+        return None  # sysfs does not say (masked in a container, or no KFD driver): the ranks' own device check decides
     try:
         n = 0
         for node in sorted(os.listdir(sysfs)):
@@ -197,7 +217,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="the config's batch (per GPU when weak, global when strong)")
-    ap.add_argument("--scaling", default=os.environ.get("MIMO_BENCH_SCALING", "weak"), choices=["weak", "strong"])
+    # strong (default) = the config's batch is the GLOBAL batch (cfg3 = 32 global, 4 per GPU at 8 GPUs);
+    # weak = the config's batch per GPU (Lightning-DDP's batch_size semantics).  At one GPU the two are the same run.
+    ap.add_argument("--scaling", default=os.environ.get("MIMO_BENCH_SCALING", "strong"), choices=["weak", "strong"])
+    ap.add_argument("--labels", default="learnable", choices=["learnable", "uniform"],
+                    help="learnable: label = learnable_label(image); uniform: SURVEY 8d's label ~ U[0,1)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the instrumented second pass (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -218,6 +242,10 @@ def main():
     # one process per GPU over RCCL ("nccl").  MIMO_BENCH_BACKEND=gloo lets several ranks share one GPU
     # (functional check of the data-parallel path on a single-GPU box; not a performance configuration)
     backend = os.environ.get("MIMO_BENCH_BACKEND", "nccl")
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        # (the spawning parent could not tell from sysfs, or the ranks were started by hand)
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible "
+                         "(MIMO_BENCH_BACKEND=gloo lets ranks share one)")
     dev = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev)
     dist = None
@@ -254,17 +282,22 @@ def main():
             dist.broadcast(t.data, 0)
     opt = model.configure_optimizers()["optimizer"]
     opt.reduce_scale = 1.0 / world
+    def make_label(image, g):
+        if args.labels == "uniform":
+            return torch.rand(image.shape[0], 1, c["H"], c["W"], device="cuda", generator=g)
+        return learnable_label(image, generator=g)
+
     def make_batch(scaling):
         if scaling == "strong":
             # the global batch, identical on every rank, sharded by rank (ddp.shard_batch: rows [r*B, (r+1)*B))
             from mimo_unet_amd.ddp import shard_batch
             g = torch.Generator(device="cuda").manual_seed(100)
             image = torch.rand(c["batch"], c["Ci"], c["H"], c["W"], device="cuda", generator=g)
-            b = shard_batch({"image": image, "label": learnable_label(image, generator=g)}, rank, world)
+            b = shard_batch({"image": image, "label": make_label(image, g)}, rank, world)
             return {k: v.contiguous() for k, v in b.items()}
         g = torch.Generator(device="cuda").manual_seed(100 + rank)
         image = torch.rand(c["batch"], c["Ci"], c["H"], c["W"], device="cuda", generator=g)
-        return {"image": image, "label": learnable_label(image, generator=g)}
+        return {"image": image, "label": make_label(image, g)}
 
     batch = make_batch(args.scaling)
 
@@ -389,7 +422,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{c['name']}, batch {c['batch']} " + ("global" if args.scaling == "strong" else "per GPU"),
                    "global_batch": world * B, "per_gpu_batch": B, "image": [c["H"], c["W"]], "scaling": args.scaling,
-                   "labels": "learnable_label(image): 5x5-smoothed channel mix + U(-0.025, 0.025) noise; same batch every step",
+                   "labels": ("learnable_label(image): 5x5-smoothed channel mix + U(-0.025, 0.025) noise" if args.labels == "learnable"
+                              else "U[0,1) (SURVEY 8d)") + "; same batch every step",
                    "parallelism": f"dp{world}" + ("" if dist is None else f" ({backend}: bucketed all-reduce started inside the backward)"),
                    "world_size": world, "backend": None if dist is None else backend,
                    # ranks that really ran RCCL (None under the gloo functional check and at one rank)
@@ -436,8 +470,9 @@ def main():
                                   "hbm_frac": round(28.0 * nparam / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "split16": SPLIT16_PEAK_TFLOPS, "bf16": 2500.0}.get(precision, 2500.0)
-        traffic = traffic_src = step_traffic = None
-        if args.config == "cfg3" and precision == "split16" and args.scaling == "weak" and not args.batch:
+        traffic = step_traffic = None
+        traffic_src = "counter summaries are collected for cfg3 / split16 / batch 32 on one GPU only"
+        if args.config == "cfg3" and precision == "split16" and world == 1 and not args.batch:
             pt, traffic_src = pmc_traffic()
             if pt is not None:
                 traffic = int(pt["classes"][dom]["bytes_per_launch"]) if dom in pt.get("classes", {}) else None
@@ -445,7 +480,10 @@ def main():
         tier_ms = [(f + b) / psteps for f, b in tiers]
         line["roofline"] = {
             "kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic,
+            "unit": "TFLOP/s", "frac": round(kernels[dom]["tflops"] / peak, 4),
+            # the same flops against the raw dense 16-bit MFMA peak (no division by the 3 MFMAs split16 spends per product)
+            "frac_raw_peak": round(kernels[dom]["tflops"] / (FP32_MFMA_PEAK_TFLOPS if precision == "fp32" else 2500.0), 4),
+            "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
             "step_traffic_bytes": step_traffic,
             "arithmetic": {"fp32": "f32-input MFMA",

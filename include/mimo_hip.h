@@ -192,14 +192,6 @@ int mimo_loss_forward(mimo_plan* plan, const float* label, const float* mask, co
  * Parameter gradients are written (not accumulated) into the bound flat grads buffer. */
 int mimo_backward(mimo_plan* plan, const float* dout, const float* dloss, float* dx, mimo_stream stream);
 
-/* Optional, after the optimiser step (no reference counterpart: cuDNN keeps no packed weight images): repack the
- * weights of the NEXT training forward now, on the plan's side stream, ordered behind everything enqueued on `stream`
- * so far (the optimiser kernel).  param_version = the mimo_forward_args::param_version the next forward will pass; a
- * forward with another version ignores the prepack and packs itself.  No-op (returns 0) for inference-only plans, with
- * MIMO_WGRAD_STREAM=0, for param_version 0.  Overlaps the repack (66 us on cfg3, 260 us on cfg4) with the small
- * kernels at the start of the next step. */
-int mimo_plan_prepack(mimo_plan* plan, int64_t param_version, mimo_stream stream);
-
 /* The same backward in stages, for data-parallel training (no reference counterpart: the reference is
  * single-GPU, scripts/train/train_ndvi.py:70 `devices=1`).  Stages run in order 0 .. n-1:
  *   0 heads + S decoders, 1 up3, 2 up2, 3 up1, 4 down4, 5 down3, 6 down2, 7 the S encoders (+ dx).

@@ -64,7 +64,6 @@ _SIGNATURES = {
     "mimo_plan_bind": (C.c_int, [_P, _P, _P, _P]),
     "mimo_plan_dropout_mask": (C.c_int, [_P, C.c_int, _P, _P]),
     "mimo_plan_status": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32, _P]),
-    "mimo_plan_prepack": (C.c_int, [_P, _L, _P]),
     "mimo_plan_num_double_convs": (C.c_int, [_P]),
     "mimo_plan_double_conv_channels": (C.c_int, [_P, C.c_int]),
     "mimo_forward": (C.c_int, [_P, C.POINTER(ForwardArgs), _P]),

@@ -654,6 +654,10 @@ int conv3x3_wide_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t st
     set_error("conv3x3 wide: weights packed for %d rows, launch geometry gives %d (nf %d)", a.wide, c.rows_pad, c.nf);
     return MIMO_ERR_INVALID;
   }
+  if ((int64_t)a.Hi * a.Wi * a.ldx * 4 > (int64_t)INT32_MAX) {  // 32-bit per-unit source offsets (WD_OFFS)
+    set_error("conv3x3 wide: input image of %d x %d x %d exceeds the kernel's 32-bit offsets", a.Hi, a.Wi, a.ldx);
+    return MIMO_ERR_INVALID;
+  }
   const int tilesY = ceil_div(a.Ho, c.TR), tilesX = ceil_div(a.Wo, c.TC);
   const int numTiles = a.N * tilesY * tilesX;
   const int coTiles = c.rows_pad / (c.nf * 32);

@@ -163,7 +163,7 @@ struct mimo_plan {
   hipStream_t wg_stream = nullptr;
   static constexpr int kDzBufs = 2;
   static constexpr int wg_bufs = kDzBufs;
-  hipEvent_t ev_dz[kDzBufs] = {}, ev_wg[kDzBufs] = {}, ev_join = nullptr, ev_pack = nullptr;
+  hipEvent_t ev_dz[kDzBufs] = {}, ev_wg[kDzBufs] = {}, ev_join = nullptr;
   bool wg_pending[kDzBufs] = {};
   float* s_dz2[kDzBufs] = {};
   // split (bf16 hi|lo) copy of dz for layers whose data gradient runs on the fp32 kernel while the weight
@@ -279,7 +279,6 @@ struct mimo_plan {
   int bwd_next_stage = 0;  // staged backward: the stage that may run next (0 = a fresh backward)
   bool fwd_no_grad = false;       // last forward folded BN/ReLU into the conv epilogue: nothing saved for a backward
   int64_t derived_version = -1;   // param_version the packed weights / eval scale+shift were derived from (-1: none)
-  int64_t prepack_version = 0;    // != 0: mimo_plan_prepack packed the weights of this param_version on the side stream (ev_pack)
   bool derived_dgrad = false;     // ... including the data-gradient weight copies
   bool need_derive = true;        // per-call: (re)pack weights and eval BN constants in this forward
   int64_t encoder_param_floats = 0;
@@ -305,7 +304,6 @@ struct mimo_plan {
       for (hipEvent_t e : {ev_dz[i], ev_wg[i]})
         if (e) (void)hipEventDestroy(e);
     if (ev_join) (void)hipEventDestroy(ev_join);
-    if (ev_pack) (void)hipEventDestroy(ev_pack);
   }
 
   template <typename T>
@@ -669,7 +667,6 @@ struct mimo_plan {
         for (int i = 0; i < wg_bufs; ++i)
           for (hipEvent_t* e : {&ev_dz[i], &ev_wg[i]}) MIMO_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         MIMO_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        MIMO_HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
       }
     }
     MIMO_TRY(alloc_act(&s_dxpadA, cap_pad, st));
@@ -773,21 +770,6 @@ struct mimo_plan {
   // one launch over the job table
   int pack_all(bool with_dgrad, hipStream_t st) {
     return pack_jobs_launch(pack_jobs, with_dgrad ? n_all_jobs : n_fwd_jobs, pack_max_total, params, st);
-  }
-
-  // mimo_plan_prepack: the weight repack of the NEXT training forward, issued right after the optimiser step on the side
-  // stream (ordered behind everything enqueued on `st` so far: the optimiser kernel that wrote the parameters, and with it
-  // the whole previous backward that read the packed images).  It runs beside the first small kernels of the next step
-  // instead of in front of its first convolution; the forward takes it only when its param_version is the one packed.
-  int prepack(int64_t version, hipStream_t st) {
-    if (!wg_async || cfg.inference_only || version == 0 || !params) return MIMO_OK;  // nothing to overlap with / unknown version
-    MIMO_HIP_CHECK(hipEventRecord(ev_pack, st));
-    MIMO_HIP_CHECK(hipStreamWaitEvent(wg_stream, ev_pack, 0));
-    MIMO_TRY(pack_all(true, wg_stream));
-    MIMO_HIP_CHECK(hipEventRecord(ev_pack, wg_stream));
-    prepack_version = version;
-    derived_version = -1;  // an eval forward re-derives its constants (the packed images now belong to `version`)
-    return MIMO_OK;
   }
 
   int convbn_forward(ConvBN& L, bool training, const float* mask, hipStream_t st) {
@@ -1012,15 +994,7 @@ struct mimo_plan {
     elem_masks.assign(1 + S, nullptr);
     if (args->elem_masks)
       for (int i = 0; i <= S; ++i) elem_masks[i] = args->elem_masks[i];
-    if (need_derive) {
-      if (prepack_version != 0 && prepack_version == args->param_version) {
-        MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_pack, 0));  // packed on the side stream since the optimiser step
-      } else {
-        if (prepack_version != 0) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_pack, 0));  // stale prepack: still order behind it
-        MIMO_TRY(pack_all(training, st));
-      }
-    }
-    prepack_version = 0;
+    if (need_derive) MIMO_TRY(pack_all(training, st));
     for (int s = 0; s < S; ++s)
       MIMO_TRY(pack_input_launch(args->x, args->stride_n, args->stride_s, args->perm, s, N, Ci, H, W, enc_in[s]->in_buf,
                                  Ci_p, st));
@@ -1527,14 +1501,6 @@ int mimo_forward(mimo_plan* plan, const mimo_forward_args* args, mimo_stream str
     return MIMO_ERR_INVALID;
   }
   return plan->forward(args, (hipStream_t)stream);
-}
-
-int mimo_plan_prepack(mimo_plan* plan, int64_t param_version, mimo_stream stream) {
-  if (!plan) {
-    set_error("mimo_plan_prepack: null plan");
-    return MIMO_ERR_INVALID;
-  }
-  return plan->prepack(param_version, (hipStream_t)stream);
 }
 
 int mimo_loss_forward(mimo_plan* plan, const float* label, const float* mask, const int64_t* perm, float* loss_out,

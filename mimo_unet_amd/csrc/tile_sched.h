@@ -3,6 +3,8 @@
 // g++ -fsanitize=address,undefined and sweeps every function over its whole argument range (tests/test_sched_cpu.py).
 #pragma once
 
+#include <cstdint>
+
 #if defined(__HIPCC__)
 #define MIMO_SCHED_HD __host__ __device__
 #else
@@ -136,6 +138,11 @@ static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, 
   const bool s16 = mode >= 4 && mode <= 7;  // 16-bit storage modes: 32-channel chunks, one MFMA per product
   if (force < 0 || !(mode == 0 || mode == 1 || s16) || rows < 1 || cin_p < 16 || Ho < 2 || Wo < 2) return c;
   if (s16 && cin_p % 8 != 0) return c;
+  // the kernel carries per-unit source offsets (iy * Wi + ix) * ld * element size as 32-bit integers: a layer whose
+  // input image (padded-domain gradients: + 2 rows / columns; ld >= cin_p) reaches 2 GiB stays on the 256-pixel kernel
+  // (pixel pitch taken as up to twice the wider channel count: a channel slice of a concat buffer; the launch checks
+  // its real geometry and refuses instead of reading out of bounds)
+  if (int64_t(Ho + 2) * int64_t(Wo + 2) * int64_t(cin_p < rows ? rows : cin_p) * 8 > int64_t(INT32_MAX)) return c;
   int TR, TC;
   pick_tile_n(Ho, Wo, kWideNPix, kWideMaxPix, &TR, &TC);
   if ((TR + 2) * (TC + 2) > kWideMaxPix) return c;

@@ -73,6 +73,10 @@ class FlatGradientAllReducer:
         self._pending: List = []
         self._held = None  # (flat, begin, end): announced, not yet issued
         self.issued: List = []  # [(begin, end)] of the collectives of the current step (diagnostics / tests)
+        # (flat buffer, its torch version counter) right after the last collective issued on it: while the counter still
+        # has that value nothing has written the gradients through torch since (no zero_grad(set_to_none=False), no
+        # clipping), so a backward that ACCUMULATES into them would sum an already-reduced micro-batch over the ranks again
+        self._reduced = None
 
     @property
     def scale(self) -> float:
@@ -83,6 +87,11 @@ class FlatGradientAllReducer:
             hi = min(end, lo + self.bucket_floats)
             self.issued.append((lo, hi))
             self._pending.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._reduced = (flat, flat._version)
+
+    def reduced_version(self, flat: torch.Tensor):
+        """torch version counter of `flat` after the last collective issued on it, None if there was none."""
+        return self._reduced[1] if self._reduced is not None and self._reduced[0] is flat else None
 
     def _flush(self) -> None:
         if self._held is not None:

@@ -156,11 +156,6 @@ class Plan:
                    2: "a BatchNorm-backward sum was not finite",
                    4: "a logit was not finite"}
 
-    def prepack(self, param_version: int) -> None:
-        """Repack the weights of the next training forward now, on the plan's side stream (mimo_plan_prepack); the
-        forward takes it when it is called with the same `param_version`."""
-        L.check(self.lib.mimo_plan_prepack(self.handle, int(param_version), L.current_stream()), "mimo_plan_prepack")
-
     def status(self, clear: bool = True) -> int:
         """Numerics status word of the plan's kernels since the last clear (mimo_plan_status; synchronises the
         current stream).  0 = nothing recorded; bits: STATUS_BITS."""

@@ -117,8 +117,6 @@ class _NetFunction(torch.autograd.Function):
         plan.bind(net._flat_params, net._flat_grads, net._flat_buffers)
         plan.forward(x, out, training=bn_training, perm=perm, masks=masks, elem_masks=elem_masks, rng=rng,
                      param_version=net._param_version())
-        if bn_training:
-            net._last_train_plan = weakref.ref(plan)  # FlatAdam.step() repacks its weights early (prepack_weights)
         if label is not None:
             loss = torch.empty(S, device=x.device, dtype=torch.float32)
             plan.loss_forward(label, lmask, perm, loss)
@@ -442,9 +440,11 @@ class MimoUNet(nn.Module):
         hook = self.grad_ready_hook
         sync = getattr(self, "grad_sync", None)  # the reducer behind the hook (FlatGradientAllReducer.attach), if any
         announcing = hook is not None and (sync is None or sync.enabled)
-        if not aliased:
-            self._reduced_in_window = False  # a fresh accumulation window (zero_grad() dropped the gradients)
-        elif announcing and sync is not None and getattr(self, "_reduced_in_window", False):
+        # "Already reduced" = the reducer really took ranges of this buffer (not a one-rank no-op reducer) and nothing has
+        # written the .grad tensors through torch since: zero_grad(set_to_none=False) of a stock optimiser zeroes them in
+        # place, which bumps their version counters — that is a fresh window, not an accumulation.
+        # (every view of the flat buffer shares its version counter; the reducer notes it after each collective it issues)
+        if aliased and announcing and sync is not None and sync.reduced_version(g) == g._version:
             # data-parallel gradient accumulation done wrong: the gradients of an earlier micro-batch were already
             # summed over the ranks in place; adding them to this micro-batch and reducing again would count them
             # world_size times
@@ -468,7 +468,6 @@ class MimoUNet(nn.Module):
             for st, (b, e) in enumerate(plan.backward_stages):
                 plan.backward(dout, dloss, dx, stage=st)
                 hook(g, b, e)
-            self._reduced_in_window = True
         for p, v in views:
             if p.grad is None:
                 p.grad = v
@@ -480,7 +479,6 @@ class MimoUNet(nn.Module):
         if announcing and aliased:
             for b, e in plan.backward_stages:
                 hook(g, b, e)
-            self._reduced_in_window = True
 
     def numerics_status(self, clear: bool = True) -> int:
         """OR of the numerics status words of the live plans (`Plan.status`; one device synchronisation per plan).
@@ -513,20 +511,6 @@ class MimoUNet(nn.Module):
     def mark_parameters_changed(self) -> None:
         """Call after writing the flat parameter / buffer storage through a raw pointer."""
         self._param_epoch += 1
-
-    def prepack_weights(self) -> None:
-        """After an optimiser step: repack the convolution weights of the plan the last training forward ran on NOW,
-        on the engine's side stream, so that the next training step does not start with the repack in front of its
-        first convolution (mimo_plan_prepack; the next forward uses it only if the parameters have not changed again)."""
-        if os.environ.get("MIMO_PREPACK", "1") == "0":  # A/B switch: repack at the start of the next forward, as before
-            return
-        ref = getattr(self, "_last_train_plan", None)
-        plan = ref() if ref is not None else None
-        # (not while a graph of that plan still waits for its backward: its data-gradient weights are the packed ones)
-        if (plan is not None and getattr(plan, "pending", None) is None and self._flat_params is not None
-                and any(p is plan for p in self._plans.values())):
-            plan.bind(self._flat_params, self._flat_grads, self._flat_buffers)
-            plan.prepack(self._param_version())
 
     def _param_version(self) -> int:
         """Changes whenever the parameters / BatchNorm buffers may have changed.  The nn.Parameters are views

@@ -76,8 +76,6 @@ class FlatAdam(torch.optim.Optimizer):
                       weight_decay=grp["weight_decay"], step=self._step, grad_scale=self.reduce_scale)
         if hasattr(self.net, "mark_parameters_changed"):
             self.net.mark_parameters_changed()  # the kernel wrote the parameters through a raw pointer
-        if hasattr(self.net, "prepack_weights"):
-            self.net.prepack_weights()  # the next step's weight repack, beside its first small kernels instead of in front of them
         return loss
 
     @property

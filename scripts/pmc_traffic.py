@@ -4,7 +4,11 @@ total) from the FETCH_SIZE / WRITE_SIZE counter summaries written by scripts/col
     python scripts/pmc_traffic.py profiles/r01/final [steps_executed=3]"""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash  # noqa: E402  (ties the summary to the kernel sources it was collected on)
 
 D = sys.argv[1].rstrip("/") + "/"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -39,7 +43,7 @@ for k, (n, c) in F.items():
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
                  "--warmup 1 --no-cpu-baseline; FETCH_SIZE in KB x2 (gfx950: a wide coalesced read is tallied at half its "
                  "bytes, MI355X_MICROARCH.md HBM section), WRITE_SIZE in KB; summed over the executed steps",
-       "steps": steps, "step_bytes": round((tot_r + tot_w) / steps), "total_gb_per_step": {"read": round(tot_r / steps / 1e9, 2), "write": round(tot_w / steps / 1e9, 2)},
+       "csrc_hash": csrc_hash(), "steps": steps, "step_bytes": round((tot_r + tot_w) / steps), "total_gb_per_step": {"read": round(tot_r / steps / 1e9, 2), "write": round(tot_w / steps / 1e9, 2)},
        "classes": {c_: {"launches_per_step": a["launches"] / steps, "read_bytes_per_launch": round(a["read"] / a["launches"]),
                         "write_bytes_per_launch": round(a["write"] / a["launches"]),
                         "bytes_per_launch": round((a["read"] + a["write"]) / a["launches"])} for c_, a in agg.items()}}

@@ -174,8 +174,17 @@ static void test_pinned_decisions() {
   }
 }
 
+// wide kernel: 32-bit per-unit source offsets - a layer whose image reaches 2 GiB must stay on the 256-pixel kernel
+static void test_wide_offset_guard() {
+  CHECK(wide_config(1, 1, 32, 32, 1024, 1024, 1).nf != 0, "1024x1024x32 fits 32-bit offsets");
+  CHECK(wide_config(1, 1, 128, 128, 2048, 2048, 1).nf == 0, "2048x2048x128 fp32 overflows 32-bit offsets: not wide");
+  CHECK(wide_config(1, 1, 32, 32, 4096, 4096, 1).nf == 0, "4096x4096x32 overflows with a 2x pixel pitch: not wide");
+  CHECK(wide_config(0, 1, 64, 64, 2048, 2048, 0).nf == 0, "data gradient, same bound");
+}
+
 int main() {
   test_xcd();
+  test_wide_offset_guard();
   test_tiles();
   test_layers();
   test_pinned_decisions();

@@ -60,7 +60,7 @@ def test_training_loop_runs_ahead_of_the_gpu():
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
     report(f"training loop, cfg3 batch 16: host enqueued 10 steps in {host * 1e3:.1f} ms, the GPU ran them in {total * 1e3:.1f} ms")
-    assert host < 0.8 * total, (host, total)  # observed 0.2; a per-step synchronisation gives ~0.9
+    assert host < 0.5 * total, (host, total)  # observed 0.2; a per-step synchronisation gives ~0.9
 
 
 def test_cfg2_full_resolution_batch8_vs_oracle():

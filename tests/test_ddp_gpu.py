@@ -173,7 +173,9 @@ def test_bench_spawns_its_own_ranks_gloo_sharing_the_gpu():
 def test_bench_two_ranks_rccl():
     line = _run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4", "--profile-steps", "0",
                       "--no-cpu-baseline")
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 8
+    # default regime = strong: the batch of 4 is the global batch, 2 per GPU; the weak regime rides along
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_batch"] == 4
+    assert line["config"]["weak_images_per_s"] > 0 and line["config"]["weak_per_gpu_batch"] == 4
     assert line["config"]["rccl_ranks"] == 2 and line["config"]["backend"] == "nccl"
     assert line["config"]["params_bit_identical_across_ranks"] is True
     assert len(set(line["config"]["rank_devices"])) == 2  # one GPU per rank

@@ -370,7 +370,8 @@ def test_bench_counts_gpus_without_touching_hip(tmp_path, monkeypatch):
     assert bench.visible_gpu_count(str(nodes)) == 2
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
     assert bench.visible_gpu_count(str(nodes)) == 1
-    assert bench.visible_gpu_count(str(tmp_path / "nothing" / "topology" / "nodes")) == 0  # no KFD at all
+    # no KFD sysfs tree (masked in a container, or no driver): "sysfs does not say" — the ranks' own device check decides
+    assert bench.visible_gpu_count(str(tmp_path / "nothing" / "topology" / "nodes")) is None
     src = open(os.path.join(ROOT, "bench.py")).read()
     body = src[src.index("def spawn_ranks"):src.index("def main")]
     assert "torch.cuda" not in body.split('"""')[2]  # the spawning parent makes no torch.cuda call
