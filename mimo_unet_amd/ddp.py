@@ -137,6 +137,8 @@ class FlatGradientAllReducer:
         self._flush()
         for w in self._pending:
             w.wait()
+        if self._pending and self._reduced is not None:
+            self._reduced = (self._reduced[0], self._reduced[0]._version)  # (a backend may bump the counter on completion)
         self._pending.clear()
         self.issued = []
 

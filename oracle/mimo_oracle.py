@@ -25,6 +25,7 @@ Reference citations (relative to /root/reference):
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -498,12 +499,25 @@ class TrainState:
         return [n for n in self.st if not is_buffer(n)]
 
 
+def reference_autocast(kind: Optional[str]):
+    """The reference's own mixed precision: Lightning `precision="16-mixed"` (scripts/train/train_ndvi.py:71,
+    train_nyuv2_depth.py:74) / "bf16-mixed" runs training_step under `torch.autocast(device, dtype)`.  Every operator of
+    this restatement is the torch functional the reference's modules call, so running it under the same context
+    reproduces the reference's rounding points (pinned by tests/golden/amp_*.npz, generated from the reference itself
+    under torch's CPU autocast policy: conv2d in the 16-bit type, reflection_pad2d in fp32, BatchNorm on 16-bit
+    activations with fp32 statistics, 16-bit logits, loss by type promotion).  kind: "bf16-mixed" | "16-mixed" | None."""
+    if kind is None:
+        return contextlib.nullcontext()
+    return torch.autocast("cpu", dtype={"bf16-mixed": torch.bfloat16, "16-mixed": torch.float16}[kind])
+
+
 def train_step(ts: TrainState, image: Tensor, label: Tensor, mask: Optional[Tensor], perms: Tensor,
                masks: Optional[Dict[str, Tensor]] = None, apply_optimizer: bool = True,
-               want_input_grad: bool = False, loss_scale: float = 1.0) -> Dict[str, Tensor]:
+               want_input_grad: bool = False, loss_scale: float = 1.0, autocast: Optional[str] = None) -> Dict[str, Tensor]:
     """training_step + backward + Adam.  Returns losses, weights, grads, outputs.  loss_scale: the backward runs on
     loss_scale * total and the gradients are divided by it (what a GradScaler does; matters only with the 16-bit
-    gradient-storage emulation)."""
+    gradient-storage emulation).  autocast: run forward + loss under `reference_autocast(kind)`, the backward outside it
+    (Lightning's MixedPrecisionPlugin)."""
     cfg = ts.cfg
     names = ts.param_names()
     leaves = {n: ts.st[n].detach().clone().requires_grad_(True) for n in names}
@@ -514,16 +528,17 @@ def train_step(ts: TrainState, image: Tensor, label: Tensor, mask: Optional[Tens
         x = x.detach().requires_grad_(True)
     y = apply_perms(label, perms)
     mk = apply_perms(mask, perms)
-    out = mimo_unet_forward(cfg, st, x, training=True, masks=masks)
-    for n in ts.st:  # BN running buffers were updated through the st copy
-        if is_buffer(n):
-            ts.st[n] = st[n]
-    p1, p2 = split_heads(out, cfg.out_channels)
-    per_elem = loss_forward(ts.loss_kind, p1, p2, y, mask=mk, reduce_mean=False)
-    loss = per_elem.mean(dim=(0, 2, 3, 4))                     # mimo_unet.py:241-242
-    weights = ts.loss_buffer.get_weights()                      # read BEFORE add (:243-245)
-    ts.loss_buffer.add(loss.detach())
-    total = (loss * weights).mean()                             # :138
+    with reference_autocast(autocast):
+        out = mimo_unet_forward(cfg, st, x, training=True, masks=masks)
+        for n in ts.st:  # BN running buffers were updated through the st copy
+            if is_buffer(n):
+                ts.st[n] = st[n]
+        p1, p2 = split_heads(out, cfg.out_channels)
+        per_elem = loss_forward(ts.loss_kind, p1, p2, y, mask=mk, reduce_mean=False)
+        loss = per_elem.mean(dim=(0, 2, 3, 4))                     # mimo_unet.py:241-242
+        weights = ts.loss_buffer.get_weights()                      # read BEFORE add (:243-245)
+        ts.loss_buffer.add(loss.detach())
+        total = (loss * weights).mean()                             # :138
     (total * loss_scale).backward()
     grads = {n: leaves[n].grad / loss_scale for n in names}
     res = {"out": out.detach(), "loss": loss.detach(), "weights": weights, "total": total.detach(), "grads": grads}

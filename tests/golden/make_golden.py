@@ -299,6 +299,69 @@ def evidential_fixture():
     print("evidential.npz")
 
 
+def amp_fixture(name, src, *, Ci, Co, S, f, N, H, W, use_mask, seed, T=0.3):
+    """The reference's PRODUCTION precision (scripts/train/train_ndvi.py:71, train_nyuv2_depth.py:74: Lightning
+    precision="16-mixed") and its bf16 twin, from the real reference modules under torch.autocast: Lightning's
+    MixedPrecisionPlugin runs training_step (forward AND loss) inside `torch.autocast(device, dtype)` and the backward
+    outside it, on scaler.scale(loss).  There is no GPU here, so this is torch's CPU autocast policy (conv2d -> 16-bit,
+    reflection_pad2d -> fp32, everything else by type promotion: BatchNorm keeps 16-bit activations with fp32
+    statistics); the fp16 run uses a FIXED loss scale (recorded) instead of GradScaler's dynamic one.
+
+    Same seed, parameters and step-0 inputs as the fp32 fixture `src` (asserted), so that each tensor here has its fp32
+    counterpart there: the distance between the two is the reference's own precision loss in that mode."""
+    ref = np.load(os.path.join(HERE, src))
+    torch.manual_seed(seed)
+    net = MimoUNet(in_channels=Ci, out_channels=Co, num_subnetworks=S, filter_base_count=f)
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    for k, v in state0.items():
+        assert np.array_equal(npd(v), ref["init/" + k]), k
+    g = torch.Generator().manual_seed(seed + 1)
+    image = torch.rand(N, Ci, H, W, generator=g)
+    label = torch.rand(N, Co // 2, H, W, generator=g)
+    mask = (torch.rand(N, 1, H, W, generator=g) > 0.25).float() if use_mask else None
+    perms = recorded_perms(1000 + seed, N, S)
+    assert np.array_equal(npd(image), ref["s0/image"]) and np.array_equal(npd(perms), ref["s0/perms"])
+    fx = {"meta": ref["meta"], "src": np.array(src), "torch_version": np.array(torch.__version__),
+          "policy": np.array("torch.autocast('cpu', dtype): forward + loss inside, backward outside (Lightning MixedPrecisionPlugin)")}
+    for tag, dtype, scale in (("bf16", torch.bfloat16, 1.0), ("fp16", torch.float16, 1024.0)):
+        net.load_state_dict(state0)
+        net.train()
+        net.zero_grad()
+        crit = LaplaceNLL()
+        lb = LossBuffer(subnetworks=S, temperature=T, buffer_size=10)
+        torch.manual_seed(1000 + seed)
+        xt, yt, mt = apply_input_transform(image, label, mask, num_subnetworks=S)
+        xt.requires_grad_(True)
+        with torch.autocast("cpu", dtype=dtype):
+            out = net(xt)
+            p1, p2 = out[:, :, :Co // 2], out[:, :, Co // 2:]
+            raw = crit.forward(p1, p2, yt, reduce_mean=False, mask=mt)
+            loss = raw.mean(dim=(0, 2, 3, 4))
+            weights = lb.get_weights()
+            lb.add(loss.detach())
+            total = (loss * weights).mean()
+        assert out.dtype == dtype
+        (total * scale).backward()
+        fx[f"{tag}/loss_scale"] = np.float64(scale)
+        fx[f"{tag}/out"], fx[f"{tag}/out_dtype"] = npd(out.float()), np.array(str(out.dtype))
+        fx[f"{tag}/loss"], fx[f"{tag}/total"] = npd(loss.float()), npd(total.float())
+        fx[f"{tag}/loss_dtype"] = np.array(str(loss.dtype))
+        fx[f"{tag}/dx"] = npd(xt.grad / scale)
+        for k, p in net.named_parameters():
+            assert p.grad.dtype == torch.float32
+            fx[f"{tag}/grad/" + k] = npd(p.grad / scale)
+        for k, v in net.state_dict().items():
+            if "running" in k:
+                fx[f"{tag}/after/" + k] = npd(v)
+        # eval-mode forward with the INITIAL running statistics (mean 0, var 1), as the fp32 eval comparisons do
+        net.load_state_dict(state0)
+        net.eval()
+        with torch.no_grad(), torch.autocast("cpu", dtype=dtype):
+            fx[f"{tag}/out_eval"] = npd(net(xt.detach()).float())
+    np.savez_compressed(os.path.join(HERE, name), **fx)
+    print(name, sum(v.nbytes for v in fx.values()) / 1e6, "MB raw")
+
+
 if __name__ == "__main__":
     # BASELINE config[0]: synthetic 3ch 64x64, S=1, fbc=8, batch 4
     train_fixture("cfg1_step.npz", Ci=3, Co=2, S=1, f=8, N=4, H=64, W=64, use_mask=False, steps=3, seed=1)
@@ -312,3 +375,6 @@ if __name__ == "__main__":
     mc_dropout_fixture()
     elem_dropout_fixture()
     evidential_fixture()
+    # the reference's production precision (Lightning "16-mixed") and bf16 autocast, one training step each
+    amp_fixture("amp_cfg1.npz", "cfg1_step.npz", Ci=3, Co=2, S=1, f=8, N=4, H=64, W=64, use_mask=False, seed=1)
+    amp_fixture("amp_mini_s2.npz", "mini_s2_step.npz", Ci=2, Co=2, S=2, f=4, N=3, H=32, W=32, use_mask=True, seed=2)

@@ -38,6 +38,49 @@ def rms_rel_err(a, b):
     return float((a - b).norm() / max(float(b.norm()), 1e-30))
 
 
+AMP_CASES = [("amp_cfg1.npz", "cfg1_step.npz"), ("amp_mini_s2.npz", "mini_s2_step.npz")]
+AMP_TAG = {"bf16-mixed": "bf16", "16-mixed": "fp16"}  # precision mode -> prefix inside tests/golden/amp_*.npz
+
+
+def is_prebn_bias(name):
+    """conv bias in front of a BatchNorm: mathematically zero gradient, pure rounding noise on both sides"""
+    return "double_conv" in name and name.endswith((".0.bias", ".3.bias"))
+
+
+def grads_rel_l2(a, b):
+    """whole-gradient relative L2 distance sqrt(sum |a-b|^2 / sum |b|^2) over every parameter but the pre-BatchNorm biases"""
+    num = den = 0.0
+    for k, gb in b.items():
+        if is_prebn_bias(k):
+            continue
+        x, y = torch.as_tensor(a[k]).double(), torch.as_tensor(gb).double()
+        num, den = num + float(((x - y) ** 2).sum()), den + float((y ** 2).sum())
+    return (num / den) ** 0.5
+
+
+def amp_reference(amp_name, src_name, mode):
+    """One training step of the REFERENCE under torch.autocast (tests/golden/amp_*.npz, make_golden.py::amp_fixture) next
+    to the same step of the reference in fp32 (the fixture it was derived from): inputs, both sets of results, and
+    `d` = how far the reference's own mixed-precision result sits from its fp32 result on each quantity — the yardstick
+    the mixed-precision tolerances are stated in."""
+    amp, fx = load_npz(amp_name), load_npz(src_name)
+    tag = AMP_TAG[mode]
+    sub = lambda pre: {k[len(pre):]: torch.from_numpy(v) for k, v in amp.items() if k.startswith(pre)}
+    g16 = sub(f"{tag}/grad/")
+    g32 = {k[len("s0/grad/"):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("s0/grad/")}
+    r = {"fx": fx, "cfg": cfg_from_meta(fx["meta"]), "scale": float(amp[f"{tag}/loss_scale"]),
+         "image": torch.from_numpy(fx["s0/image"]), "label": torch.from_numpy(fx["s0/label"]),
+         "perms": torch.from_numpy(fx["s0/perms"]), "mask": torch.from_numpy(fx["s0/mask"]) if "s0/mask" in fx else None,
+         "out16": torch.from_numpy(amp[f"{tag}/out"]), "out32": torch.from_numpy(fx["s0/out"]),
+         "eval16": torch.from_numpy(amp[f"{tag}/out_eval"]), "loss16": torch.from_numpy(amp[f"{tag}/loss"]),
+         "loss32": torch.from_numpy(fx["s0/loss"]), "total16": float(amp[f"{tag}/total"]), "grads16": g16, "grads32": g32,
+         "dx16": torch.from_numpy(amp[f"{tag}/dx"]), "dx32": torch.from_numpy(fx["s0/dx"]), "after16": sub(f"{tag}/after/")}
+    r["d_out"] = rel_err(r["out16"], r["out32"])
+    r["d_grads"] = grads_rel_l2(g16, g32)
+    r["d_dx"] = rel_err(r["dx16"], r["dx32"])
+    return r
+
+
 def free_port():
     """A TCP port that is free right now on 127.0.0.1 (rendezvous of the multi-process tests)."""
     import socket

@@ -3,7 +3,9 @@
 largest batch the oracle finishes in well under a minute — plus the split16 path against the independent
 fp32-MFMA kernel family on random geometries.  Observed errors go to the parity log (tests/helpers.report).
 
-    cfg2  3->1 ch, S=2, fbc=21, batch 64     -> N=8  vs fp32 + fp64 oracle
+    cfg2  3->1 ch, S=2, fbc=21, batch 64     -> N=8  vs fp32 + fp64 oracle; N=64 (the config's batch): properties + a
+                                                4-image slice of the eval forward vs the oracle
+    cfg3  ... batch 32                       -> the eval forward of all 32 images vs the oracle
     cfg3  2->1 ch, S=2, fbc=30, batch 32     -> N=16 vs fp32 + fp64 oracle (pins the N-dependent weight-gradient
                                                 split schedule: at N=16 the layers use the same kernels and
                                                 split counts > 1 as at N=32)
@@ -67,6 +69,71 @@ def test_cfg2_full_resolution_batch8_vs_oracle():
     e_out, worst = _oracle_vs_hip(O.NetConfig(3, 2, 2, 21), N=8, H=256, W=256, seed=22, with_mask=True)
     report(f"cfg2 256x256 N=8 [split16]: out err {e_out:.2e}; worst grad tensor {worst}")
     assert e_out < TOL
+
+
+def _full_batch_properties(cfg, N, seed, slice_rows):
+    """A BASELINE configuration at ITS batch, through size-independent properties plus an oracle comparison that stays
+    cheap: (1) a training step is bit-reproducible and finite; (2) loss == mean over pixels / images of the Laplace NLL
+    of the returned predictions and scales (first step: loss-buffer weights are exactly 1); (3) eval mode is equivariant
+    under a permutation of the batch; (4) eval-mode outputs of `slice_rows` against the fp32 oracle (eval-mode BatchNorm
+    makes images independent, so the slice is the oracle's answer for those rows of the full batch)."""
+    S = cfg.num_subnetworks
+    st = O.init_state(cfg, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in st:  # running statistics a trained checkpoint would hold
+        if k.endswith("running_mean"):
+            st[k] = 0.1 * torch.randn(st[k].shape, generator=g)
+        if k.endswith("running_var"):
+            st[k] = 0.5 + torch.rand(st[k].shape, generator=g)
+    model = build_model(cfg, st)
+    image = torch.rand(N, cfg.in_channels, 256, 256, generator=g)
+    label = torch.rand(N, 1, 256, 256, generator=g)
+    perms = O.draw_perms(N, S, generator=g)
+    model.train()
+    outs = []
+    for _ in range(2):
+        model.load_state_dict({"model." + k: v for k, v in st.items()})
+        model.loss_buffer.buffer.zero_()
+        model.loss_buffer.index = 0
+        model.zero_grad()
+        o = model.training_step_with_perms(image.cuda(), label.cuda(), None, perms.cuda())
+        o["loss"].backward()
+        outs.append((o["loss"].item(), o["preds"].clone(), model.model.flat_gradients().clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.isfinite(outs[0][2]).all() and torch.isfinite(outs[0][1]).all()
+    mu, std, lab = o["preds"].double(), o["aleatoric_std_map"].double(), o["label"].double()
+    scale = (std / 2 ** 0.5).clamp(1e-5, 1e3)  # LaplaceNLL.std = exp(log_scale) * sqrt(2)  (losses.py:166-167)
+    nll = float((scale.log() + (mu - lab).abs() / scale).mean())
+    e_nll = abs(outs[0][0] - nll) / abs(nll)
+    model.load_state_dict({"model." + k: v for k, v in st.items()})
+    model.eval()
+    with torch.no_grad():
+        x5 = torch.stack([image[perms[s]] for s in range(S)], 1)
+        a1, a2 = model(x5.cuda())
+        pi = torch.randperm(N, generator=torch.Generator().manual_seed(1))
+        b1, b2 = model(x5[pi].cuda())
+        ref = O.mimo_unet_forward(cfg, st, x5[slice_rows], training=False)
+    e_perm = max(rel_err(b1.cpu(), a1.cpu()[pi]), rel_err(b2.cpu(), a2.cpu()[pi]))
+    e_slice = rel_err(torch.cat([a1, a2], dim=2).cpu()[slice_rows], ref)
+    return outs[0][0], e_nll, e_perm, e_slice
+
+
+def test_cfg2_at_its_batch_of_64():
+    """BASELINE config 2 (NYUv2 shape: 3 -> 1 ch, S = 2, fbc = 21) at ITS batch, 64 images of 256 x 256 — the dispatch
+    (wide-kernel rule, weight-gradient split counts, fbc = 21 padding paths) depends on the batch."""
+    loss, e_nll, e_perm, e_slice = _full_batch_properties(O.NetConfig(3, 2, 2, 21), N=64, seed=41, slice_rows=[0, 21, 42, 63])
+    report(f"cfg2 256x256 N=64 [split16]: loss {loss:.6f} bit-reproducible; loss vs mean NLL of the returned maps {e_nll:.1e}; "
+           f"eval batch-permutation equivariance {e_perm:.1e}; eval rows 0/21/42/63 vs fp32 oracle {e_slice:.2e}")
+    assert e_nll < 1e-5 and e_perm < 1e-5 and e_slice < TOL
+
+
+def test_cfg3_at_its_batch_of_32_eval_forward_vs_oracle():
+    """BASELINE config 3 at ITS batch (32 x 256 x 256): properties, and the eval forward of all 32 images against the
+    fp32 oracle (no fp64 backward: ~20 s of host time)."""
+    loss, e_nll, e_perm, e_slice = _full_batch_properties(O.NetConfig(2, 2, 2, 30), N=32, seed=43, slice_rows=list(range(32)))
+    report(f"cfg3 256x256 N=32 [split16]: loss {loss:.6f} bit-reproducible; loss vs mean NLL of the returned maps {e_nll:.1e}; "
+           f"eval batch-permutation equivariance {e_perm:.1e}; eval forward of all 32 images vs fp32 oracle {e_slice:.2e}")
+    assert e_nll < 1e-5 and e_perm < 1e-5 and e_slice < TOL
 
 
 def test_cfg4_geometry_split16_vs_oracle():

@@ -3,16 +3,21 @@
 their gradients live in HBM as bf16 / fp16, convolution operands are that type, fp32 accumulation, fp32 master
 weights / BatchNorm statistics / logits / loss / optimiser, loss scaling through torch's GradScaler protocol.
 
-No reference fixture pins these modes (the reference's autocast arithmetic lives in cuDNN); parity is stated against
-(a) the oracle with the engine's rounding points inserted (`O.conv_operands("bf16-mixed" | "16-mixed")`, eval forward)
-and (b) the fp32 goldens / fp32 oracle at mixed-precision tolerance.  Tolerances below = about 5x the values observed
-on the box (profiles/r02/parity_errors.txt)."""
+Pinned to the reference (round 4): tests/golden/amp_*.npz hold a training step of the imported reference under
+torch.autocast (bf16 and fp16; make_golden.py::amp_fixture), the oracle under the same context reproduces them bit for bit
+(tests/test_oracle_golden.py), and the tolerances of the HIP modes are stated in units of the reference's OWN precision
+loss in that mode — d = |autocast reference - fp32 reference|, read from the fixtures.  The two runs round at different
+points (the engine rounds less: DESIGN 4), so they are two independent noise realisations around the fp32 result: a HIP
+mode must sit about as close to fp32 as the reference's own mode does (<= 1.25 d; observed 0.55-1.11 d) and within 1.5 d
+of the autocast reference (two independent vectors of length d are sqrt(2) d apart; observed 0.97-1.38 d; training-mode
+BatchNorm on these tiny networks amplifies single rounding-boundary flips, hence the spread).  The older checks remain: (a) the oracle with the engine's
+rounding points inserted (`O.conv_operands`), (b) the fp32 goldens / fp32 oracle at mixed-precision tolerance."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import mimo_oracle as O
-from tests.helpers import cfg_from_meta, load_npz, rel_err, report, state_from
+from tests.helpers import AMP_CASES, amp_reference, cfg_from_meta, grads_rel_l2, load_npz, rel_err, report, state_from
 from tests.test_network_gpu import build_model, is_prebn_bias
 
 pytestmark = pytest.mark.gpu
@@ -70,6 +75,82 @@ def test_storage_modes_on_the_reference_goldens(name, mode):
     assert t32 < 3e-1 and cos > (0.8 if mode == "bf16-mixed" else 0.95) and 0.85 < ratio < 1.15
     np.testing.assert_allclose(out["loss"].item(), fx["s0/total"], rtol=5e-2, atol=5e-3)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("amp_name,src", AMP_CASES)
+def test_storage_modes_against_the_reference_under_autocast(amp_name, src, mode):
+    """The HIP 16-bit storage modes against the REFERENCE run under torch.autocast (tests/golden/amp_*.npz: Lightning's
+    precision="16-mixed", scripts/train/train_ndvi.py:71, and its bf16 twin), same parameters, inputs, shuffles and loss
+    scale.  d_* = the reference's own distance between its autocast and its fp32 result on that quantity (fixtures)."""
+    r = amp_reference(amp_name, src, mode)
+    cfg, fx = r["cfg"], r["fx"]
+    S, N, half = cfg.num_subnetworks, r["image"].shape[0], cfg.out_channels // 2
+    model = build_model(cfg, state_from(fx, "init/"), T=float(fx["temperature"]), precision=mode)
+    model.train()
+    out = model.training_step_with_perms(r["image"].cuda(), r["label"].cuda(), None if r["mask"] is None else r["mask"].cuda(),
+                                         r["perms"].cuda())
+    (out["loss"] * r["scale"]).backward()
+    hip = {k[len("model."):]: p.grad.detach().cpu() / r["scale"] for k, p in model.named_parameters()}
+    preds = out["preds"].view(N, S, half, *r["image"].shape[-2:]).cpu()
+    e_out16, e_out32 = rel_err(preds, r["out16"][:, :, :half]), rel_err(preds, r["out32"][:, :, :half])
+    d_out = rel_err(r["out16"][:, :, :half], r["out32"][:, :, :half])
+    e_g16, e_g32 = grads_rel_l2(hip, r["grads16"]), grads_rel_l2(hip, r["grads32"])
+    e_loss = abs(out["loss"].item() - r["total16"]) / abs(r["total16"])
+    # eval mode with the initial running statistics (no batch statistics to amplify a rounding)
+    model2 = build_model(cfg, state_from(fx, "init/"), precision=mode)
+    model2.eval()
+    x = torch.stack([r["image"][r["perms"][s]] for s in range(S)], dim=1)
+    with torch.no_grad():
+        q1, q2 = model2(x.cuda())
+        o32 = O.mimo_unet_forward(cfg, state_from(fx, "init/"), x, training=False)
+    q = torch.cat([q1, q2], dim=2).cpu()
+    d_eval, e_ev16, e_ev32 = rel_err(r["eval16"], o32), rel_err(q, r["eval16"]), rel_err(q, o32)
+    report(f"{mode} {amp_name} vs the reference under autocast: train out {e_out16:.2e} (d {d_out:.2e}; vs fp32 ref {e_out32:.2e}); "
+           f"gradient rel-L2 {e_g16:.2e} (d {r['d_grads']:.2e}; vs fp32 ref {e_g32:.2e}); loss {e_loss:.2e}; "
+           f"eval out {e_ev16:.2e} (d {d_eval:.2e}; vs fp32 oracle {e_ev32:.2e})")
+    assert e_out32 <= 1.25 * d_out and e_g32 <= 1.25 * r["d_grads"]    # about as close to fp32 as the reference's own mode
+    assert e_out16 <= 1.5 * d_out and e_g16 <= 1.5 * r["d_grads"]      # two independent roundings: ~sqrt(2) d apart
+    assert e_loss < 5e-3
+    assert e_ev32 <= 0.5 * d_eval and e_ev16 <= 1.25 * d_eval
+
+
+@pytest.mark.parametrize("mode,H", [("bf16-mixed", 256), ("16-mixed", 128)])
+def test_storage_modes_against_the_autocast_oracle_at_cfg3_widths(mode, H):
+    """cfg3's widths (2 -> 1 ch, S = 2, fbc = 30: 120 ... 960-channel core) against the oracle run under the reference's
+    autocast context (`O.reference_autocast`, pinned bit for bit to tests/golden/amp_*.npz) on this box's host — the
+    reference-precision counterpart of the per-tensor emulation test below.  256 x 256 for bf16; 128 x 128 for fp16,
+    whose CPU convolutions are ~40 x slower.  Bounds in units of d = autocast oracle vs fp32 oracle, as above."""
+    cfg = O.NetConfig(2, 2, 2, 30)
+    N, S = 2, 2
+    g = torch.Generator().manual_seed(33)
+    st = O.init_state(cfg, 33)
+    image, label = torch.rand(N, 2, H, H, generator=g), torch.rand(N, 1, H, H, generator=g)
+    perms = O.draw_perms(N, S, generator=g)
+    scale = 1024.0 if mode == "16-mixed" else 1.0
+    lb_w = torch.tensor([0.8, 1.2])
+    model = build_model(cfg, st, precision=mode)
+    model.train()
+    model.loss_buffer.get_weights = lambda: lb_w
+    out = model.training_step_with_perms(image.cuda(), label.cuda(), None, perms.cuda())
+    (out["loss"] * scale).backward()
+    hip = {k[len("model."):]: p.grad.detach().cpu() / scale for k, p in model.named_parameters()}
+
+    def oracle(autocast):
+        ts = O.TrainState(cfg=cfg, st={k: v.clone() for k, v in st.items()}, loss_buffer=O.LossBuffer(S, 0.3, 10))
+        ts.loss_buffer.get_weights = lambda: lb_w
+        return O.train_step(ts, image, label, None, perms, apply_optimizer=False, loss_scale=scale, autocast=autocast)
+
+    a16, f32 = oracle(mode), oracle(None)
+    preds = out["preds"].view(N, S, 1, H, H).cpu()
+    d_out = rel_err(a16["out"][:, :, :1].float(), f32["out"][:, :, :1])
+    e_out16, e_out32 = rel_err(preds, a16["out"][:, :, :1].float()), rel_err(preds, f32["out"][:, :, :1])
+    d_g = grads_rel_l2(a16["grads"], f32["grads"])
+    e_g16, e_g32 = grads_rel_l2(hip, a16["grads"]), grads_rel_l2(hip, f32["grads"])
+    report(f"{mode} cfg3 widths {H}x{H} N=2 vs the autocast oracle: train out {e_out16:.2e} (d {d_out:.2e}; vs fp32 {e_out32:.2e}); "
+           f"gradient rel-L2 {e_g16:.2e} (d {d_g:.2e}; vs fp32 {e_g32:.2e})")
+    assert e_out32 <= 1.25 * d_out and e_g32 <= 1.25 * d_g
+    assert e_out16 <= 1.5 * d_out and e_g16 <= 1.5 * d_g
 
 
 def test_cfg4_geometry_bf16_mixed_vs_oracle_and_memory():

@@ -261,6 +261,7 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, prec
     e_buf = max(rel_err(sd["model." + k].cpu(), v) for k, v in ts32.st.items() if "running" in k)
     grads = {k[len("model."):]: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
     worst, dot, nh, nr, nd = ("", 0.0, 0.0), 0.0, 0.0, 0.0, 0.0
+    n_tensors = arm_all = need_all = 0
     # The yardstick is what fp32 arithmetic itself does on this problem (fp32 oracle against the fp64 oracle): per tensor,
     # and over all tensors — training-mode BatchNorm over a small batch amplifies rounding into every gradient at once,
     # and WHICH tensor the fp32 oracle happens to get right depends on its thread count (reduction order)
@@ -274,14 +275,19 @@ def _oracle_vs_hip(cfg, N, H, W, seed, loss="laplace_nll", with_mask=False, prec
         eo = float((ref["grads"][k].double() - g64).norm() / g64.norm())
         if eh > worst[1]:
             worst = (k, eh, eo)
-        assert eh <= (5e-3 if small_net else 1e-3) + 5.0 * max(eo, eo_all), (k, eh, eo, eo_all)
+        floor = 5e-3 if small_net else 1e-3
+        assert eh <= floor + 5.0 * max(eo, eo_all), (k, eh, eo, eo_all)
+        n_tensors += 1
+        arm_all += eo_all > eo               # the whole-gradient arm is the larger of the two for this tensor
+        need_all += eh > floor + 5.0 * eo    # ... and the tensor would NOT have passed on its own fp32-oracle error
         dot += float((grads[k] * g64).sum())
         nh += float((grads[k] ** 2).sum())
         nr += float((g64 ** 2).sum())
         nd += float(((grads[k] - g64) ** 2).sum())
     cos, rel_l2 = dot / (nh * nr) ** 0.5, (nd / nr) ** 0.5
     report(f"[{precision}] out {e_out:.2e} loss {e_loss:.2e} bn-buffers {e_buf:.2e}; grads vs fp64: cos {cos:.7f} rel-L2 {rel_l2:.2e}; "
-          f"worst tensor {worst[0]} hip {worst[1]:.2e} (fp32 oracle {worst[2]:.2e}; fp32 oracle over all tensors {eo_all:.2e})")
+          f"worst tensor {worst[0]} hip {worst[1]:.2e} (fp32 oracle {worst[2]:.2e}; fp32 oracle over all tensors {eo_all:.2e}); "
+          f"bound arms: eo_all > eo on {arm_all} of {n_tensors} tensors, {need_all} needed it to pass")
     assert e_out < TOL and e_loss < TOL and e_buf < TOL
     assert cos > (0.9995 if small_net else 0.9999) and rel_l2 < (3e-2 if small_net else 2e-2)
     return e_out, worst
