@@ -67,6 +67,16 @@ enum mimo_precision {
 
 enum mimo_loss_kind { MIMO_LOSS_LAPLACE_NLL = 0, MIMO_LOSS_GAUSSIAN_NLL = 1 };
 
+/* Block variants: the reference's blocks are BatchNorm2d + ReLU (components.py:22-30) and bilinear
+ * align_corners up-sampling (components.py:77-85; its ConvTranspose2d branch, components.py:95-104, is unreachable from
+ * the LightningModule: mimo_unet.py:73-74 hard-wire bilinear=True).  Those are the values 0 — the only ones implemented
+ * and the only ones that can be parity-checked against the reference; mimo_plan_create rejects any other value with
+ * MIMO_ERR_INVALID.  The fields exist so that a GroupNorm / SiLU / transposed-convolution variant (BASELINE.json's
+ * north_star wording) is a new enum value, not an ABI change. */
+enum mimo_norm_kind { MIMO_NORM_BATCH = 0 };
+enum mimo_act_kind { MIMO_ACT_RELU = 0 };
+enum mimo_up_kind { MIMO_UP_BILINEAR_ALIGN_CORNERS = 0 };
+
 /* Constructor arguments of mimo.models.mimo_components.model.MimoUNet (model.py:31-44) plus
  * the batch geometry the plan is specialised for.  bilinear=True/use_pooling_indices=False are
  * hard-wired exactly as mimo/models/mimo_unet.py:73-74 hard-wires them. */
@@ -87,6 +97,7 @@ typedef struct mimo_config {
                               * training = 0 and no_grad = 1.  What torch.no_grad() + eval() means for memory. */
   float center_dropout_rate, final_dropout_rate; /* element-wise nn.Dropout (model.py:213, :277-281): the rates the
                               * in-engine generator uses for those sites (mimo_forward_args.rng_sites) */
+  int32_t norm_kind, act_kind, up_kind; /* mimo_norm_kind / mimo_act_kind / mimo_up_kind: 0 = the reference's blocks */
 } mimo_config;
 
 const char* mimo_last_error(void);

@@ -30,6 +30,7 @@ class MimoConfig(C.Structure):
         ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("loss_kind", C.c_int32),
         ("eps_min", C.c_float), ("eps_max", C.c_float), ("device", C.c_int32), ("precision", C.c_int32),
         ("inference_only", C.c_int32), ("center_dropout_rate", C.c_float), ("final_dropout_rate", C.c_float),
+        ("norm_kind", C.c_int32), ("act_kind", C.c_int32), ("up_kind", C.c_int32),
     ]
 
 

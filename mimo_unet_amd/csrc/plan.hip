@@ -518,6 +518,11 @@ struct mimo_plan {
       set_error("unknown precision %d", cfg.precision);
       return MIMO_ERR_INVALID;
     }
+    if (cfg.norm_kind != MIMO_NORM_BATCH || cfg.act_kind != MIMO_ACT_RELU || cfg.up_kind != MIMO_UP_BILINEAR_ALIGN_CORNERS) {
+      set_error("block variant norm %d / act %d / up %d is not implemented: only BatchNorm2d + ReLU + bilinear align_corners "
+                "up-sampling, the reference's blocks (components.py:22-30, 77-85)", cfg.norm_kind, cfg.act_kind, cfg.up_kind);
+      return MIMO_ERR_INVALID;
+    }
     S = cfg.num_subnetworks;
     f = cfg.filter_base_count;
     N = cfg.batch;

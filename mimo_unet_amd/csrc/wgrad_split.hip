@@ -342,7 +342,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   constexpr int kWsTR = TR_, kWsAPix = (kWsTR + 2) * kWgTCP, kWsDPix = kWsTR * kWgTC;
   constexpr int PA = X16 ? wg_pitch16(CI) : wg_pitch(CI), PD = D16 ? wg_pitch16(CO) : wg_pitch(CO);
   constexpr int QA = X16 ? CI / 8 : CI / 4, QD = D16 ? CO / 8 : CO / 4;  // 16-byte units per pixel
+#ifdef MIMO_WGRAD_ABLATE
+  // timing-only builds (results are wrong): 1 = the producers stage only the first half of the activation halo tile (what
+  // a row ring that shares halo rows between vertically adjacent tiles would stage per tile); 2 = none of it; 4 = no dz
+  constexpr int XA = (MIMO_WGRAD_ABLATE & 2) ? 1 : (MIMO_WGRAD_ABLATE & 1) ? (kWsAPix * QA / 2 + 255) / 256 : (kWsAPix * QA + 255) / 256;
+  constexpr int XD = (MIMO_WGRAD_ABLATE & 4) ? 1 : (kWsDPix * QD + 255) / 256;
+#else
   constexpr int XA = (kWsAPix * QA + 255) / 256, XD = (kWsDPix * QD + 255) / 256;  // per producer thread
+#endif
   constexpr int ABYTES = kWsAPix * PA, DBYTES = kWsDPix * PD, BUFBYTES = ABYTES + DBYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFBYTES];
 

@@ -56,7 +56,8 @@ class Plan:
             geom.in_channels, geom.out_channels, geom.num_subnetworks, geom.filter_base_count, batch, height, width,
             geom.encoder_dropout_rate, geom.core_dropout_rate, geom.decoder_dropout_rate,
             1e-5, 0.1, L.LOSS_KINDS[geom.loss], 1e-5, 1e3, device.index or 0, L.PRECISIONS[geom.precision],
-            int(bool(inference_only)), geom.center_dropout_rate, geom.final_dropout_rate)
+            int(bool(inference_only)), geom.center_dropout_rate, geom.final_dropout_rate,
+            0, 0, 0)  # BatchNorm2d + ReLU + bilinear up-sampling: the reference's blocks (the only variants that exist)
         self.inference_only = bool(inference_only)
         handle = C.c_void_p()
         with torch.cuda.device(device):

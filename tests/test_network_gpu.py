@@ -482,6 +482,29 @@ def test_staged_backward_equals_monolithic_and_hook_ranges():
     assert torch.allclose(total, 2 * grads[0], rtol=1e-5, atol=1e-8)
 
 
+def test_plan_create_rejects_block_variants_the_reference_does_not_have():
+    """mimo_config.norm_kind / act_kind / up_kind: 0 = BatchNorm2d + ReLU + bilinear align_corners, the reference's
+    blocks and the only implemented ones; anything else is MIMO_ERR_INVALID with a message, not silently BatchNorm."""
+    import ctypes as C
+    from mimo_unet_amd import _lib as L
+    lib = L.load()
+
+    def create(**kw):
+        cfg = L.MimoConfig(2, 2, 1, 4, 1, 32, 32, 0.0, 0.0, 0.0, 1e-5, 0.1, 0, 1e-5, 1e3, 0, 1, 0, 0.0, 0.0, 0, 0, 0)
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.mimo_plan_create(C.byref(cfg), C.byref(h))
+        if rc == 0:
+            lib.mimo_plan_destroy(h)
+        return rc, lib.mimo_last_error().decode()
+
+    assert create()[0] == 0
+    for field in ("norm_kind", "act_kind", "up_kind"):
+        rc, msg = create(**{field: 1})
+        assert rc == -1 and "not implemented" in msg, (field, rc, msg)
+
+
 def test_training_forward_always_uses_the_current_parameters():
     """Every training forward repacks the convolution weights from the flat parameter buffer, so a parameter write torch
     cannot see (`p.data.mul_()`, a raw-pointer writer) between `optimizer.step()` and the next training forward takes
