@@ -25,6 +25,13 @@
 
 #include "common.h"
 
+#ifndef MIMO_WGRAD_PIN_PROLOGUE
+// 1: pin the prologue's LDS reads into a scheduling group of their own, which puts the consumers' fragment reads really
+// one tap ahead of their MFMAs in the ISA.  Measured SLOWER (round 4, profiles/r04/wgrad_read_pipeline.txt: +3.5 % per
+// layer, wgrad class 6.16-6.29 -> 6.29-6.41 ms in four alternating step pairs): off.
+#define MIMO_WGRAD_PIN_PROLOGUE 0
+#endif
+
 namespace mimo {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -549,6 +556,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     WS_READ_B(0, 0)                                                                  \
     _Pragma("unroll") for (int s_ = 0; s_ < kDepth; ++s_)                            \
       WS_READ_A1(s_ % (kDepth + 1), s_ / (NT), (T0) + s_ % (NT))                     \
+    /* Without this pin the FIRST in-loop group (the reads of step kDepth) takes the prologue's reads and every later \
+       group moves one step down: in the ISA the fragments of a tap are read right in front of its MFMAs.  With it   \
+       they are read one tap ahead, as the source says — and the kernel is 3.5 % slower (see the switch's comment). */ \
+    if (MIMO_WGRAD_PIN_PROLOGUE) __builtin_amdgcn_sched_group_barrier(0x100, kRB + kDepth * kRA, 0); \
     _Pragma("unroll") for (int s_ = 0; s_ < kSteps; ++s_) {                          \
       const int r_ = s_ / (NT), tt = s_ % (NT);                                      \
       const bool rb_ = tt == 0 && r_ + 1 < kWsTR, ra_ = s_ + kDepth < kSteps;        \
