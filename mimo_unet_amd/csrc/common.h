@@ -75,7 +75,15 @@ struct ConvLaunch {
   // != 0: a.wpk holds the wide kernel's image — [16-channel chunk][tap][wide rows][hi 16 | lo 16] — and the launch runs
   // on conv_wide.hip (value = packed rows, conv3x3_wide_rows)
   int wide = 0;
+  // != nullptr (split16 forward on the wave-specialised kernels only, conv3x3_split_fuses_input): x is the PRE-activation
+  // tensor z of the producing convolution and the loaders apply its BatchNorm + ReLU on the way into LDS — relu(z *
+  // in_scale[c] + in_shift[c]), bn_relu_fwd_kernel's arithmetic (components.py:24-25 between the two convolutions of a
+  // DoubleConv) — so that the activated tensor is never written to HBM
+  const float* in_scale = nullptr;
+  const float* in_shift = nullptr;
 };
+// 1 when conv3x3_bf16x3_launch(mode) runs this launch on a kernel whose loaders can apply ConvLaunch::in_scale / in_shift
+int conv3x3_split_fuses_input(int mode, int wide, int Ho, int Wo);
 // returns number of partial-stat rows (spatial blocks) through *rows when stats != nullptr
 int conv3x3_launch(const ConvLaunch& a, int* rows, hipStream_t stream);
 // split 16-bit variant (conv_bf16x3.hip): same ConvLaunch, reads a.wpk instead of a.w.
@@ -119,8 +127,15 @@ struct WgradLaunch {
   // split kernels, operand storage: 0 = activations fp32 + dz pre-split bf16 pair records; 1 / 2 = activations and dz
   // plain NHWC bf16 / fp16 (ldx, lddz in elements); 3 / 4 = activations fp32 (the packed image) + dz plain bf16 / fp16
   int store = 0;
+  // != nullptr (split16 wave-specialised kernel only, wgrad_split_fuses_input): x is the PRE-activation tensor z of the
+  // producing convolution and the loader applies its BatchNorm + ReLU on the way in — a = relu(z * in_scale[c] +
+  // in_shift[c]), the arithmetic of bn_relu_fwd_kernel — so that the activated tensor is never materialised
+  const float* in_scale = nullptr;
+  const float* in_shift = nullptr;
 };
 int wgrad_launch(const WgradLaunch& a, hipStream_t stream);
+// 1 when wgrad_split_launch runs this geometry on a kernel that can apply WgradLaunch::in_scale / in_shift in its loader
+int wgrad_split_fuses_input(int cin_p, int cout_p, int store, int np);
 // split-bf16 variant (wgrad_split.hip): cin_pad / cout_pad must be multiples of its (CI, CO) tile
 void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO);
 int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO, int store = 0);  // store: WgradLaunch::store

@@ -407,13 +407,20 @@ constexpr int kWsMaxMF = 4;
 // vmcnt that leaves their own (younger) input-tile loads in flight, then pass a raw s_barrier.  A DMA instruction
 // writes 64 x 16 contiguous bytes, so the weight rows are unpadded 128-byte rows with the slot index XORed by
 // (row & 7) (conflict-free ds_read_b128, as SWZ); the XOR is applied to the per-lane SOURCE address.
-template <int NF, int MODE, int MF_, bool PAIR = false, bool WDMA = true>
+//
+// FIN (split16 forward, grad-enabled path; round 4): the input is the producing convolution's pre-activation tensor and the
+// producers apply its BatchNorm + ReLU (ConvLaunch::in_scale / in_shift: relu(fma(z, scale, shift)), bn_relu_fwd_kernel's
+// arithmetic) in front of the fp16 split, so the activated tensor between the two convolutions of a DoubleConv
+// (components.py:24-25) is never written.  A thread's units all hold one channel quad of a chunk; its constants are loaded
+// one stage ahead, in front of that phase's weight DMA and input loads (the counted vmcnt waits stay valid).
+template <int NF, int MODE, int MF_, bool PAIR = false, bool WDMA = true, bool FIN = false>
 __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws_kernel(ConvLaunch a, int TR, int TC,
                                                                                           int tilesY, int tilesX,
                                                                                           int numTiles, int xcd_order,
                                                                                           int gx, int coTiles) {
   MIMO_CONV_MODE_CONSTANTS
   static_assert(!PAIR || (NP == 3 && !IN16), "tap pairing: split16 modes");
+  static_assert(!FIN || (MODE == 1 && WDMA), "fused input BatchNorm + ReLU: the split16 forward, weights by DMA");
   typedef typename Elem<F16>::T ET;
   typedef typename Elem<F16>::V8 bf16x8;
   typedef typename Elem<F16>::V4 bf16x4;
@@ -487,6 +494,15 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
       u_off[k] = ((tr * a.Wi + tc) * a.ldx + 4 * ((ptid + k * 256) & 7)) * 4;  // pre-split input only
     }
     const u32x4* wpk = reinterpret_cast<const u32x4*>(a.wpk);
+    // FIN: BatchNorm scale / shift of the thread's channel quad, of the stage being stored (in_sc / in_sh) and of the stage
+    // being loaded (in_sc_n / in_sh_n); channels past cin_p come from the zero page: relu(0 * 0 + 0) keeps them zero
+    f32x4 in_sc = f32x4{0.f, 0.f, 0.f, 0.f}, in_sh = in_sc, in_sc_n = in_sc, in_sh_n = in_sc;
+#define WS_LOAD_SS(SC, SH, STAGE)                                                                    \
+  if (FIN) {                                                                                         \
+    const int c_ = ((STAGE) % nchunks) * 32 + 4 * (ptid & 7);                                        \
+    SC = *reinterpret_cast<const f32x4*>(c_ < a.cin_p ? a.in_scale + c_ : kZeroPage);                \
+    SH = *reinterpret_cast<const f32x4*>(c_ < a.cin_p ? a.in_shift + c_ : kZeroPage);                \
+  }
     // stage j = (tile j / nchunks, chunk j % nchunks)
 #define WS_LOAD_X(K0, K1, STAGE)                                                                     \
   {                                                                                                  \
@@ -547,7 +563,13 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     const int u_ = ptid + k_ * 256;                                                                  \
     const int p_ = u_ >> UPPS, q_ = u_ & (UPP - 1);                                                  \
     if (p_ < npix_lds) {                                                                             \
-      const f32x4 v_ = xreg[k_];                                                                     \
+      f32x4 v_ = xreg[k_];                                                                           \
+      if (FIN) {                                                                                     \
+        v_[0] = fmaxf(fmaf(v_[0], in_sc[0], in_sh[0]), 0.f);                                         \
+        v_[1] = fmaxf(fmaf(v_[1], in_sc[1], in_sh[1]), 0.f);                                         \
+        v_[2] = fmaxf(fmaf(v_[2], in_sc[2], in_sh[2]), 0.f);                                         \
+        v_[3] = fmaxf(fmaf(v_[3], in_sc[3], in_sh[3]), 0.f);                                         \
+      }                                                                                              \
       unsigned char* row_ = xs + (BUF) * XBYTES + p_ * PITCH;                                        \
       const int sx_ = 0;                                                                             \
       if (CVT) {                                                                                     \
@@ -623,6 +645,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #define WS_DMA_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 #endif
     const int nphases = 3 * nstages;
+    WS_LOAD_SS(in_sc, in_sh, 0)
     WS_LOAD_X(0, XU, 0)  // nstages >= 1: the grid never exceeds the tile count
     if (WDMA) {
       WS_DMA_W(0, 0)
@@ -635,6 +658,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     if (!WDMA) {
       WS_STORE_W(0, 0)
     }
+    WS_LOAD_SS(in_sc_n, in_sh_n, min(1, nstages - 1))
     WS_LOAD_X(0, XU, min(1, nstages - 1))
     if (WDMA) {
       WS_DMA_WAIT(XU)
@@ -645,6 +669,10 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     // consumers released at the last barrier; then refill those registers two / three phases ahead
     for (int j = 0; j < nstages; ++j) {
       const int xb = (j + 1) & 1;
+      if (FIN) { /* the constants of stage j + 1: loaded one stage ago, older than every load still in flight */
+        in_sc = in_sc_n;
+        in_sh = in_sh_n;
+      }
 #define WS_PHASE(R)                                                                                  \
   {                                                                                                  \
     /* no conditionals: past the end the loads re-read the last stage / phase and the stores go to   \
@@ -652,6 +680,9 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
        (a conditional load forces a full drain at the join and collapses the prefetch depth) */      \
     const int ph_ = 3 * j + (R);                                                                     \
     if (WDMA) {                                                                                      \
+      if ((R) == 0) {                                                                                \
+        WS_LOAD_SS(in_sc_n, in_sh_n, min(j + 2, nstages - 1)) /* in front of this phase's DMA and input loads */ \
+      }                                                                                              \
       if (!(abl & 2)) {                                                                              \
         WS_STORE_X((R) * XP, ((R) + 1) * XP, xb)                                                     \
       }                                                                                              \
@@ -677,6 +708,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
       WS_PHASE(2)
 #undef WS_PHASE
     }
+#undef WS_LOAD_SS
 #undef WS_LOAD_X
 #undef WS_STORE_X
 #undef WS_LOAD_W
@@ -1004,6 +1036,23 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   // MIMO_CONV_WDMA=0: weights staged through registers (ds_write) as before
   static const bool wdma = !(getenv("MIMO_CONV_WDMA") && atoi(getenv("MIMO_CONV_WDMA")) == 0);
   const int xcd = xcd_;
+  if (a.in_scale) {
+    if constexpr (MODE == 1) {
+      if (!wdma || a.ep_scale || !a.in_shift || (a.pair && a.pair != conv3x3_pair_tail(MODE, a.cin_p, a.Ho, a.Wo))) {
+        set_error("conv3x3 split: the input BatchNorm + ReLU can be fused into the split16 training forward (weights by DMA) only");
+        return MIMO_ERR_INVALID;
+      }
+      if (a.pair)
+        hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, MF, true, true, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
+      else
+        hipLaunchKernelGGL((conv3x3_ws_kernel<NF, MODE, MF, false, true, true>), grid, dim3(512), 0, stream, a, TR, TC, tilesY, tilesX, numTiles, xcd, gx, coTiles);
+      MIMO_KERNEL_CHECK();
+      return MIMO_OK;
+    } else {
+      set_error("conv3x3 split: the input BatchNorm + ReLU can be fused into the split16 forward only");
+      return MIMO_ERR_INVALID;
+    }
+  }
   if (a.pair) {
     if constexpr (MODE <= 1) {
       if (a.pair != conv3x3_pair_tail(MODE, a.cin_p, a.Ho, a.Wo)) {
@@ -1038,8 +1087,19 @@ static int launch_bf16x3(const ConvLaunch& a, int* rows, hipStream_t stream) {
 // MF = 4 (512-pixel tiles) when the image is large enough to fill them, else 2.
 static bool use_big_tile(int Ho, int Wo) { return Ho * Wo >= 1024; }
 
+// 1 when the launch runs on a kernel whose loaders can apply ConvLaunch::in_scale / in_shift (the wide kernel and the
+// 256-pixel wave-specialised kernel, split16 forward)
+int conv3x3_split_fuses_input(int mode, int wide, int Ho, int Wo) {
+  static const bool wdma = !(getenv("MIMO_CONV_WDMA") && atoi(getenv("MIMO_CONV_WDMA")) == 0);
+  return mode == 1 && (wide != 0 || (conv_ws_enabled() && wdma && Ho * Wo >= 256)) ? 1 : 0;
+}
+
 template <int MODE>
 static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t stream) {
+  if (a.in_scale && !conv3x3_split_fuses_input(MODE, 0, a.Ho, a.Wo)) {
+    set_error("conv3x3 split: this launch cannot apply the input BatchNorm + ReLU in its loader (conv3x3_split_fuses_input)");
+    return MIMO_ERR_INVALID;
+  }
   const int nfr = a.cout_pad / 16;
   int nf = 4;
   while (nfr % nf != 0) --nf;

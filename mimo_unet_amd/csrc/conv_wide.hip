@@ -77,10 +77,15 @@ constexpr int kXBytes = kMaxPix * kXPitch;  // 51200
 // NF: 32-channel tiles per workgroup; TPP: taps per phase (3 = one tap row, 9 = a whole chunk)
 // EPI (forward): the inference epilogue — eval-mode BatchNorm + ReLU (+ Dropout2d multipliers) folded into the store, no
 // statistics; else bias + BatchNorm partial sums
-template <int NF, int MODE, int TPP, bool EPI>
+// FIN (split16 forward, training / grad-enabled path): the input is the producing convolution's pre-activation tensor and the
+// producers apply its BatchNorm + ReLU (ConvLaunch::in_scale / in_shift) in front of the fp16 split.  A thread's units all
+// hold the same channel quad of a chunk (256 threads step over whole pixels), so a stage costs two 16-byte loads of constants
+// per thread — issued one stage ahead, in front of that phase's weight DMA and input loads, so that the counted waits stay valid.
+template <int NF, int MODE, int TPP, bool EPI, bool FIN = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int TR, int TC, int tilesY, int tilesX,
                                                                 int numTiles, int gx, int coTiles) {
   static_assert(MODE == 0 || MODE == 1 || (MODE >= 4 && MODE <= 7), "split16 and 16-bit storage modes");
+  static_assert(!FIN || (MODE == 1 && !EPI), "fused input BatchNorm + ReLU: the split16 forward with statistics");
   static_assert((NF == 2 && TPP == 3) || (NF == 1 && TPP == 9), "instances: 64 channels x tap rows, 32 channels x chunks");
   constexpr bool FWD = MODE == 1 || MODE == 4 || MODE == 6;
   constexpr bool S16 = MODE >= 4;                 // 16-bit storage: plain 16-bit input and output, one MFMA per product
@@ -191,6 +196,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     const char* l_img = nullptr;  // image base of the load tile
     int l_y0 = 0, l_x0 = 0;
     bool l_new = true;            // the stage is the first of its tile: unit offsets are recomputed part by part
+    // FIN: BatchNorm scale / shift of the thread's channel quad — of the stage being stored (in_sc / in_sh) and of the stage
+    // being loaded (in_sc_n / in_sh_n); channels past cin_p come from the zero page: relu(0 * 0 + 0) keeps them zero
+    f32x4 in_sc = f32x4{0.f, 0.f, 0.f, 0.f}, in_sh = in_sc, in_sc_n = in_sc, in_sh_n = in_sc;
+#define WD_LOAD_SS(SC, SH, CK)                                                                       \
+  if (FIN) {                                                                                         \
+    const int c_ = (CK) * CKC + 4 * uq;                                                              \
+    SC = *reinterpret_cast<const f32x4*>(c_ < a.cin_p ? a.in_scale + c_ : kZeroPage);                \
+    SH = *reinterpret_cast<const f32x4*>(c_ < a.cin_p ? a.in_shift + c_ : kZeroPage);                \
+  }
 #define WD_TILE(TI)                                                                                  \
   {                                                                                                  \
     int t_ = vbx + (TI) * gx;                                                                        \
@@ -278,7 +292,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
        un-waited on that path, and hipcc then drains the whole queue (vmcnt(0)) before it reuses the register —   \
        every phase, which collapsed the prefetch depth to zero (found in the ISA) */                              \
     {                                                                                                \
-      const f32x4 v_ = xreg[k_];                                                                     \
+      f32x4 v_ = xreg[k_];                                                                           \
+      if (FIN) {                                                                                     \
+        v_[0] = fmaxf(fmaf(v_[0], in_sc[0], in_sh[0]), 0.f);                                         \
+        v_[1] = fmaxf(fmaf(v_[1], in_sc[1], in_sh[1]), 0.f);                                         \
+        v_[2] = fmaxf(fmaf(v_[2], in_sc[2], in_sh[2]), 0.f);                                         \
+        v_[3] = fmaxf(fmaf(v_[3], in_sc[3], in_sh[3]), 0.f);                                         \
+      }                                                                                              \
       unsigned char* row_ = xs + (BUF) * kXBytes + p_ * kXPitch;                                     \
       if (CVT) {                                                                                     \
         f16x4_t hi_, lo_;                                                                            \
@@ -328,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
 
     // ---- prologue: stage 0 in input buffer 0, weights of phase 0 (and 1) on their way; input of stage 1 in registers
     WD_TILE(0)
+    WD_LOAD_SS(in_sc, in_sh, 0)
     WD_LOAD_X(0, XU)
     WD_DMA_W(0)
     if (NWB == 3) {
@@ -335,6 +356,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     }
     WD_STORE_X(0, XU, 0)
     WD_NEXT_STAGE()
+    WD_LOAD_SS(in_sc_n, in_sh_n, l_ck)
     WD_LOAD_X(0, XU)
     // Every load of the prologue is waited for HERE, visibly to the compiler: the loop's first consumer of a register
     // is otherwise waited for with the count that is safe on the path from the prologue too — vmcnt(0) if that
@@ -348,15 +370,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     int wslot = NWB == 3 ? 2 : 1;  // buffer of the next DMA = (ph + NWB - 1) % NWB
     for (int j = 0; j < nstages; ++j) {
       const int xb = (j + 1) & 1;
+      if (FIN) { /* the constants of stage j + 1 (loaded one stage ago, older than every load still in flight) */
+        in_sc = in_sc_n;
+        in_sh = in_sh_n;
+      }
       WD_NEXT_STAGE()  // the load stream: stage j + 2
 #define WD_PHASE(R)                                                                                  \
   {                                                                                                  \
+    if ((R) == 0) {                                                                                  \
+      WD_LOAD_SS(in_sc_n, in_sh_n, l_ck) /* in front of this phase's DMA and input loads */          \
+    }                                                                                                \
     WD_STORE_X(XK0(R), XK0((R) + 1), xb)                                                             \
     WD_DMA_W(wslot)                                                                                  \
     wslot = wslot + 1 == NWB ? 0 : wslot + 1;                                                        \
     WD_LOAD_X(XK0(R), XK0((R) + 1))                                                                  \
-    /* three buffers: the weights of phase ph + 1 were issued one phase ago, in front of that phase's input loads */ \
-    WD_WAIT_BAR(NWB == 3 ? XKN(((R) + 2) % 3) + WU + XKN(R) : XKN(R))                                \
+    /* three buffers: the weights of phase ph + 1 were issued one phase ago, in front of that phase's input loads     \
+       (FIN, phase 0: the two loads of constants sit between them and this phase's DMA) */                            \
+    WD_WAIT_BAR(NWB == 3 ? XKN(((R) + 2) % 3) + WU + XKN(R) + ((FIN && (R) == 0) ? 2 : 0) : XKN(R))  \
   }
       WD_PHASE(0)
       if (PARTS == 3) {
@@ -365,6 +395,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       }
 #undef WD_PHASE
     }
+#undef WD_LOAD_SS
 #undef WD_TILE
 #undef WD_OFFS
 #undef WD_NEXT_STAGE
@@ -675,6 +706,20 @@ int conv3x3_wide_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t st
   if (mode >= 4 && (a.ldx % 8 != 0 || a.cin_p % 8 != 0)) {
     set_error("conv3x3 wide, 16-bit storage: channel counts must be multiples of 8");
     return MIMO_ERR_INVALID;
+  }
+  if (a.in_scale && (mode != 1 || a.ep_scale || !a.in_shift)) {
+    set_error("conv3x3 wide: the input BatchNorm + ReLU can be fused into the split16 training forward only");
+    return MIMO_ERR_INVALID;
+  }
+  if (a.in_scale) {
+    if (c.nf == 2)
+      hipLaunchKernelGGL((conv3x3_wide_kernel<2, 1, 3, false, true>), grid, dim3(512), 0, stream, a, c.TR, c.TC, tilesY, tilesX,
+                         numTiles, gx, coTiles);
+    else
+      hipLaunchKernelGGL((conv3x3_wide_kernel<1, 1, 9, false, true>), grid, dim3(512), 0, stream, a, c.TR, c.TC, tilesY, tilesX,
+                         numTiles, gx, coTiles);
+    MIMO_KERNEL_CHECK();
+    return MIMO_OK;
   }
 #define WIDE_FWD(MODE_)            \
   if (a.ep_scale) {                \

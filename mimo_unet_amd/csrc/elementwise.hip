@@ -1026,10 +1026,10 @@ __global__ void up_bwd_kernel(const T* __restrict__ dxpad, int ldp, int choff, T
       cx[k] = min(max(ox, 0), 2 * w - 1) + padL;
     }
     float4 v = f4zero();
-    if (cy[0] >= 2 && cy[3] <= H - 3 && cx[0] >= 2 && cx[3] <= W - 3) {
-      // none of the 16 candidates receives a reflected border: 16 independent loads, weights 0 where the
-      // candidate does not read this input (adds an exact zero, same sum as skipping it)
-      const T* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + choff + 4 * t.q;
+    const T* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + choff + 4 * t.q;
+    // the 16 candidates themselves (padded-domain pixel of image pixel (y, x) = (y + 1, x + 1)): 16 independent loads,
+    // weights 0 where the candidate does not read this input (adds an exact zero, same sum as skipping it)
+    {
       float4 g[4][4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -1045,17 +1045,51 @@ __global__ void up_bwd_kernel(const T* __restrict__ dxpad, int ldp, int choff, T
           v.z += ww * g[k][j].z;
           v.w += ww * g[k][j].w;
         }
-    } else {
+    }
+    if (!(cy[0] >= 2 && cy[3] <= H - 3 && cx[0] >= 2 && cx[3] <= W - 3)) {
+      // Near the border some candidates also receive a reflected pad row / column (transpose of the reflect padding: pad
+      // row -1 folds onto row 1, pad row H onto row H - 2; columns alike).  Folding is linear, so instead of folding every
+      // candidate (up to 4 dependent loads each, 16 times, in divergent loops: the whole launch waited for these threads —
+      // 94 us at 4 images per GPU where the data moves in 15) the pad rows / columns enter as two more rows and columns of
+      // the weighted sum, with the weight of the image row / column they fold onto: at most 20 more independent loads.
+      float ey[2] = {0.f, 0.f}, ex[2] = {0.f, 0.f};  // weight of pad row -1 / H, pad column -1 / W
+#pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (wy[k] == 0.f) continue;
-        for (int j = 0; j < 4; ++j) {
-          if (wx[j] == 0.f) continue;
-          const float4 g = fold_read(dxpad, ldp, n, cy[k], cx[j], H, W, choff + 4 * t.q);
-          const float ww = wy[k] * wx[j];
-          v.x += ww * g.x;
-          v.y += ww * g.y;
-          v.z += ww * g.z;
-          v.w += ww * g.w;
+        ey[0] += cy[k] == 1 ? wy[k] : 0.f;
+        ey[1] += cy[k] == H - 2 ? wy[k] : 0.f;
+        ex[0] += cx[k] == 1 ? wx[k] : 0.f;
+        ex[1] += cx[k] == W - 2 ? wx[k] : 0.f;
+      }
+      const int pry[2] = {0, H + 1}, prx[2] = {0, W + 1};  // padded-domain indices of the pad rows / columns
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (ey[e] != 0.f) {  // pad row e against the four candidate columns and the two pad columns
+          float4 g[6];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] = ld4(base + ((size_t)pry[e] * (W + 2) + (cx[j] + 1)) * ldp);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) g[4 + j] = ld4(base + ((size_t)pry[e] * (W + 2) + prx[j]) * ldp);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const float ww = ey[e] * (j < 4 ? wx[j] : ex[j - 4]);
+            v.x += ww * g[j].x;
+            v.y += ww * g[j].y;
+            v.z += ww * g[j].z;
+            v.w += ww * g[j].w;
+          }
+        }
+        if (ex[e] != 0.f) {  // pad column e against the four candidate rows
+          float4 g[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g[k] = ld4(base + ((size_t)(cy[k] + 1) * (W + 2) + prx[e]) * ldp);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float ww = wy[k] * ex[e];
+            v.x += ww * g[k].x;
+            v.y += ww * g[k].y;
+            v.z += ww * g[k].z;
+            v.w += ww * g[k].w;
+          }
         }
       }
     }

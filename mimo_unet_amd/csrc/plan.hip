@@ -81,6 +81,13 @@ struct ConvBN {
   int ld_a = 0;
   float* pool_out = nullptr;  // the MaxPool2d(2) of `a` is written by the BatchNorm + ReLU pass (training forward)
   int pool_ld = 0;
+  // Second convolution of a DoubleConv whose loaders apply the first one's BatchNorm + ReLU themselves (round 4): forward and
+  // weight gradient read the first convolution's pre-activation tensor `in_z` with its scale / shift, and the activated
+  // tensor between the two convolutions (components.py:24-25) is never written.  `act_elided` marks that first convolution.
+  bool fuse_in = false, act_elided = false;
+  const float* in_z = nullptr;
+  int ld_in_z = 0;
+  const float *in_scale = nullptr, *in_shift = nullptr;
 };
 
 enum InputKind { IN_IMAGE = 0, IN_POOL = 1, IN_UPCAT = 2 };
@@ -464,6 +471,22 @@ struct mimo_plan {
     dc->c1.ld_a = dc->c1.cout_p;
     dc->c2.in = dc->mid;
     dc->c2.ld_in = dc->c1.cout_p;
+    {
+      // BatchNorm + ReLU of the first convolution applied by the second one's loaders: split16, when BOTH readers of the
+      // activated tensor — the second convolution's forward and its weight gradient — run on kernels that can (the
+      // wide / 256-pixel wave-specialised forward, the wave-specialised weight gradient).  MIMO_FUSE_BN_IN=0: materialise.
+      const bool on = !(getenv("MIMO_FUSE_BN_IN") && atoi(getenv("MIMO_FUSE_BN_IN")) == 0);  // read per plan (A/B, tests)
+      ConvBN& c2 = dc->c2;
+      if (on && cfg.precision == MIMO_PREC_SPLIT16 && !cfg.inference_only && c2.fwd_split && c2.wg_split && dc->c1.dtz == ST_F32 &&
+          conv3x3_split_fuses_input(fwd_mode(), c2.fwd_wide, h, w) && wgrad_split_fuses_input(c2.cin_p, c2.cout_p, 0, 3)) {
+        c2.fuse_in = true;
+        c2.in_z = dc->c1.z;
+        c2.ld_in_z = dc->c1.cout_p;
+        c2.in_scale = dc->c1.scale;
+        c2.in_shift = dc->c1.shift;
+        dc->c1.act_elided = true;
+      }
+    }
     dc->c2.a = o.a;
     dc->c2.ld_a = o.ld;
     *outp = dc.get();
@@ -784,8 +807,16 @@ struct mimo_plan {
     if (!training && need_derive)
       MIMO_TRY(bn_eval_prepare_launch(L.Cout, L.cout_p, params + L.off_gamma, params + L.off_beta, bnbuf + L.off_rm,
                                       bnbuf + L.off_rv, cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
+    // Training forward only.  (A forward without a graph folds BatchNorm + ReLU into every convolution's epilogue, and an
+    // eval-mode forward WITH a graph — FGSM — keeps the separate pass, whose finiteness test feeds the numerics status word:
+    // the activated tensors exist in both.  The weight gradient applies scale / shift to z either way: identical values.)
+    const bool fin = L.fuse_in && training && !fwd_no_grad;
     ConvLaunch a;
-    a.x = L.in;
+    a.x = fin ? L.in_z : L.in;
+    if (fin) {
+      a.in_scale = L.in_scale;
+      a.in_shift = L.in_shift;
+    }
     a.y = fused ? L.a : L.z;  // fused: the activation type; else z (fp32 on the fp32 kernel family)
     if (fused) {
       a.ep_scale = L.scale;
@@ -800,7 +831,7 @@ struct mimo_plan {
     a.N = L.N;
     a.Hi = a.Ho = L.H;
     a.Wi = a.Wo = L.W;
-    a.ldx = L.ld_in;
+    a.ldx = fin ? L.ld_in_z : L.ld_in;
     a.cin_p = L.cin_p;
     a.ldy = fused ? L.ld_a : L.cout_p;
     a.cout_pad = L.cout_pad;
@@ -830,7 +861,7 @@ struct mimo_plan {
                                         cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
       }
     }
-    if (!fused) {
+    if (!fused && !(L.act_elided && training)) {
       pr = prof_begin(MIMO_PROF_BN_RELU_FWD, st);
       if (L.pool_out)
         MIMO_TRY(bn_relu_pool_fwd_launch(L.z, L.dtz, L.cout_p, L.a, this->st, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, L.N,
@@ -1138,13 +1169,17 @@ struct mimo_plan {
       ws = wg_stream;
     }
     WgradLaunch wg;
-    wg.x = L.in;
+    wg.x = L.fuse_in ? L.in_z : L.in;
+    if (L.fuse_in) {
+      wg.in_scale = L.in_scale;
+      wg.in_shift = L.in_shift;
+    }
     wg.dz = dz_wg;
     wg.partial = s_wslab;
     wg.N = L.N;
     wg.H = L.H;
     wg.W = L.W;
-    wg.ldx = L.ld_in;
+    wg.ldx = L.fuse_in ? L.ld_in_z : L.ld_in;
     wg.lddz = L.cout_p;
     wg.cin_p = L.cin_p;
     wg.cout_p = L.cout_p;

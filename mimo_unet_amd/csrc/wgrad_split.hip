@@ -334,9 +334,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int 
 static bool wgrad_s16(int om) { return om == 1 || om == 2; }
 static int wgrad_ws_tr(int CI, int om) { return sched::wg_ws_tr(CI, wgrad_s16(om)); }
 
-template <int NP, int NI, int CI_, int TR_, int OM>
+// FIN (split16 only): the activation operand is the producing convolution's PRE-activation tensor and the producers apply
+// its BatchNorm + ReLU (WgradLaunch::in_scale / in_shift) in front of the bf16 split: relu(fma(z, scale, shift)), exactly
+// bn_relu_fwd_kernel's arithmetic, so the activated tensor need not exist in HBM.  A lane's units all hold the same
+// channel quad (256 threads step over whole pixels), so the eight constants are loaded once per thread.
+template <int NP, int NI, int CI_, int TR_, int OM, bool FIN = false>
 __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
   static_assert(OM == 0 || NP == 1, "16-bit storage: one MFMA per product");
+  static_assert(!FIN || (OM == 0 && NP == 3), "fused input BatchNorm + ReLU: split16 only");
   constexpr bool X16 = OM == 1 || OM == 2, D16 = OM >= 1;  // operand storage, see wg_mfma above
   // consumer wave = 16 ci x CO co (MI = 1, NI = CO/16 = 2, 3 or 4): an A fragment (re-read for every tap)
   // feeds 3*NI MFMAs; at NI = 4, 52 instead of 80 transposed LDS reads per 108 MFMAs of a 32x32 arrangement.
@@ -383,13 +388,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
 #pragma unroll
     for (int k = 0; k < XA; ++k) {
       const int u = ptid + k * 256;
-      const int uc = min(u, kWsAPix * QA - 1);
+      // units past the tile (XA rounds up) repeat the thread's OWN previous unit: same lane, same channel quad
+      static_assert(256 % QA == 0 && kWsAPix * QA >= 256, "a thread's units share one channel quad");
+      const int uc = u < kWsAPix * QA ? u : u - 256;
       const int pix = uc / QA, qq = uc - pix * QA;
       a_tr[k] = pix / kWgTCP - 1;
       a_tc[k] = pix % kWgTCP - 1;
       constexpr int kChU = X16 ? 8 : 4;  // channels per unit; its hi-plane bytes = 2 * kChU
       a_ch[k] = ci0 + kChU * qq < a.cin_p ? ci0 + kChU * qq : -1;
-      // units past the tile (XA rounds up) repeat the LAST unit — same source (uc), same destination, same bytes: every
+      // units past the tile repeat an earlier unit — same source (uc), same destination, same bytes: every
       // store below is unconditional.  A store skipped by a branch leaves its load un-waited on that path and hipcc then
       // drains the whole queue (vmcnt(0)) before the registers are reused, which cut the prefetch from two tiles to one
       // (found in the ISA in round 3, as in conv_wide.hip).
@@ -407,6 +414,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
                     ? (D16 ? ch : (ch >> 5) * 64 + half * rc + (ch & 31))  // plain NHWC / pair records, in 16-bit units
                     : -1;
       d_dst[k] = ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + half * 2 * CO + c8 * 16;
+    }
+    f32x4 in_sc = f32x4{0.f, 0.f, 0.f, 0.f}, in_sh = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (FIN && a_ch[0] >= 0) {  // (channels past cin_p are loaded from the zero page and must stay zero: relu(0 * 0 + 0))
+      in_sc = *reinterpret_cast<const f32x4*>(a.in_scale + a_ch[0]);
+      in_sh = *reinterpret_cast<const f32x4*>(a.in_shift + a_ch[0]);
     }
     const int H2 = 2 * a.H - 2, W2 = 2 * a.W - 2;
 #define WS_LOAD(XA_, XD_, TILE)                                                                     \
@@ -452,8 +464,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     } else {                                                                                        \
       bf16x4 hi_, lo_;                                                                              \
       _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                            \
-        hi_[e_] = (__bf16)(V)[e_];                                                                  \
-        lo_[e_] = (__bf16)((V)[e_] - (float)hi_[e_]);                                               \
+        const float v_ = FIN ? fmaxf(fmaf((V)[e_], in_sc[e_], in_sh[e_]), 0.f) : (V)[e_];           \
+        hi_[e_] = (__bf16)v_;                                                                       \
+        lo_[e_] = (__bf16)(v_ - (float)hi_[e_]);                                                    \
       }                                                                                             \
       *reinterpret_cast<bf16x4*>(DST) = hi_;                                                        \
       if (NP == 3) *reinterpret_cast<bf16x4*>((DST) + 2 * (CCH)) = lo_;                             \
@@ -627,6 +640,12 @@ int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int 
   return sched::wg_pick_splits(N, H, W, cin_pad, cout_pad, CI, CO, wgrad_ws_enabled(), mode, wgrad_s16(store));
 }
 
+int wgrad_split_fuses_input(int cin_p, int cout_p, int store, int np) {
+  int CI, CO;
+  wgrad_split_tiles(cin_p, cout_p, &CI, &CO);
+  return wgrad_use_ws(CI, CO) && store == 0 && np == 3 ? 1 : 0;
+}
+
 int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
   int CI, CO;
   wgrad_split_tiles(a.cin_p, a.cout_p, &CI, &CO);
@@ -635,6 +654,10 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
     return MIMO_ERR_INVALID;
   }
   const bool ws = wgrad_use_ws(CI, CO);
+  if (a.in_scale && !(ws && a.store == 0 && a.np == 3 && a.in_shift)) {
+    set_error("wgrad_split: this geometry cannot apply the input BatchNorm + ReLU in its loader (wgrad_split_fuses_input)");
+    return MIMO_ERR_INVALID;
+  }
   const int tilesY = ceil_div(a.H, ws ? wgrad_ws_tr(CI, a.store) : kWgTR), tilesX = ceil_div(a.W, kWgTC);
   const int numTiles = a.N * tilesY * tilesX;
   dim3 grid((a.cin_pad / CI) * (a.cout_pad / CO), a.splits);
@@ -646,8 +669,15 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
   }
   if (ws) {
     grid = dim3(grid.x * grid.y);  // 1-D, decoded XCD-aware inside the kernel
-#define WS_LAUNCH3(NP_, NI_, CI_, TR_, OM_) \
-  hipLaunchKernelGGL((wgrad_split_ws_kernel<NP_, NI_, CI_, TR_, OM_>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles)
+#define WS_LAUNCH3(NP_, NI_, CI_, TR_, OM_)                                                                             \
+  if constexpr ((NP_) == 3 && (OM_) == 0) {                                                                             \
+    if (a.in_scale)                                                                                                     \
+      hipLaunchKernelGGL((wgrad_split_ws_kernel<NP_, NI_, CI_, TR_, OM_, true>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \
+    else                                                                                                                \
+      hipLaunchKernelGGL((wgrad_split_ws_kernel<NP_, NI_, CI_, TR_, OM_, false>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \
+  } else {                                                                                                              \
+    hipLaunchKernelGGL((wgrad_split_ws_kernel<NP_, NI_, CI_, TR_, OM_, false>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \
+  }
 #define WS_LAUNCH2(NI_, CI_, TR_)                \
   switch (om) {                                  \
     case 1: WS_LAUNCH3(1, NI_, CI_, 4, 1); break; /* both operands 16-bit: 4-row tiles */ \

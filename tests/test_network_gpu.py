@@ -482,6 +482,52 @@ def test_staged_backward_equals_monolithic_and_hook_ranges():
     assert torch.allclose(total, 2 * grads[0], rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("geom", [(2, 2, 2, 30, 2, 256, 256), (3, 2, 2, 21, 3, 96, 80), (2, 2, 1, 12, 2, 64, 64)],
+                         ids=lambda g: "-".join(map(str, g)))
+def test_bn_relu_in_the_second_convolutions_loaders_is_bit_identical(geom, monkeypatch):
+    """Round 4: in split16 the BatchNorm + ReLU between the two convolutions of a DoubleConv (components.py:24-25) is applied
+    by the second convolution's loaders (forward: wide / 256-pixel kernels; weight gradient: wave-specialised kernel), and
+    the activated tensor is never written.  Same arithmetic (relu(fma(z, scale, shift)) in fp32, then the 16-bit split) as
+    the separate pass: predictions, loss, every gradient and the BatchNorm buffers are BIT-identical to MIMO_FUSE_BN_IN=0
+    (cfg3 widths at 256 x 256: wide-kernel layers; cfg2 widths at an odd size: pairing tails and 32-channel weight-gradient
+    tiles; a small net whose deep layers fall below 256 pixels and stay unfused)."""
+    Ci, Co, S, f, N, H, W = geom
+    cfg = O.NetConfig(Ci, Co, S, f)
+    st = O.init_state(cfg, 77)
+    g = torch.Generator().manual_seed(78)
+    for k in st:  # non-trivial BatchNorm affine parameters (negative scales too)
+        if (".double_conv.1." in k or ".double_conv.4." in k) and k.endswith("weight"):
+            st[k] = torch.randn(st[k].shape, generator=g)
+        if (".double_conv.1." in k or ".double_conv.4." in k) and k.endswith(".bias"):
+            st[k] = 0.3 * torch.randn(st[k].shape, generator=g)
+    image, label = torch.rand(N, Ci, H, W, generator=g).cuda(), torch.rand(N, 1, H, W, generator=g).cuda()
+    perms = O.draw_perms(N, S, generator=g).cuda()
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MIMO_FUSE_BN_IN", flag)
+        m = build_model(cfg, st)
+        m.train()
+        outs = []
+        for _ in range(2):  # two steps: the second one runs on updated running statistics / reused buffers
+            m.zero_grad()
+            o = m.training_step_with_perms(image, label, None, perms)
+            o["loss"].backward()
+            outs.append((o["loss"].detach().clone(), o["preds"].clone(), m.model.flat_gradients().clone()))
+        m.eval()  # eval mode with a graph (FGSM): the separate pass stays, the weight gradient still reads z
+        x5 = torch.stack([image[perms[s]] for s in range(S)], 1).requires_grad_(True)
+        p1, p2 = m(x5)
+        m.zero_grad()
+        (p1.mean() + p2.mean()).backward()
+        outs.append((p1.detach().clone(), x5.grad.clone(), m.model.flat_gradients().clone()))
+        res.append((outs, {k: v.clone() for k, v in m.state_dict().items()}))
+    (a, sa), (b, sb) = res
+    for ta, tb in zip(a, b):
+        for x, y in zip(ta, tb):
+            assert torch.equal(x, y)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 def test_plan_create_rejects_block_variants_the_reference_does_not_have():
     """mimo_config.norm_kind / act_kind / up_kind: 0 = BatchNorm2d + ReLU + bilinear align_corners, the reference's
     blocks and the only implemented ones; anything else is MIMO_ERR_INVALID with a message, not silently BatchNorm."""
