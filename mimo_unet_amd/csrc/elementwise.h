@@ -68,8 +68,9 @@ int bn_relu_pool_fwd_launch(const void* z, int dtz, int ldz, void* a, int dta, i
 int maxpool_fwd_launch(const void* a, int dt, int lda, int N, int H, int W, int Cp, void* out, int ldo, hipStream_t st);
 // out[N,H,W,csp+clp] = cat(skip, zero_pad(bilinear_x2_align_corners(low))); skip == nullptr: channels [0, csp) of
 // out already hold the skip tensor (its producer writes it in place), only the up-sampled part is written
+// lo_scale / lo_shift != nullptr: `low` is the producing convolution's pre-activation tensor, its BatchNorm + ReLU is applied here
 int upcat_fwd_launch(const void* skip, int dt, int lds, int csp, const void* low, int ldl, int clp, int N, int H, int W,
-                     int h, int w, void* out, hipStream_t st);
+                     int h, int w, void* out, hipStream_t st, const float* lo_scale = nullptr, const float* lo_shift = nullptr);
 
 // ---- backward gathers.  "dxpad" = gradient on the reflect-padded domain [N,H+2,W+2,ldp]
 // produced by the dgrad convolution; fold = transpose of reflect padding. ------------------
@@ -131,8 +132,11 @@ int vec_finalize_launch(const double* sums, int chunks, int cols, int C, float* 
 // ---- 1x1 head + loss ------------------------------------------------------------------------
 // out[n][s][co][yx] = bias[co] + sum_c a[n,yx,c] * w[co][c]      (components.py:126)
 // status != nullptr: kStatusLogits is OR-ed into it when a logit is not finite
+// in_scale / in_shift != nullptr (head_fwd / head_bwd): `a` is the pre-activation tensor of the decoder's last convolution and
+// its BatchNorm + ReLU is applied on the way in (relu(fma(z, scale, shift)): bn_relu_fwd_kernel's arithmetic)
 int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float* bias, int C, int Co, int N, int S, int s,
-                    int HW, float* out, hipStream_t st, int* status = nullptr);
+                    int HW, float* out, hipStream_t st, int* status = nullptr, const float* in_scale = nullptr,
+                    const float* in_shift = nullptr);
 // per-subnetwork sum of the un-reduced NLL (losses.py:151-160) -> partial [S][blocks]
 int loss_fwd_launch(const float* out, const float* label, const float* mask, const int64_t* perm, int N, int S,
                     int Co, int HW, int kind, float eps_min, float eps_max, float* partial, int* blocks,
@@ -142,7 +146,7 @@ int loss_finalize_launch(const float* partial, int S, int blocks, double count, 
 int head_bwd_launch(const void* a, int dt, int lda, const float* w, int C, int Cp, int Co, int N, int S, int s, int HW,
                     const float* out, const float* dout, const float* dloss, const float* label, const float* mask,
                     const int64_t* perm, int kind, float eps_min, float eps_max, void* da, float* partial,
-                    int* rows, hipStream_t st);
+                    int* rows, hipStream_t st, const float* in_scale = nullptr, const float* in_shift = nullptr);
 int head_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int Co, float* dw, float* db,
                              hipStream_t st);
 

@@ -706,10 +706,19 @@ __device__ __forceinline__ float lerp_weight(int o, int i, int in) {
   return (l.i0 == i ? l.l0 : 0.f) + (l.i1 == i ? l.l1 : 0.f);
 }
 
+// lo_scale != nullptr: `low` is the pre-activation tensor of the producing convolution and its BatchNorm + ReLU is applied to
+// the four sources of every output pixel here (relu(fma(z, scale, shift)), bn_relu_fwd_kernel's arithmetic, then the same
+// interpolation): the activated low-resolution tensor is never written (round 4)
+__device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
+  return make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f), fmaxf(fmaf(v.z, sc.z, sh.z), 0.f),
+                     fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+}
+
 template <typename T>
 __global__ void upcat_fwd_kernel(const T* __restrict__ skip, int lds, int csv, const T* __restrict__ low,
                                  int ldl, int clv, int N, int H, int W, int h, int w, int padT, int padL,
-                                 T* __restrict__ out) {
+                                 T* __restrict__ out, const float* __restrict__ lo_scale,
+                                 const float* __restrict__ lo_shift) {
   const int Cv = csv + clv;
   // skip == nullptr: the skip tensor already lives in channels [0, 4*csv) of `out` (its producer writes it
   // there); only the up-sampled part is written, and the threads are mapped over those channels alone
@@ -718,6 +727,11 @@ __global__ void upcat_fwd_kernel(const T* __restrict__ skip, int lds, int csv, c
   if (!skip) t.q += csv;
   const int ldo = 4 * Cv;
   const int P = N * H * W;
+  float4 lsc = f4zero(), lsh = f4zero();
+  if (lo_scale && t.q >= csv) {
+    lsc = ld4(lo_scale + 4 * (t.q - csv));
+    lsh = ld4(lo_shift + 4 * (t.q - csv));
+  }
   PixIter it = pix_iter(t.p, t.pstep, H, W);
   for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
     float4 v;
@@ -730,8 +744,14 @@ __global__ void upcat_fwd_kernel(const T* __restrict__ skip, int lds, int csv, c
       if (uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w) {
         const Lerp ly = lerp_src(uy, h, 2 * h), lx = lerp_src(ux, w, 2 * w);
         const T* b = low + (size_t)n * h * w * ldl + 4 * (t.q - csv);
-        const float4 v00 = ld4(b + ((size_t)ly.i0 * w + lx.i0) * ldl), v01 = ld4(b + ((size_t)ly.i0 * w + lx.i1) * ldl);
-        const float4 v10 = ld4(b + ((size_t)ly.i1 * w + lx.i0) * ldl), v11 = ld4(b + ((size_t)ly.i1 * w + lx.i1) * ldl);
+        float4 v00 = ld4(b + ((size_t)ly.i0 * w + lx.i0) * ldl), v01 = ld4(b + ((size_t)ly.i0 * w + lx.i1) * ldl);
+        float4 v10 = ld4(b + ((size_t)ly.i1 * w + lx.i0) * ldl), v11 = ld4(b + ((size_t)ly.i1 * w + lx.i1) * ldl);
+        if (lo_scale) {
+          v00 = bn_relu4(v00, lsc, lsh);
+          v01 = bn_relu4(v01, lsc, lsh);
+          v10 = bn_relu4(v10, lsc, lsh);
+          v11 = bn_relu4(v11, lsc, lsh);
+        }
         v.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
         v.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
         v.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
@@ -743,7 +763,7 @@ __global__ void upcat_fwd_kernel(const T* __restrict__ skip, int lds, int csv, c
 }
 
 int upcat_fwd_launch(const void* skip, int dt, int lds, int csp, const void* low, int ldl, int clp, int N, int H, int W,
-                     int h, int w, void* out, hipStream_t st) {
+                     int h, int w, void* out, hipStream_t st, const float* lo_scale, const float* lo_shift) {
   const int Cv = (csp + clp) / 4;
   const int padT = (H - 2 * h) / 2, padL = (W - 2 * w) / 2;  // F.pad(diff//2, diff - diff//2), components.py:110-115
   if (H < 2 * h || W < 2 * w) {
@@ -752,7 +772,7 @@ int upcat_fwd_launch(const void* skip, int dt, int lds, int csp, const void* low
   }
   MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(upcat_fwd_kernel<T>, pq_grid(skip ? Cv : clp / 4, (int64_t)N * H * W, 4096), dim3(256), 0,
                                              st, (const T*)skip, lds, csp / 4, (const T*)low, ldl, clp / 4, N, H, W, h, w, padT, padL,
-                                             (T*)out));
+                                             (T*)out, lo_scale, lo_shift));
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1343,7 +1363,9 @@ int bn_bwd_apply_launch(const void* da, int dta, int ldda, const void* dxpad, in
 template <int G, int CO, typename T>
 __global__ void head_fwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
                                 const float* __restrict__ bias, int C, int Cp, int Co, int N, int S, int s, int HW,
-                                float* __restrict__ out, int* __restrict__ status) {
+                                float* __restrict__ out, int* __restrict__ status, const float* __restrict__ in_scale,
+                                const float* __restrict__ in_shift) {
+  // in_scale != nullptr: `a` is the pre-activation tensor of the decoder's last convolution, its BatchNorm + ReLU is applied here
   // CO = compile-time bound of Co (2: one target, 4: the evidential head, 8: the rest); UN pixels per thread and
   // iteration, their loads issued together (one 16-byte load in flight per thread ran at 3.4 TB/s)
   const int g = threadIdx.x % G, pl = threadIdx.x / G;
@@ -1356,6 +1378,8 @@ __global__ void head_fwd_kernel(const T* __restrict__ a, int lda, const float* _
     for (int j = 0; j < 4; ++j) wq[co][j] = (co < Co && 4 * g + j < C) ? w[co * C + 4 * g + j] : 0.f;
   }
   const bool has = 4 * g < Cp;
+  const bool fin = in_scale != nullptr;
+  const float4 isc = (fin && has) ? ld4(in_scale + 4 * g) : f4zero(), ish = (fin && has) ? ld4(in_shift + 4 * g) : f4zero();
   const int64_t P = (int64_t)N * HW, stride = (int64_t)gridDim.x * PPB;
   for (int64_t p0 = (int64_t)blockIdx.x * PPB + pl; p0 < P; p0 += stride * UN) {
     float4 v[UN];
@@ -1363,6 +1387,7 @@ __global__ void head_fwd_kernel(const T* __restrict__ a, int lda, const float* _
     for (int u = 0; u < UN; ++u) {
       const int64_t p = p0 + u * stride;
       v[u] = (has && p < P) ? ld4(a + p * lda + 4 * g) : f4zero();
+      if (fin) v[u] = bn_relu4(v[u], isc, ish);  // (lanes without channels: relu(0 * 0 + 0) = 0)
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -1391,7 +1416,7 @@ __global__ void head_fwd_kernel(const T* __restrict__ a, int lda, const float* _
 }
 
 int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float* bias, int C, int Co, int N, int S, int s,
-                    int HW, float* out, hipStream_t st, int* status) {
+                    int HW, float* out, hipStream_t st, int* status, const float* in_scale, const float* in_shift) {
   if (Co > kMaxHeadOut || C > 256) {
     set_error("head: out_channels %d > %d or filter_base_count %d > 256 unsupported", Co, kMaxHeadOut, C);
     return MIMO_ERR_INVALID;
@@ -1403,7 +1428,7 @@ int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float*
   const int blocks = (int)std::min<int64_t>(ceil_div64(P, (256 / G) * 4), 4096);
 #define HEAD_LAUNCH2(GG, CC)                                                                                         \
   MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL((head_fwd_kernel<GG, CC, T>), dim3(blocks), dim3(256), 0, st, (const T*)a, lda, w, bias, \
-                                             C, Cp, Co, N, S, s, HW, out, status))
+                                             C, Cp, Co, N, S, s, HW, out, status, in_scale, in_shift))
 #define HEAD_LAUNCH(GG)             \
   if (Co <= 2) {                    \
     HEAD_LAUNCH2(GG, 2);            \
@@ -1515,10 +1540,13 @@ __global__ void head_bwd_kernel(const T* __restrict__ a, int lda, const float* _
                                 const float* __restrict__ dout, const float* __restrict__ dloss,
                                 const float* __restrict__ label, const float* __restrict__ mask,
                                 const int64_t* __restrict__ perm, int kind, float eps_min, float eps_max, float inv_count,
-                                T* __restrict__ da, float* __restrict__ partial) {
+                                T* __restrict__ da, float* __restrict__ partial, const float* __restrict__ in_scale,
+                                const float* __restrict__ in_shift) {
   __shared__ float4 red[256];
   constexpr int UN = 4;
   const PQ t = pixquad(Cv);
+  const bool fin = in_scale != nullptr;
+  const float4 isc = (fin && t.active) ? ld4(in_scale + 4 * t.q) : f4zero(), ish = (fin && t.active) ? ld4(in_shift + 4 * t.q) : f4zero();
   const int Cp = 4 * Cv, Ct = Co / 2;
   float4 wq[CO], dwacc[CO];
   float dbacc[CO];
@@ -1562,6 +1590,7 @@ __global__ void head_bwd_kernel(const T* __restrict__ a, int lda, const float* _
             }
         }
         av[u] = ld4(a + (size_t)p * lda + 4 * t.q);
+        if (fin) av[u] = bn_relu4(av[u], isc, ish);
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
@@ -1619,7 +1648,7 @@ __global__ void head_bwd_kernel(const T* __restrict__ a, int lda, const float* _
 int head_bwd_launch(const void* a, int dt, int lda, const float* w, int C, int Cp, int Co, int N, int S, int s, int HW,
                     const float* out, const float* dout, const float* dloss, const float* label, const float* mask,
                     const int64_t* perm, int kind, float eps_min, float eps_max, void* da, float* partial, int* rows,
-                    hipStream_t st) {
+                    hipStream_t st, const float* in_scale, const float* in_shift) {
   if (Co > kMaxHeadOut || (Co & 1)) {
     set_error("head: out_channels %d unsupported", Co);
     return MIMO_ERR_INVALID;
@@ -1632,7 +1661,7 @@ int head_bwd_launch(const void* a, int dt, int lda, const float* w, int C, int C
 #define HEAD_BWD_LAUNCH(CC)                                                                                              \
   MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL((head_bwd_kernel<CC, T>), grid, dim3(256), 0, st, (const T*)a, lda, w, C, Cv, Co, N, S, s, \
                                              HW, out, dout, dloss, label, mask, perm, kind, eps_min, eps_max, inv_count, (T*)da,  \
-                                             partial))
+                                             partial, in_scale, in_shift))
   if (Co <= 2) {
     HEAD_BWD_LAUNCH(2);
   } else if (Co <= 4) {

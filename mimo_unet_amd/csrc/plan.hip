@@ -57,6 +57,11 @@ struct Act {
   const float* skipgrad = nullptr;
   int skipgrad_ld = 0;
   bool pooled = false;  // some Down block pools this tensor (its pool_bwd then takes the skip gradient along)
+  // != nullptr: in a TRAINING forward `a` is not written — its readers (the bilinear up-sampling into the next block's
+  // concat buffer, the 1x1 head and its backward) take the producing convolution's pre-activation tensor z (pixel pitch
+  // z_ld) and apply scale / shift + ReLU themselves (round 4; Up blocks without dropout in split16)
+  const float *z = nullptr, *z_scale = nullptr, *z_shift = nullptr;
+  int z_ld = 0;
 };
 
 struct ConvBN {
@@ -84,7 +89,7 @@ struct ConvBN {
   // Second convolution of a DoubleConv whose loaders apply the first one's BatchNorm + ReLU themselves (round 4): forward and
   // weight gradient read the first convolution's pre-activation tensor `in_z` with its scale / shift, and the activated
   // tensor between the two convolutions (components.py:24-25) is never written.  `act_elided` marks that first convolution.
-  bool fuse_in = false, act_elided = false;
+  bool fuse_in = false, act_elided = false;  // (act_elided on a second convolution: its readers apply it, see Act::z)
   const float* in_z = nullptr;
   int ld_in_z = 0;
   const float *in_scale = nullptr, *in_shift = nullptr;
@@ -634,6 +639,11 @@ struct mimo_plan {
         rehome_skip(x2cat, up3, pr);
       }
     }
+    // the outputs of the core's Up blocks are read only by the next block's bilinear up-sampling: it applies their
+    // BatchNorm + ReLU itself and the activated tensor is not written in a training forward (elide_output)
+    elide_output(up1);
+    elide_output(up2);
+    elide_output(up3);
     // MaxPool2d inputs are produced by the BatchNorm + ReLU pass of the tensor they pool (one pass less per Down block)
     if (!(getenv("MIMO_POOL_FUSED") && atoi(getenv("MIMO_POOL_FUSED")) == 0)) {
       auto fuse = [this](DoubleConv* producer, DoubleConv* consumer, int choff) {
@@ -655,6 +665,8 @@ struct mimo_plan {
                        cfg.decoder_dropout_rate, nullptr, 0, nullptr, 0));
       MIMO_TRY(set_input(dc, IN_UPCAT, &enc_in[s]->out, &up3->out, (int)m.size(), H1, W1));
       if (skip_alias) rehome_skip(enc_in[s]->out, dc, {{enc_in[s], 0}});
+      // read by the 1x1 head (forward and backward) only; the element-wise final dropout would need the activated tensor
+      if (cfg.final_dropout_rate <= 0.f) elide_output(dc);
       up4.push_back(dc);
     }
     for (int s = 0; s < S; ++s) {
@@ -874,6 +886,21 @@ struct mimo_plan {
     return MIMO_OK;
   }
 
+  // Output activation of an Up block read through BatchNorm + ReLU by its consumers (Act::z): split16 training plans, no
+  // Dropout2d on the block (its multipliers act on the activated tensor), MIMO_FUSE_BN_IN != 0.  The decoders' blocks
+  // additionally need the element-wise final dropout off (checked where they are built).
+  void elide_output(DoubleConv* dc) {
+    const bool on = !(getenv("MIMO_FUSE_BN_IN") && atoi(getenv("MIMO_FUSE_BN_IN")) == 0);
+    if (!on || cfg.precision != MIMO_PREC_SPLIT16 || cfg.inference_only || dc->drop_p > 0.f || dc->c2.pool_out ||
+        dc->c2.dtz != ST_F32)
+      return;
+    dc->c2.act_elided = true;
+    dc->out.z = dc->c2.z;
+    dc->out.z_ld = dc->c2.cout_p;
+    dc->out.z_scale = dc->c2.scale;
+    dc->out.z_shift = dc->c2.shift;
+  }
+
   int dc_forward(DoubleConv* dc, bool training, hipStream_t st) {
     const int h = dc->c1.H, w = dc->c1.W;
     const int blk = prof_begin(kProfTierBase + 2 * tier_of(h), st);
@@ -884,8 +911,10 @@ struct mimo_plan {
     } else if (dc->kind == IN_UPCAT) {
       Act *sk = dc->src0, *lo = dc->src1;
       const int pr = prof_begin(MIMO_PROF_UPCAT_FWD, st);
-      MIMO_TRY(upcat_fwd_launch(dc->skip_in_place ? nullptr : sk->a, this->st, sk->ld, sk->Cp, lo->a, lo->ld, lo->Cp, N, h, w,
-                                lo->H, lo->W, dc->in_buf, st));
+      const bool lz = lo->z && training && !fwd_no_grad;  // the low-resolution tensor through its BatchNorm + ReLU
+      MIMO_TRY(upcat_fwd_launch(dc->skip_in_place ? nullptr : sk->a, this->st, sk->ld, sk->Cp, lz ? lo->z : lo->a,
+                                lz ? lo->z_ld : lo->ld, lo->Cp, N, h, w, lo->H, lo->W, dc->in_buf, st, lz ? lo->z_scale : nullptr,
+                                lz ? lo->z_shift : nullptr));
       // writes the up-sampled channels at (h, w), reads the low-resolution tensor once
       prof_end(pr, 0.0, 4.0 * lo->Cp * ((double)N * h * w + (double)N * lo->H * lo->W), st);
     }
@@ -1062,8 +1091,13 @@ struct mimo_plan {
       }
       const int blk = prof_begin(kProfTierBase, st);
       const int pr = prof_begin(MIMO_PROF_HEAD_FWD, st);
-      MIMO_TRY(head_fwd_launch(o.a, this->st, o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co, N, S, s, H * W,
-                               args->out, st, d_status));
+      const bool oz = o.z && training && !fwd_no_grad;
+      if (o.z && (elem_masks[1 + s] || elem_rng_on[1 + s])) {
+        set_error("mimo_forward: element-wise final dropout on a plan built with final_dropout_rate = 0");
+        return MIMO_ERR_INVALID;
+      }
+      MIMO_TRY(head_fwd_launch(oz ? o.z : o.a, this->st, oz ? o.z_ld : o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co,
+                               N, S, s, H * W, args->out, st, d_status, oz ? o.z_scale : nullptr, oz ? o.z_shift : nullptr));
       prof_end(pr, 0.0, 4.0 * (double)N * H * W * (pad_channels(f) + Co), st);
       prof_end(blk, 0.0, 0.0, st);
     }
@@ -1328,9 +1362,11 @@ struct mimo_plan {
           int rows = 0;
           const int blk = prof_begin(kProfTierBase + 1, st);
           const int pr = prof_begin(MIMO_PROF_HEAD_BWD, st);
-          MIMO_TRY(head_bwd_launch(dc->out.a, this->st, dc->out.ld, params + heads[s].off_w, f, fp, Co, N, S, s, H * W, out, dout, dloss,
-                                   label, lmask, lperm, cfg.loss_kind, cfg.eps_min, cfg.eps_max, dc->out.da, s_partial, &rows,
-                                   st));
+          // (z through scale / shift + ReLU gives the activated values whichever way the forward ran: identical bits)
+          const Act& o = dc->out;
+          MIMO_TRY(head_bwd_launch(o.z ? o.z : o.a, this->st, o.z ? o.z_ld : o.ld, params + heads[s].off_w, f, fp, Co, N, S, s, H * W,
+                                   out, dout, dloss, label, lmask, lperm, cfg.loss_kind, cfg.eps_min, cfg.eps_max, dc->out.da,
+                                   s_partial, &rows, st, o.z_scale, o.z_shift));
           prof_end(pr, 0.0, 4.0 * (double)N * H * W * (2.0 * fp + Co + Co / 2), st);
           MIMO_TRY(head_bwd_stats_launch(s_partial, rows, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, colsum(), st));
           {
