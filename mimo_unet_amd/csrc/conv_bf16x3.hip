@@ -794,7 +794,11 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
   // The order is pinned with sched_group_barriers for the data gradient only: measured 7.9 -> 7.3 ms per
   // step there, but 6.9 -> 7.4 ms for the forward, whose producers carry the fp32 -> fp16 split and share
   // the SIMD's vector issue with the MFMAs (a v_mfma_16x16x32 holds it for 8 of its 16 cycles).
+#ifdef MIMO_CONV_PIN_FWD
+  constexpr bool PINNED = true;  // A/B build: the forward's consumers pinned as well (round 2 measured it slower; round 4 re-checked)
+#else
   constexpr bool PINNED = !CVT;
+#endif
   constexpr int RA = NP == 3 ? 2 : 1, RB = NF * RA;  // LDS reads per A fragment / per tap's B fragments
   // register sets: A fragments alternate per 16-pixel fragment m, B fragments per tap
   bf16x8 ah[2], al[2], bh[2][NF], bl[2][NF];
