@@ -377,6 +377,37 @@ def test_bench_counts_gpus_without_touching_hip(tmp_path, monkeypatch):
     assert "torch.cuda" not in body.split('"""')[2]  # the spawning parent makes no torch.cuda call
 
 
+def test_bench_reports_counter_traffic_only_for_the_running_kernel_sources(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from a committed rocprofv3 counter summary; it must be the summary of THIS
+    build.  pmc_traffic.json carries the content hash of mimo_unet_amd/csrc/*.{hip,h} it was collected on; another hash (or
+    none, as in the round-3 file) gives (None, reason) and bench.py prints traffic: null."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    h = bench.csrc_hash()
+    assert len(h) == 16 and h == bench.csrc_hash()
+    final = tmp_path / "profiles" / "r99" / "final"
+    final.mkdir(parents=True)
+    # the hash is computed over the real sources: keep ROOT for it, redirect only the profile lookup
+    real_root = bench.ROOT
+    monkeypatch.setattr(bench, "csrc_hash", lambda: h)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (final / "pmc_traffic.json").write_text(json.dumps({"csrc_hash": "0" * 16, "step_bytes": 1, "classes": {}}))
+    pt, why = bench.pmc_traffic()
+    assert pt is None and "other kernel sources" in why
+    (final / "pmc_traffic.json").write_text(json.dumps({"step_bytes": 1, "classes": {}}))  # no hash at all (round-3 file)
+    assert bench.pmc_traffic()[0] is None
+    (final / "pmc_traffic.json").write_text(json.dumps({"csrc_hash": h, "step_bytes": 7, "classes": {}}))
+    pt, src = bench.pmc_traffic()
+    assert pt["step_bytes"] == 7 and src.endswith("pmc_traffic.json")
+    monkeypatch.setattr(bench, "ROOT", real_root)
+    # the committed summary of this round belongs to the committed sources
+    pt, src = bench.pmc_traffic()
+    assert pt is not None and "r04" in src, src
+
+
 def test_bench_algorithmic_byte_model_matches_survey_table():
     """SURVEY 8(d) contract figures: cfg3 = 525.3 / 188.7 / 94.4 / 47.2 / 5.9 MB per image and tier (861.5 total),
     194.8 GFLOP per image; cfg2 605.0 MB, 95.4 GFLOP."""
