@@ -108,10 +108,55 @@ int dropout2d_masks_launch(const Dropout2dSite* sites_dev, int nsites, int max_c
                            uint64_t offset, hipStream_t st);
 
 // ---- BatchNorm + ReLU backward ------------------------------------------------------------
-// dy = da * mask * [z*scale+shift > 0] is evaluated on the fly by both passes (never stored).
-// da source: plain (da != nullptr, ldda) or folded from dxpad (da == nullptr).
+// dy = (gradient arriving at the activation) * mask * [z*scale+shift > 0] is evaluated on the fly by both passes (never
+// stored).  Where that gradient comes from:
+enum GradSrcKind {
+  GS_PLAIN = 0,  // a plain NHWC buffer (da, ldda)
+  GS_FOLD = 1,   // the padded-domain data gradient of the next convolution, folded (dxpad, ldp)
+  // the tensor is pooled by a Down block (and possibly the skip input of an Up block): MaxPool2d backward of
+  // fold(dxpad at the pooled size)[choff ...] — the window's activations are re-formed from z, the arithmetic of
+  // bn_relu_pool_fwd_kernel — plus fold(skip)[skoff ...]: what pool_bwd_kernel would have written, never written
+  // (fp32 storage; components.py:48 backward + the skip half of torch.cat's backward, components.py:118)
+  GS_POOL = 2,
+  // the tensor feeds the 1x1 head: W^T (dout + dloss/count * dNLL/dlogit) formed per pixel from the logits and labels —
+  // what head_bwd_kernel would have written; the reduce pass also accumulates the head's weight / bias gradient
+  // partial rows [rows][Co*Cp + Co] (Co == 2, fp32 storage; components.py:126 backward + losses.py:151-160)
+  GS_HEAD = 3,
+};
+struct HeadGrad {
+  const float* w;
+  int C, Co, N, S, s, HW;
+  const float *out, *dout, *dloss, *label, *mask;
+  const int64_t* perm;
+  int kind;
+  float eps_min, eps_max, inv_count;
+  float* partial;  // reduce pass: the head's weight / bias gradient partial rows
+};
+struct GradSrc {
+  int kind = GS_PLAIN;
+  const void* da = nullptr;
+  int ldda = 0;
+  const void* dxpad = nullptr;
+  int ldp = 0, choff = 0;
+  const void* skip = nullptr;
+  int ldsk = 0, skoff = 0;
+  HeadGrad head = {};
+  static GradSrc plain(const void* da, int ldda) {
+    GradSrc g;
+    g.da = da;
+    g.ldda = ldda;
+    return g;
+  }
+  static GradSrc fold(const void* dxpad, int ldp) {
+    GradSrc g;
+    g.kind = GS_FOLD;
+    g.dxpad = dxpad;
+    g.ldp = ldp;
+    return g;
+  }
+};
 // pass 1: partial rows of (sum dy, sum dy*xhat)
-int bnrelu_bwd_reduce_launch(const void* da, int dta, int ldda, const void* dxpad, int ldp, const void* z, int dtz, int ldz,
+int bnrelu_bwd_reduce_launch(const GradSrc& src, int dta, const void* z, int dtz, int ldz,
                              const float* scale, const float* shift, const float* mean, const float* invstd,
                              const float* mask, int C, int Cp, int N, int H, int W, float* partial, int* rows,
                              hipStream_t st);
@@ -119,7 +164,7 @@ int bnrelu_bwd_reduce_launch(const void* da, int dta, int ldda, const void* dxpa
 int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_t count, int training, float* c1,
                            float* c2, float* dgamma, float* dbeta, hipStream_t st);
 // pass 2: dz = scale * (dy - c1 - xhat*c2); partial rows of sum dz (conv bias gradient)
-int bn_bwd_apply_launch(const void* da, int dta, int ldda, const void* dxpad, int ldp, const void* z, int dtz, int ldz,
+int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int ldz,
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
                         int C, const float* c1, const float* c2, int Cp, int N, int H, int W, void* dz, int split_out,
                         float* partial, int* rows, hipStream_t st);

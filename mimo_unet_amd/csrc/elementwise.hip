@@ -1132,25 +1132,67 @@ int up_bwd_launch(const void* dxpad, int dt, int ldp, int choff, void* da, int l
 // ---------------------------------------------------------------------------------------
 // BatchNorm + ReLU backward
 // ---------------------------------------------------------------------------------------
-// dy = (gradient arriving at the activation) * dropout mask * [relu input > 0], evaluated on the fly by
-// both passes (never stored): the source is a plain NHWC buffer or the padded-domain dgrad output
-template <typename TA>
-__device__ __forceinline__ float4 relu_grad4(const TA* da, int ldda, const TA* dxpad, int ldp, const float* mask, int C,
-                                             int p, const PixIter& it, int q, int H, int W, float4 v, float4 sc, float4 sh) {
-  float4 g;
-  const int n = it.n;
-  if (da) {
-    g = ld4(da + (size_t)p * ldda + 4 * q);
+// value and gradient of the element-wise NLL.  The clamp acts on the value only
+// (losses.py:153-155 clamps in place under no_grad), so d/dlog keeps the unclamped exp.
+__device__ __forceinline__ float nll_value(int kind, float d, float lp, float eps_min, float eps_max) {
+  const float sc = fminf(fmaxf(expf(lp), eps_min), eps_max);
+  return kind == MIMO_LOSS_LAPLACE_NLL ? logf(sc) + fabsf(d) / sc : logf(sc) + d * d / sc;
+}
+__device__ __forceinline__ void nll_grad(int kind, float d, float lp, float eps_min, float eps_max, float* gmu, float* glp) {
+  const float e = expf(lp);
+  const float sc = fminf(fmaxf(e, eps_min), eps_max);
+  if (kind == MIMO_LOSS_LAPLACE_NLL) {
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    *gmu = sgn / sc;
+    *glp = (1.f / sc - fabsf(d) / (sc * sc)) * e;
   } else {
-    g = fold_read(dxpad, ldp, n, it.y, it.x, H, W, 4 * q);
+    *gmu = 2.f * d / sc;
+    *glp = (1.f / sc - d * d / (sc * sc)) * e;
   }
-  if (mask) {
-    const float4 m = mask4(mask, n, C, 4 * q);
-    g.x *= m.x;
-    g.y *= m.y;
-    g.z *= m.z;
-    g.w *= m.w;
+}
+
+// dy = (gradient arriving at the activation) * dropout mask * [relu input > 0], evaluated on the fly by
+// both passes (never stored); the arriving gradient per GradSrc (elementwise.h)
+struct HeadLane {  // GS_HEAD per-thread constants: this channel quad's 1x1 weights, dloss[s] / count
+  float4 w0, w1;
+  float coef;
+};
+__device__ __forceinline__ HeadLane head_lane(const HeadGrad& h, int q, bool active) {
+  HeadLane l;
+  l.w0 = l.w1 = f4zero();
+  l.coef = h.dloss ? h.dloss[h.s] * h.inv_count : 0.f;
+  if (active) {
+    const int c0 = 4 * q;
+    float* a0 = reinterpret_cast<float*>(&l.w0);
+    float* a1 = reinterpret_cast<float*>(&l.w1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a0[j] = c0 + j < h.C ? h.w[c0 + j] : 0.f;
+      a1[j] = c0 + j < h.C ? h.w[h.C + c0 + j] : 0.f;
+    }
   }
+  return l;
+}
+// dlogit of pixel p (Co == 2: mean, log-scale), head_bwd_kernel's arithmetic
+__device__ __forceinline__ void head_dlogit(const HeadGrad& h, const HeadLane& l, int p, float* d0, float* d1) {
+  const int n = p / h.HW;
+  const int yx = p - n * h.HW;
+  const int64_t obase = (((int64_t)n * h.S + h.s) * 2) * h.HW + yx;
+  float a = h.dout ? h.dout[obase] : 0.f, b = h.dout ? h.dout[obase + h.HW] : 0.f;
+  if (h.dloss) {
+    const int64_t src = h.perm ? h.perm[(int64_t)h.s * h.N + n] : n;
+    const float mk = h.mask ? h.mask[src * h.HW + yx] : 1.f;
+    const float mu = h.out[obase], lp = h.out[obase + h.HW], y = h.label[src * h.HW + yx];
+    float gm, gl;
+    nll_grad(h.kind, mu - y, lp, h.eps_min, h.eps_max, &gm, &gl);
+    a += l.coef * mk * gm;
+    b += l.coef * mk * gl;
+  }
+  *d0 = a;
+  *d1 = b;
+}
+
+__device__ __forceinline__ float4 relu_gate4(float4 g, float4 v, float4 sc, float4 sh) {
   g.x = fmaf(v.x, sc.x, sh.x) > 0.f ? g.x : 0.f;
   g.y = fmaf(v.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
   g.z = fmaf(v.z, sc.z, sh.z) > 0.f ? g.z : 0.f;
@@ -1158,9 +1200,82 @@ __device__ __forceinline__ float4 relu_grad4(const TA* da, int ldda, const TA* d
   return g;
 }
 
+// GS_POOL: one thread owns the 2x2 cell (cy, cx) of image n — as pool_bwd_kernel did: one folded read of the pooled
+// gradient, the four pre-activation values once, the window's activations re-formed with bn_relu_pool_fwd_kernel's
+// arithmetic, the first maximum in scan order takes the gradient, + the folded skip gradient of each pixel.  Cells of the
+// last row / column of an odd-sized image hold one or two pixels and no window.  Returns the valid pixels as a bit mask,
+// their pre-activation values in zz[] and their dy (dropout multiplier and ReLU gate applied) in g[].
 template <typename TZ, typename TA>
+__device__ __forceinline__ int pool_cell4(const GradSrc& s, const TZ* z, int ldz, int n, int cy, int cx, int H, int W, int q,
+                                          float4 sc, float4 sh, bool masked, float4 m, float4 zz[4], float4 g[4]) {
+  const int Hp = H / 2, Wp = W / 2, y0 = 2 * cy, x0 = 2 * cx;
+  const bool win = cy < Hp && cx < Wp;
+  const int valid = win ? 15 : ((1 | (x0 + 1 < W ? 2 : 0)) | (y0 + 1 < H ? (4 | (x0 + 1 < W ? 8 : 0)) : 0));
+  const TZ* zs = z + (((size_t)n * H + y0) * W + x0) * ldz + 4 * q;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) zz[j] = (valid >> j) & 1 ? ld4(zs + ((size_t)(j >> 1) * W + (j & 1)) * ldz) : f4zero();
+  float4 gp = f4zero();
+  if (win) gp = fold_read((const TA*)s.dxpad, s.ldp, n, cy, cx, Hp, Wp, s.choff + 4 * q);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    g[j] = (s.skip && ((valid >> j) & 1)) ? fold_read((const TA*)s.skip, s.ldsk, n, y0 + (j >> 1), x0 + (j & 1), H, W, s.skoff + 4 * q)
+                                           : f4zero();
+  if (win) {
+    auto act = [&](float v, float k, float b, float mm) { return fmaxf(fmaf(v, k, b), 0.f) * mm; };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // route + skip: pool_bwd_kernel's operands in its order
+      g[j].x = route_max(gp.x, act(zz[0].x, sc.x, sh.x, m.x), act(zz[1].x, sc.x, sh.x, m.x), act(zz[2].x, sc.x, sh.x, m.x), act(zz[3].x, sc.x, sh.x, m.x), j) + g[j].x;
+      g[j].y = route_max(gp.y, act(zz[0].y, sc.y, sh.y, m.y), act(zz[1].y, sc.y, sh.y, m.y), act(zz[2].y, sc.y, sh.y, m.y), act(zz[3].y, sc.y, sh.y, m.y), j) + g[j].y;
+      g[j].z = route_max(gp.z, act(zz[0].z, sc.z, sh.z, m.z), act(zz[1].z, sc.z, sh.z, m.z), act(zz[2].z, sc.z, sh.z, m.z), act(zz[3].z, sc.z, sh.z, m.z), j) + g[j].z;
+      g[j].w = route_max(gp.w, act(zz[0].w, sc.w, sh.w, m.w), act(zz[1].w, sc.w, sh.w, m.w), act(zz[2].w, sc.w, sh.w, m.w), act(zz[3].w, sc.w, sh.w, m.w), j) + g[j].w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (masked) {
+      g[j].x *= m.x;
+      g[j].y *= m.y;
+      g[j].z *= m.z;
+      g[j].w *= m.w;
+    }
+    g[j] = relu_gate4(g[j], zz[j], sc, sh);
+  }
+  return valid;
+}
+
+template <int SRC, typename TZ, typename TA>
+__device__ __forceinline__ float4 relu_grad4(const GradSrc& s, const HeadLane& hl, const float* mask, int C, int p,
+                                             const PixIter& it, int q, int H, int W, float4 v, float4 sc, float4 sh, float* d0,
+                                             float* d1) {
+  static_assert(SRC != GS_POOL, "pooled tensors: pool_cell4");
+  float4 g;
+  const int n = it.n;
+  float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (mask) m = mask4(mask, n, C, 4 * q);
+  if constexpr (SRC == GS_PLAIN) {
+    g = ld4((const TA*)s.da + (size_t)p * s.ldda + 4 * q);
+  } else if constexpr (SRC == GS_FOLD) {
+    g = fold_read((const TA*)s.dxpad, s.ldp, n, it.y, it.x, H, W, 4 * q);
+  } else {
+    head_dlogit(s.head, hl, p, d0, d1);
+    g = f4zero();
+    g.x = fmaf(*d1, hl.w1.x, fmaf(*d0, hl.w0.x, g.x));
+    g.y = fmaf(*d1, hl.w1.y, fmaf(*d0, hl.w0.y, g.y));
+    g.z = fmaf(*d1, hl.w1.z, fmaf(*d0, hl.w0.z, g.z));
+    g.w = fmaf(*d1, hl.w1.w, fmaf(*d0, hl.w0.w, g.w));
+  }
+  if (mask) {
+    g.x *= m.x;
+    g.y *= m.y;
+    g.z *= m.z;
+    g.w *= m.w;
+  }
+  return relu_gate4(g, v, sc, sh);
+}
+
+template <typename TZ, typename TA, int SRC>
 __global__ __launch_bounds__(kBnReduceThreads) void bnrelu_bwd_reduce_kernel(
-    const TA* __restrict__ da, int ldda, const TA* __restrict__ dxpad, int ldp, const TZ* __restrict__ z, int ldz,
+    const GradSrc src, const TZ* __restrict__ z, int ldz,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ mask, int C, int Cv, int N, int H, int W,
     float* __restrict__ partial) {
@@ -1168,18 +1283,55 @@ __global__ __launch_bounds__(kBnReduceThreads) void bnrelu_bwd_reduce_kernel(
   const PQ t = pixquad<kBnReduceThreads>(Cv);
   const int Cp = 4 * Cv;
   float4 a1 = f4zero(), a2 = f4zero();
+  float4 hw0 = f4zero(), hw1 = f4zero();  // GS_HEAD: the head's weight gradient (this quad's channels x 2 logits), bias gradient
+  float hb0 = 0.f, hb1 = 0.f;
+  HeadLane hl = {};
+  if constexpr (SRC == GS_HEAD) hl = head_lane(src.head, t.q, t.active);
   if (t.active) {
     const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q), mu = ld4(mean + 4 * t.q), is = ld4(invstd + 4 * t.q);
-    const int P = N * H * W;
+    if constexpr (SRC == GS_POOL) {
+      const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, P = N * Hc * Wc;
+      PixIter it = pix_iter(t.p, t.pstep, Hc, Wc);
+      for (int p = t.p; p < P; p += t.pstep, pix_next(it, Hc, Wc)) {
+        float4 zz[4], g[4];
+        const float4 m = mask ? mask4(mask, it.n, C, 4 * t.q) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const int valid = pool_cell4<TZ, TA>(src, z, ldz, it.n, it.y, it.x, H, W, t.q, sc, sh, mask != nullptr, m, zz, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((valid >> j) & 1) {
+            a1 = f4add(a1, g[j]);
+            a2.x += g[j].x * (zz[j].x - mu.x) * is.x;
+            a2.y += g[j].y * (zz[j].y - mu.y) * is.y;
+            a2.z += g[j].z * (zz[j].z - mu.z) * is.z;
+            a2.w += g[j].w * (zz[j].w - mu.w) * is.w;
+          }
+      }
+    }
+    const int P = SRC == GS_POOL ? 0 : N * H * W;
     PixIter it = pix_iter(t.p, t.pstep, H, W);
     for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
       const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
-      const float4 g = relu_grad4(da, ldda, dxpad, ldp, mask, C, p, it, t.q, H, W, v, sc, sh);
+      float d0 = 0.f, d1 = 0.f;
+      float4 g = f4zero();
+      if constexpr (SRC != GS_POOL) g = relu_grad4<SRC, TZ, TA>(src, hl, mask, C, p, it, t.q, H, W, v, sc, sh, &d0, &d1);
       a1 = f4add(a1, g);
       a2.x += g.x * (v.x - mu.x) * is.x;
       a2.y += g.y * (v.y - mu.y) * is.y;
       a2.z += g.z * (v.z - mu.z) * is.z;
       a2.w += g.w * (v.w - mu.w) * is.w;
+      if constexpr (SRC == GS_HEAD) {  // the head's input is this tensor's activation (no dropout on this path)
+        const float4 av = bn_relu4(v, sc, sh);
+        hw0.x = fmaf(d0, av.x, hw0.x);
+        hw0.y = fmaf(d0, av.y, hw0.y);
+        hw0.z = fmaf(d0, av.z, hw0.z);
+        hw0.w = fmaf(d0, av.w, hw0.w);
+        hw1.x = fmaf(d1, av.x, hw1.x);
+        hw1.y = fmaf(d1, av.y, hw1.y);
+        hw1.z = fmaf(d1, av.z, hw1.z);
+        hw1.w = fmaf(d1, av.w, hw1.w);
+        hb0 += d0;
+        hb1 += d1;
+      }
     }
   }
   const float4 s1 = quad_block_sum(a1, t, red);
@@ -1189,19 +1341,55 @@ __global__ __launch_bounds__(kBnReduceThreads) void bnrelu_bwd_reduce_kernel(
     st4(row + 4 * t.q, s1);
     st4(row + Cp + 4 * t.q, s2);
   }
+  if constexpr (SRC == GS_HEAD) {  // partial row as head_bwd_kernel writes it: [2][Cp] weight gradient, [2] bias gradient
+    float* row = src.head.partial + (size_t)blockIdx.x * (2 * Cp + 2);
+    const float4 w0 = quad_block_sum(hw0, t, red);
+    const float4 w1 = quad_block_sum(hw1, t, red);
+    const float4 sb = quad_block_sum(make_float4(hb0, hb1, 0.f, 0.f), t, red);
+    if (t.pl == 0 && t.q < Cv) {
+      st4(row + 4 * t.q, w0);
+      st4(row + Cp + 4 * t.q, w1);
+    }
+    if (t.pl == 0 && t.q == 0) {
+      row[2 * Cp] = sb.x;
+      row[2 * Cp + 1] = sb.y;
+    }
+  }
 }
 
-int bnrelu_bwd_reduce_launch(const void* da, int dta, int ldda, const void* dxpad, int ldp, const void* z, int dtz, int ldz,
+// the fused sources exist for fp32 storage (TZ = TA = float) only
+static int check_grad_src(const GradSrc& src, int dta, int dtz) {
+  if (src.kind < GS_PLAIN || src.kind > GS_HEAD || (src.kind >= GS_POOL && (dta != ST_F32 || dtz != ST_F32)) ||
+      (src.kind == GS_HEAD && src.head.Co != 2)) {
+    set_error("BatchNorm backward: gradient source %d unsupported here", src.kind);
+    return MIMO_ERR_INVALID;
+  }
+  return MIMO_OK;
+}
+
+int bnrelu_bwd_reduce_launch(const GradSrc& src, int dta, const void* z, int dtz, int ldz,
                              const float* scale, const float* shift, const float* mean, const float* invstd,
                              const float* mask, int C, int Cp, int N, int H, int W, float* partial, int* rows,
                              hipStream_t st) {
+  MIMO_TRY(check_grad_src(src, dta, dtz));
   const int Cv = Cp / 4;
-  const dim3 grid = pq_grid(Cv, (int64_t)N * H * W, kBlocksBnReduce, kBnReduceThreads);
+  const int64_t units = src.kind == GS_POOL ? (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) : (int64_t)N * H * W;  // cells / pixels
+  // (the fused sources hold more registers: 4 / 5 waves per SIMD = one 1024-thread workgroup per CU, a single round)
+  const dim3 grid = pq_grid(Cv, units, src.kind >= GS_POOL ? 256 : kBlocksBnReduce, kBnReduceThreads);
   *rows = grid.x;
-  MIMO_ST_DISPATCH2(dtz, dta, TZ, TA,
-                    hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<TZ, TA>), grid, dim3(kBnReduceThreads), 0, st, (const TA*)da, ldda,
-                                       (const TA*)dxpad, ldp, (const TZ*)z, ldz, scale, shift, mean, invstd, mask, C, Cv, N, H, W,
-                                       partial))
+#define REDUCE_LAUNCH(TZ, TA, SRC)                                                                                              \
+  hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<TZ, TA, SRC>), grid, dim3(kBnReduceThreads), 0, st, src, (const TZ*)z, ldz, scale, \
+                     shift, mean, invstd, mask, C, Cv, N, H, W, partial)
+  if (src.kind == GS_POOL) {
+    REDUCE_LAUNCH(float, float, GS_POOL);
+  } else if (src.kind == GS_HEAD) {
+    REDUCE_LAUNCH(float, float, GS_HEAD);
+  } else if (src.kind == GS_PLAIN) {
+    MIMO_ST_DISPATCH2(dtz, dta, TZ, TA, REDUCE_LAUNCH(TZ, TA, GS_PLAIN))
+  } else {
+    MIMO_ST_DISPATCH2(dtz, dta, TZ, TA, REDUCE_LAUNCH(TZ, TA, GS_FOLD))
+  }
+#undef REDUCE_LAUNCH
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1298,9 +1486,8 @@ int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStrea
   return MIMO_OK;
 }
 
-template <typename TZ, typename TA>
-__global__ void bn_bwd_apply_kernel(const TA* __restrict__ da, int ldda, const TA* __restrict__ dxpad, int ldp,
-                                    const TZ* __restrict__ z, int ldz, const float* __restrict__ scale,
+template <typename TZ, typename TA, int SRC>
+__global__ void bn_bwd_apply_kernel(const GradSrc src, const TZ* __restrict__ z, int ldz, const float* __restrict__ scale,
                                     const float* __restrict__ shift, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ mask, int C,
                                     const float* __restrict__ c1, const float* __restrict__ c2, int Cv, int N, int H,
@@ -1309,14 +1496,12 @@ __global__ void bn_bwd_apply_kernel(const TA* __restrict__ da, int ldda, const T
   const PQ t = pixquad(Cv);
   const int Cp = 4 * Cv;
   float4 acc = f4zero();
+  HeadLane hl = {};
+  if constexpr (SRC == GS_HEAD) hl = head_lane(src.head, t.q, t.active);
   if (t.active) {
     const float4 sc = ld4(scale + 4 * t.q), sh = ld4(shift + 4 * t.q), mu = ld4(mean + 4 * t.q), is = ld4(invstd + 4 * t.q);
     const float4 k1 = ld4(c1 + 4 * t.q), k2 = ld4(c2 + 4 * t.q);
-    const int P = N * H * W;
-    PixIter it = pix_iter(t.p, t.pstep, H, W);
-    for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
-      const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
-      const float4 g = relu_grad4(da, ldda, dxpad, ldp, mask, C, p, it, t.q, H, W, v, sc, sh);
+    auto emit = [&](int p, float4 g, float4 v) {
       float4 r;
       r.x = sc.x * (g.x - k1.x - (v.x - mu.x) * is.x * k2.x);
       r.y = sc.y * (g.y - k1.y - (v.y - mu.y) * is.y * k2.y);
@@ -1327,6 +1512,27 @@ __global__ void bn_bwd_apply_kernel(const TA* __restrict__ da, int ldda, const T
       else
         st4(dz + (size_t)p * Cp + 4 * t.q, r);
       acc = f4add(acc, r);
+    };
+    if constexpr (SRC == GS_POOL) {
+      const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, P = N * Hc * Wc;
+      PixIter it = pix_iter(t.p, t.pstep, Hc, Wc);
+      for (int p = t.p; p < P; p += t.pstep, pix_next(it, Hc, Wc)) {
+        float4 zz[4], g[4];
+        const float4 m = mask ? mask4(mask, it.n, C, 4 * t.q) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const int valid = pool_cell4<TZ, TA>(src, z, ldz, it.n, it.y, it.x, H, W, t.q, sc, sh, mask != nullptr, m, zz, g);
+        const int p0 = (it.n * H + 2 * it.y) * W + 2 * it.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((valid >> j) & 1) emit(p0 + (j >> 1) * W + (j & 1), g[j], zz[j]);
+      }
+    } else {
+      const int P = N * H * W;
+      PixIter it = pix_iter(t.p, t.pstep, H, W);
+      for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
+        const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
+        float d0, d1;
+        emit(p, relu_grad4<SRC, TZ, TA>(src, hl, mask, C, p, it, t.q, H, W, v, sc, sh, &d0, &d1), v);
+      }
     }
   }
   if (!partial) return;  // training mode: the bias gradient is exactly zero, no column sums wanted
@@ -1334,21 +1540,32 @@ __global__ void bn_bwd_apply_kernel(const TA* __restrict__ da, int ldda, const T
   if (t.pl == 0 && t.q < Cv) st4(partial + (size_t)blockIdx.x * Cp + 4 * t.q, s);
 }
 
-int bn_bwd_apply_launch(const void* da, int dta, int ldda, const void* dxpad, int ldp, const void* z, int dtz, int ldz,
+int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int ldz,
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
                         int C, const float* c1, const float* c2, int Cp, int N, int H, int W, void* dz, int split_out,
                         float* partial, int* rows, hipStream_t st) {
+  MIMO_TRY(check_grad_src(src, dta, dtz));
   const int Cv = Cp / 4;
-  const dim3 grid = pq_grid(Cv, (int64_t)N * H * W, kBlocksBnBwd);
+  const int64_t units = src.kind == GS_POOL ? (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) : (int64_t)N * H * W;
+  const dim3 grid = pq_grid(Cv, units, src.kind == GS_POOL ? 1024 : src.kind == GS_HEAD ? 1280 : kBlocksBnBwd);  // 4 / 5 / 7 per CU
   *rows = grid.x;
   if (split_out && dta != ST_F32) {
     set_error("bn_bwd_apply: pair-split dz exists for fp32 storage only");
     return MIMO_ERR_INVALID;
   }
-  MIMO_ST_DISPATCH2(dtz, dta, TZ, TA,
-                    hipLaunchKernelGGL((bn_bwd_apply_kernel<TZ, TA>), grid, dim3(256), 0, st, (const TA*)da, ldda, (const TA*)dxpad,
-                                       ldp, (const TZ*)z, ldz, scale, shift, mean, invstd, mask, C, c1, c2, Cv, N, H, W, (TA*)dz,
-                                       split_out, partial))
+#define APPLY_LAUNCH(TZ, TA, SRC)                                                                                              \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<TZ, TA, SRC>), grid, dim3(256), 0, st, src, (const TZ*)z, ldz, scale, shift, mean, invstd, \
+                     mask, C, c1, c2, Cv, N, H, W, (TA*)dz, split_out, partial)
+  if (src.kind == GS_POOL) {
+    APPLY_LAUNCH(float, float, GS_POOL);
+  } else if (src.kind == GS_HEAD) {
+    APPLY_LAUNCH(float, float, GS_HEAD);
+  } else if (src.kind == GS_PLAIN) {
+    MIMO_ST_DISPATCH2(dtz, dta, TZ, TA, APPLY_LAUNCH(TZ, TA, GS_PLAIN))
+  } else {
+    MIMO_ST_DISPATCH2(dtz, dta, TZ, TA, APPLY_LAUNCH(TZ, TA, GS_FOLD))
+  }
+#undef APPLY_LAUNCH
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1449,25 +1666,6 @@ int head_fwd_launch(const void* a, int dt, int lda, const float* w, const float*
 #undef HEAD_LAUNCH2
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
-}
-
-// value and gradient of the element-wise NLL.  The clamp acts on the value only
-// (losses.py:153-155 clamps in place under no_grad), so d/dlog keeps the unclamped exp.
-__device__ __forceinline__ float nll_value(int kind, float d, float lp, float eps_min, float eps_max) {
-  const float sc = fminf(fmaxf(expf(lp), eps_min), eps_max);
-  return kind == MIMO_LOSS_LAPLACE_NLL ? logf(sc) + fabsf(d) / sc : logf(sc) + d * d / sc;
-}
-__device__ __forceinline__ void nll_grad(int kind, float d, float lp, float eps_min, float eps_max, float* gmu, float* glp) {
-  const float e = expf(lp);
-  const float sc = fminf(fmaxf(e, eps_min), eps_max);
-  if (kind == MIMO_LOSS_LAPLACE_NLL) {
-    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    *gmu = sgn / sc;
-    *glp = (1.f / sc - fabsf(d) / (sc * sc)) * e;
-  } else {
-    *gmu = 2.f * d / sc;
-    *glp = (1.f / sc - d * d / (sc * sc)) * e;
-  }
 }
 
 __global__ void loss_fwd_kernel(const float* __restrict__ out, const float* __restrict__ label,

@@ -57,6 +57,14 @@ struct Act {
   const float* skipgrad = nullptr;
   int skipgrad_ld = 0;
   bool pooled = false;  // some Down block pools this tensor (its pool_bwd then takes the skip gradient along)
+  // Pooled gradient of this tensor left in the pooling Down block's own padded-domain buffer (pixel pitch poolgrad_ld) for
+  // the BatchNorm backward of the producing convolution(s) to route through the max-pool windows themselves (GS_POOL,
+  // elementwise.h): pool_bwd is not launched and `da` is not written.  A channel slice of a concat tensor (down1[s] inside
+  // x2cat) finds both gradients on `parent`, at channel offset parent_choff.
+  const float* poolgrad = nullptr;
+  int poolgrad_ld = 0;
+  Act* parent = nullptr;
+  int parent_choff = 0;
   // != nullptr: in a TRAINING forward `a` is not written — its readers (the bilinear up-sampling into the next block's
   // concat buffer, the 1x1 head and its backward) take the producing convolution's pre-activation tensor z (pixel pitch
   // z_ld) and apply scale / shift + ReLU themselves (round 4; Up blocks without dropout in split16)
@@ -160,6 +168,8 @@ struct mimo_plan {
   // scratch
   float *s_dz = nullptr, *s_dxpadA = nullptr, *s_dxpadB = nullptr, *s_wslab = nullptr,
         *s_partial = nullptr, *s_losspart = nullptr;
+  float* s_headpart = nullptr;  // GS_HEAD: the head's weight / bias gradient partial rows, written by the BatchNorm-backward reduction
+  int head_rows = 0;            // ... and how many (that launch's grid)
   double* s_sums = nullptr;
   int* s_tickets = nullptr;  // colsum tickets of the scratch set in use (zero between launches)
   ColsumScratch colsum() const { return ColsumScratch{s_sums, s_tickets, d_status}; }
@@ -172,6 +182,10 @@ struct mimo_plan {
   // (Measured and removed in round 3: per-layer dz buffers without back-pressure, 3-4 ping-pong buffers, releasing a
   // weight gradient only after its layer's data gradient — none faster)
   bool wg_async = false;
+  // BatchNorm backward forms the gradient arriving at a pooled tensor / at the head's input itself (GS_POOL / GS_HEAD):
+  // fp32 storage, MIMO_FUSE_BWD_SRC=0 switches it off (read per plan)
+  bool fuse_bwd_src = false;
+  bool fuse_bwd_pool = false, fuse_bwd_head = false;  // (MIMO_FUSE_BWD_SRC=2: pooled tensors only, 3: head only — A/B)
   hipStream_t wg_stream = nullptr;
   static constexpr int kDzBufs = 2;
   static constexpr int wg_bufs = kDzBufs;
@@ -525,6 +539,8 @@ struct mimo_plan {
     static const bool skip_keep = !(getenv("MIMO_SKIP_GRAD_IN_PLACE") && atoi(getenv("MIMO_SKIP_GRAD_IN_PLACE")) == 0);
     if (kind == IN_UPCAT && skip_keep && s0->pooled && !cfg.inference_only)
       MIMO_TRY(alloc_act(&dc->dxpad_own, (size_t)N * (h + 2) * (w + 2) * in_cp, st));
+    // the pooled gradient stays in this block's own buffer until the producers' BatchNorm backward has routed it (GS_POOL)
+    if (kind == IN_POOL && fuse_bwd_pool) MIMO_TRY(alloc_act(&dc->dxpad_own, (size_t)N * (h + 2) * (w + 2) * in_cp, st));
     dc->in_ld = in_cp;
     dc->c1.in = dc->in_buf;
     dc->c1.ld_in = in_cp;
@@ -542,6 +558,12 @@ struct mimo_plan {
     f16 = cfg.precision == MIMO_PREC_FP16_MIXED;
     st = !mixed ? ST_F32 : f16 ? ST_F16 : ST_BF16;
     esz = store_bytes(st);
+    {
+      const int v = getenv("MIMO_FUSE_BWD_SRC") ? atoi(getenv("MIMO_FUSE_BWD_SRC")) : 1;
+      fuse_bwd_src = !mixed && !cfg.inference_only && v != 0;
+      fuse_bwd_pool = fuse_bwd_src && v != 3;
+      fuse_bwd_head = fuse_bwd_src && v != 2;
+    }
     if (cfg.precision < MIMO_PREC_FP32 || cfg.precision > MIMO_PREC_FP16_MIXED) {
       set_error("unknown precision %d", cfg.precision);
       return MIMO_ERR_INVALID;
@@ -600,6 +622,8 @@ struct mimo_plan {
                        2 * f, H2, W2, cfg.encoder_dropout_rate, eoff(x2cat.a, (size_t)s * c2p), x2cat.Cp,
                        x2cat.da ? eoff(x2cat.da, (size_t)s * c2p) : nullptr, x2cat.Cp));
       MIMO_TRY(set_input(dc, IN_POOL, &enc_in[s]->out, nullptr, enc_in[s]->out.Cp, H2, W2));
+      dc->out.parent = &x2cat;
+      dc->out.parent_choff = s * c2p;
       down1.push_back(dc);
     }
     encoder_param_floats = param_floats;  // everything registered so far belongs to the S encoders
@@ -713,6 +737,7 @@ struct mimo_plan {
     MIMO_TRY(alloc_act(&s_dxpadB, cap_pad, st));
     MIMO_TRY(dalloc(&s_wslab, cap_slab));
     MIMO_TRY(dalloc(&s_partial, cap_partial));
+    if (fuse_bwd_src) MIMO_TRY(dalloc(&s_headpart, (size_t)kBnReduceMaxBlocks * (2 * pad_channels(f) + 2)));
     MIMO_TRY(dalloc(&s_sums, cap_sums));
     MIMO_TRY(dalloc(&s_tickets, kColsumMaxGroups));
     MIMO_TRY(dalloc(&s_losspart, (size_t)S * 512));
@@ -1133,14 +1158,18 @@ struct mimo_plan {
   // gradient arriving at an activation: first writer assigns, later writers accumulate
   static int acc_flag(Act* t) { return t->grad_writes++ > 0 ? 1 : 0; }
 
-  int convbn_backward(ConvBN& L, const float* da, int ldda, const float* dxpad_src, const float* mask, bool need_dgrad,
-                      float* dxpad_out, hipStream_t st) {
+  // `src`: where the gradient arriving at L's activation comes from (GradSrc, elementwise.h)
+  int convbn_backward(ConvBN& L, const GradSrc& src, const float* mask, bool need_dgrad, float* dxpad_out, hipStream_t st) {
     int rows = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
+    // algorithmic bytes of the source per pixel and channel (z and dz are counted below): the pooled gradient is a quarter
+    // of the image, the head's logits / labels a few floats per pixel
+    const double src_b = src.kind == GS_POOL ? (1.0 + (src.skip ? 4.0 : 0.0)) : src.kind == GS_HEAD ? 0.5 : 4.0;
     int pr = prof_begin(MIMO_PROF_BN_BWD_REDUCE, st);
-    MIMO_TRY(bnrelu_bwd_reduce_launch(da, this->st, ldda, dxpad_src, L.cout_p, L.z, L.dtz, L.cout_p, L.scale, L.shift, L.mean, L.invstd,
+    MIMO_TRY(bnrelu_bwd_reduce_launch(src, this->st, L.z, L.dtz, L.cout_p, L.scale, L.shift, L.mean, L.invstd,
                                       mask, L.Cout, L.cout_p, L.N, L.H, L.W, s_partial, &rows, st));
-    prof_end(pr, 0.0, 8.0 * (double)P * L.cout_p, st);
+    prof_end(pr, 0.0, (4.0 + src_b) * (double)P * L.cout_p, st);
+    if (src.kind == GS_HEAD) head_rows = rows;
     MIMO_TRY(bn_bwd_stats_launch(s_partial, rows, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
                                  grads + L.off_gamma, grads + L.off_beta, fwd_training ? grads + L.off_b : nullptr, colsum(), st));
     // (with the profiler armed everything runs on the caller's stream: per-kernel times, not overlapped times)
@@ -1152,10 +1181,10 @@ struct mimo_plan {
       if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
     }
     pr = prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
-    MIMO_TRY(bn_bwd_apply_launch(da, this->st, ldda, dxpad_src, L.cout_p, L.z, L.dtz, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
+    MIMO_TRY(bn_bwd_apply_launch(src, this->st, L.z, L.dtz, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
                                  L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, (L.dg_split && !mixed) ? 1 : 0,
                                  fwd_training ? nullptr : s_partial, &rows, st));
-    prof_end(pr, 0.0, 12.0 * (double)P * L.cout_p, st);
+    prof_end(pr, 0.0, (8.0 + src_b) * (double)P * L.cout_p, st);
     // dz storage: bf16 hi|lo pairs when the data-gradient kernel is the bf16-pair one (then the weight
     // gradient is too); fp32 otherwise, with a split copy for a bf16-pair weight gradient
     const float* dz_wg = dz;
@@ -1249,20 +1278,40 @@ struct mimo_plan {
     return MIMO_OK;
   }
 
-  int dc_backward(DoubleConv* dc, bool need_input_grad, hipStream_t st) {
+  int dc_backward(DoubleConv* dc, bool need_input_grad, hipStream_t st, const GradSrc* head_src = nullptr) {
     const int blk = prof_begin(kProfTierBase + 2 * tier_of(dc->c1.H) + 1, st);
-    const int rc = dc_backward_impl(dc, need_input_grad, st);
+    const int rc = dc_backward_impl(dc, need_input_grad, st, head_src);
     prof_end(blk, 0.0, 0.0, st);
     return rc;
   }
 
-  int dc_backward_impl(DoubleConv* dc, bool need_input_grad, hipStream_t st) {
-    MIMO_TRY(convbn_backward(dc->c2, dc->out.da, dc->out.ldda, nullptr, dc->mask, true, s_dxpadA, st));
+  int dc_backward_impl(DoubleConv* dc, bool need_input_grad, hipStream_t st, const GradSrc* head_src = nullptr) {
+    GradSrc src = GradSrc::plain(dc->out.da, dc->out.ldda);
+    {
+      const Act* root = dc->out.parent ? dc->out.parent : &dc->out;
+      if (head_src) {
+        src = *head_src;
+      } else if (root->poolgrad) {  // pooled by a Down block that left its gradient in place (below)
+        src.kind = GS_POOL;
+        src.dxpad = root->poolgrad;
+        src.ldp = root->poolgrad_ld;
+        src.skip = root->skipgrad;
+        src.ldsk = root->skipgrad_ld;
+        src.choff = src.skoff = dc->out.parent ? dc->out.parent_choff : 0;
+      }
+    }
+    MIMO_TRY(convbn_backward(dc->c2, src, dc->mask, true, s_dxpadA, st));
     float* dxB = dc->dxpad_own ? dc->dxpad_own : s_dxpadB;
-    MIMO_TRY(convbn_backward(dc->c1, nullptr, 0, s_dxpadA, nullptr, need_input_grad, dxB, st));
+    MIMO_TRY(convbn_backward(dc->c1, GradSrc::fold(s_dxpadA, dc->c1.cout_p), nullptr, need_input_grad, dxB, st));
     if (!need_input_grad) return MIMO_OK;
     const int h = dc->c1.H, w = dc->c1.W, ldp = dc->c1.cin_p;
-    if (dc->kind == IN_POOL) {
+    if (dc->kind == IN_POOL && fuse_bwd_pool && dc->dxpad_own && dc->src0->grad_writes == 0) {
+      // nobody has written the pooled tensor's gradient buffer (its skip gradient, if any, waits in the Up block's own
+      // buffer): the producers' BatchNorm backward reads pool route + skip fold straight from the two padded-domain buffers
+      Act* s = dc->src0;
+      s->poolgrad = dxB;
+      s->poolgrad_ld = ldp;
+    } else if (dc->kind == IN_POOL) {
       Act* s = dc->src0;
       const int pr = prof_begin(MIMO_PROF_POOL_BWD, st);
       const bool acc = acc_flag(s) != 0;
@@ -1350,9 +1399,11 @@ struct mimo_plan {
         for (auto& dc : dcs) {
           dc->out.grad_writes = 0;
           dc->out.skipgrad = nullptr;
+          dc->out.poolgrad = nullptr;
         }
         x2cat.grad_writes = 0;
         x2cat.skipgrad = nullptr;
+        x2cat.poolgrad = nullptr;
         if (!fwd_training) {  // eval-mode forward skipped the dgrad weight packing
           MIMO_TRY(pack_all(true, st));
         }
@@ -1360,6 +1411,19 @@ struct mimo_plan {
         for (int s = S - 1; s >= 0; --s) {
           DoubleConv* dc = up4[s];
           int rows = 0;
+          const float* em = elem_masks.empty() ? nullptr : elem_masks[1 + s];
+          if (fuse_bwd_head && Co == 2 && !dc->mask && !em && !elem_rng_on[1 + s]) {
+            // the head's input gradient is formed by the BatchNorm backward of the decoder's last convolution itself (GS_HEAD):
+            // head_bwd is not launched, the gradient of the decoder output is never written
+            GradSrc hs;
+            hs.kind = GS_HEAD;
+            hs.head = HeadGrad{params + heads[s].off_w, f, Co, N, S, s, H * W, out, dout, dloss, label, lmask, lperm, cfg.loss_kind,
+                               cfg.eps_min, cfg.eps_max, 1.f / (float)((double)N * (Co / 2) * H * W), s_headpart};
+            MIMO_TRY(dc_backward(dc, true, st, &hs));
+            // (the head's partial rows: one per workgroup of that reduction)
+            MIMO_TRY(head_bwd_stats_launch(s_headpart, head_rows, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, colsum(), st));
+            continue;
+          }
           const int blk = prof_begin(kProfTierBase + 1, st);
           const int pr = prof_begin(MIMO_PROF_HEAD_BWD, st);
           // (z through scale / shift + ReLU gives the activated values whichever way the forward ran: identical bits)
@@ -1369,13 +1433,10 @@ struct mimo_plan {
                                    s_partial, &rows, st, o.z_scale, o.z_shift));
           prof_end(pr, 0.0, 4.0 * (double)N * H * W * (2.0 * fp + Co + Co / 2), st);
           MIMO_TRY(head_bwd_stats_launch(s_partial, rows, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, colsum(), st));
-          {
-            const float* em = elem_masks.empty() ? nullptr : elem_masks[1 + s];
-            if (em || elem_rng_on[1 + s]) {
-              const ElemRng g = elem_rng(1 + s);
-              MIMO_TRY(elem_mask_mul_launch(dc->out.da, this->st, dc->out.ldda, em, N, dc->out.C, dc->out.Cp, H * W, st,
-                                            em ? nullptr : &g));
-            }
+          if (em || elem_rng_on[1 + s]) {
+            const ElemRng g = elem_rng(1 + s);
+            MIMO_TRY(elem_mask_mul_launch(dc->out.da, this->st, dc->out.ldda, em, N, dc->out.C, dc->out.Cp, H * W, st,
+                                          em ? nullptr : &g));
           }
           prof_end(blk, 0.0, 0.0, st);
           MIMO_TRY(dc_backward(dc, true, st));

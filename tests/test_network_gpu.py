@@ -528,6 +528,71 @@ def test_bn_relu_in_the_second_convolutions_loaders_is_bit_identical(geom, monke
         assert torch.equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize("geom", [(2, 2, 2, 30, 2, 256, 256, 0.0), (3, 2, 3, 10, 3, 100, 100, 0.2), (1, 2, 1, 8, 2, 50, 70, 0.0)],
+                         ids=lambda g: "-".join(map(str, g)))
+def test_pool_and_head_gradients_formed_by_the_batchnorm_backward(geom, monkeypatch):
+    """Round 4: the gradient arriving at a pooled (and skip-connected) encoder tensor — MaxPool2d backward of the Down block's
+    data gradient + the skip half of torch.cat's backward (components.py:48,118) — and the one arriving at the head's input
+    (1x1 conv + NLL backward, components.py:126, losses.py:151-160) are formed by the two BatchNorm-backward passes of the
+    producing convolution; pool_bwd / head_bwd are not launched and those gradient tensors are never written.
+    Each element's arriving gradient has the same bits as what the separate kernel wrote (same operands, same order), but the
+    launches differ — one thread owns a 2x2 window of a pooled tensor, the fused reductions run on one workgroup per CU — so
+    the per-channel sums of BatchNorm's backward (and the head's own weight / bias gradient) group their terms differently:
+    against MIMO_FUSE_BWD_SRC=0 the forward quantities and BatchNorm buffers are bit-identical and every gradient agrees to
+    fp32 summation-order noise (bound 2e-5 of each tensor's scale, observed ~1e-6); =3 is the head alone, =1 both.
+    Odd sizes (100 -> 50 -> 25 -> 12: rows / columns outside every window), Dropout2d masks on the encoder blocks, a masked
+    loss, S = 1 and S = 3, and the eval-mode backward (FGSM)."""
+    Ci, Co, S, f, N, H, W, p_enc = geom
+    cfg = O.NetConfig(Ci, Co, S, f, encoder_dropout_rate=p_enc)
+    st = O.init_state(cfg, 91)
+    g = torch.Generator().manual_seed(92)
+    for k in st:
+        if (".double_conv.1." in k or ".double_conv.4." in k) and k.endswith("weight"):
+            st[k] = torch.randn(st[k].shape, generator=g)
+        if (".double_conv.1." in k or ".double_conv.4." in k) and k.endswith(".bias"):
+            st[k] = 0.3 * torch.randn(st[k].shape, generator=g)
+    image, label = torch.rand(N, Ci, H, W, generator=g).cuda(), torch.rand(N, 1, H, W, generator=g).cuda()
+    mask = (torch.rand(N, 1, H, W, generator=g) > 0.3).float().cuda() if S == 3 else None
+    perms = O.draw_perms(N, S, generator=g).cuda()
+    res = {}
+    for flag in ("0", "3", "1"):
+        monkeypatch.setenv("MIMO_FUSE_BWD_SRC", flag)
+        torch.manual_seed(93)
+        m = build_model(cfg, st, dropout=(p_enc, 0.0, 0.0))
+        m.train()
+        outs = []
+        for _ in range(2):
+            m.zero_grad()
+            o = m.training_step_with_perms(image, label, mask, perms)
+            o["loss"].backward()
+            outs.append((o["loss"].detach().clone(), o["preds"].clone(), {n: p.grad.clone() for n, p in m.model.named_parameters()}))
+        m.eval()
+        x5 = torch.stack([image[perms[s]] for s in range(S)], 1).requires_grad_(True)
+        p1, p2 = m(x5)
+        m.zero_grad()
+        (p1.mean() + p2.mean()).backward()
+        outs.append((p1.detach().clone(), x5.grad.clone(), {n: p.grad.clone() for n, p in m.model.named_parameters()}))
+        res[flag] = (outs, {k: v.clone() for k, v in m.state_dict().items()})
+
+    def close(x, y, scale, tol):
+        return float((x - y).abs().max()) <= tol * (float(scale.abs().max()) + 1e-30)
+
+    (b, sb) = res["0"]
+    worst = 0.0
+    for flag in ("3", "1"):
+        a, sa = res[flag]
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta[0], tb[0])  # forward quantities: untouched
+            for x, y, n in [(ta[1], tb[1], "second output")] + [(ta[2][n], tb[2][n], n) for n in ta[2]]:
+                # (pre-BatchNorm conv biases: a mathematically zero gradient, judged on the scale of their weight gradient)
+                scale = tb[2][n[:-4] + "weight"] if is_prebn_bias(n) else y
+                worst = max(worst, float((x - y).abs().max()) / (float(scale.abs().max()) + 1e-30))
+                assert close(x, y, scale, 2e-5), (flag, n)
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+    report(f"fused gradient sources {geom}: worst deviation from the separate kernels {worst:.2e} of the tensor's scale (bound 2e-5)")
+
+
 def test_plan_create_rejects_block_variants_the_reference_does_not_have():
     """mimo_config.norm_kind / act_kind / up_kind: 0 = BatchNorm2d + ReLU + bilinear align_corners, the reference's
     blocks and the only implemented ones; anything else is MIMO_ERR_INVALID with a message, not silently BatchNorm."""

@@ -22,6 +22,7 @@ VARIANTS = {
         "MIMO_SKIP_GRAD_IN_PLACE": "0",    # skip-connection gradients copied out by fold_slice
         "MIMO_POOL_FUSED": "0",            # separate MaxPool2d pass after BatchNorm + ReLU
         "MIMO_FUSE_BN_IN": "0",            # the activation between the two convolutions of a block materialised
+        "MIMO_FUSE_BWD_SRC": "0",          # pool_bwd / head_bwd as separate kernels writing the gradient tensors
     },
     "specialised_kernels_plain": {
         "MIMO_CONV_WIDE": "0",             # 256-pixel kernels everywhere ...
