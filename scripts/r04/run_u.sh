@@ -1,0 +1,19 @@
+#!/bin/bash
+# round-4 GPU call U: BatchNorm-backward passes with 4 pixels in flight per thread: parity, grid scan, step A/B against HEAD~
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r04_u
+mkdir -p $O
+cd $R
+true || timeout 900 python -m pytest tests/test_network_gpu.py tests/test_ops_gpu.py -x -q -m gpu -k "golden or pool_and_head or bit_identical or fgsm or bn or odd" > $O/pytest.txt 2>&1
+tail -3 $O/pytest.txt
+one() {
+  python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=l['roofline']; b=r['bandwidth_kernels']['kernels']; print('$1', l['value'], l['ms_per_step'], 'bw', r['bandwidth_kernels']['ms_per_step'], 'reduce', b['bn_bwd_reduce']['ms_per_step'], 'apply', b['bn_bwd_apply']['ms_per_step'])" >> $O/step_ab.txt
+}
+for i in 1 2; do
+  MIMO_BN_BLOCKS_R=448 MIMO_BN_BLOCKS_A=1792 one "un2-R448-A1792"
+  MIMO_BN_BLOCKS_R=384 MIMO_BN_BLOCKS_A=1536 one "un2-R384-A1536"
+  MIMO_BN_BLOCKS_R=256 MIMO_BN_BLOCKS_A=1280 one "un2-R256-A1280"
+  MIMO_HIP_LIB=$R/build/variants/libmimo_prev.so one "previous-build"
+done
+cat $O/step_ab.txt
