@@ -1,6 +1,10 @@
-"""Random geometries through the public model surface: the activation elision of round 4 (MIMO_FUSE_BN_IN=1, default —
-BatchNorm + ReLU applied by the readers' loaders) against every activation materialised (=0).  The arithmetic is the same, so
-predictions, loss and every gradient must be BIT-identical.  Diagnostic for the GPU box, not a test:
+"""Random geometries through the public model surface, two fusions of round 4 against their unfused forms:
+  * the activation elision (MIMO_FUSE_BN_IN=1, default — BatchNorm + ReLU applied by the readers' loaders) against every
+    activation materialised (=0): the arithmetic is the same, so predictions, loss and every gradient must be BIT-identical;
+  * the gradients of pooled tensors / of the head input formed by the BatchNorm backward (MIMO_FUSE_BWD_SRC=1, default)
+    against pool_bwd / head_bwd as separate kernels (=0): the same per-element values, per-channel sums grouped
+    differently — forward quantities and buffers bit-identical, every gradient within 1e-4 of its scale (printed: worst).
+Diagnostic for the GPU box, not a test:
     python tests/tools/fuzz_fusion.py [cases=20] [seed=0]"""
 import os
 import random
@@ -13,8 +17,9 @@ sys.path.insert(0, ROOT)
 from mimo.models.mimo_unet import MimoUnetModel  # noqa: E402
 
 
-def run(flag, args, state, image, label, perms, rng_state):
+def run(flag, args, state, image, label, perms, rng_state, bwd_src="1"):
     os.environ["MIMO_FUSE_BN_IN"] = flag  # read per plan
+    os.environ["MIMO_FUSE_BWD_SRC"] = bwd_src
     torch.manual_seed(0)
     m = MimoUnetModel(**args).cuda().train()
     m.load_state_dict(state)
@@ -22,7 +27,18 @@ def run(flag, args, state, image, label, perms, rng_state):
     torch.cuda.set_rng_state(rng_state)  # same Dropout2d draws
     out = m.training_step_with_perms(image, label, None, perms)
     out["loss"].backward()
-    return out["loss"].detach().clone(), out["preds"].clone(), m.model.flat_gradients().clone(), m.state_dict()
+    named = {n: p.grad.clone() for n, p in m.model.named_parameters()}
+    return out["loss"].detach().clone(), out["preds"].clone(), m.model.flat_gradients().clone(), m.state_dict(), named
+
+
+def worst_grad_deviation(a, b):
+    """max over parameters of max|a - b| / max|b| (pre-BatchNorm conv biases — zero gradients — on their weight's scale)"""
+    worst = 0.0
+    for n, y in b.items():
+        pre_bn_bias = "double_conv" in n and n.endswith((".0.bias", ".3.bias"))
+        scale = b[n[:-4] + "weight"] if pre_bn_bias else y
+        worst = max(worst, float((a[n] - y).abs().max()) / (float(scale.abs().max()) + 1e-30))
+    return worst
 
 
 def main():
@@ -53,9 +69,16 @@ def main():
         a = run("1", args, state, image, label, perms, st)
         b = run("0", args, state, image, label, perms, st)
         same = all(torch.equal(x, y) for x, y in zip(a[:3], b[:3])) and all(torch.equal(a[3][k], b[3][k]) for k in a[3])
-        bad += not same
-        print(f"S={S} f={f:2d} N={N} {H}x{W} Ci={Ci} drop={drop}: {'bit-identical' if same else 'MISMATCH   <-- CHECK'}", flush=True)
+        c = run("1", args, state, image, label, perms, st, bwd_src="0")
+        fwd_same = torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and all(torch.equal(a[3][k], c[3][k]) for k in a[3])
+        dev = worst_grad_deviation(a[4], c[4])
+        ok = same and fwd_same and dev <= 1e-4
+        bad += not ok
+        print(f"S={S} f={f:2d} N={N} {H}x{W} Ci={Ci} drop={drop}: elision {'bit-identical' if same else 'MISMATCH   <-- CHECK'}; "
+              f"gradient sources: forward {'bit-identical' if fwd_same else 'MISMATCH   <-- CHECK'}, worst gradient deviation {dev:.1e}"
+              f"{'' if dev <= 1e-4 else '   <-- CHECK'}", flush=True)
     os.environ.pop("MIMO_FUSE_BN_IN", None)
+    os.environ.pop("MIMO_FUSE_BWD_SRC", None)
     print("mismatches:", bad)
     return 1 if bad else 0
 
