@@ -84,6 +84,10 @@ static inline void wg_tiles(int cin_p, int cout_p, bool ws_enabled, int* CI, int
   // the wave-specialised kernel (64 input channels per workgroup) also comes 32 and 48 output channels wide and keeps
   // its efficiency there: take the 48-wide tile whenever it saves >= 15 % of padded work
   if (*CI == 64 && ws_enabled && cout_p > 32 && rup(cout_p, 48) <= 0.85 * rup(cout_p, 64)) *CO = 48;
+  // ... and it comes 32 input channels wide (4-row tiles): slower per padded MFMA (~320 against ~400 TFLOP/s), so only where
+  // 32-channel tiles save >= 20 % of padded work — 90 -> 45 at 256x256 (96 instead of 128 padded input channels: weight
+  // gradient 577 -> ~500 us, step -0.2 ms in three alternating pairs, round 4), 84-channel inputs of fbc = 21
+  if (*CI == 64 && ws_enabled && rup(cin_p, 32) <= 0.80 * rup(cin_p, 64)) *CI = 32;
 }
 static inline bool wg_use_ws(int CI, int CO, bool ws_enabled) {
   return ws_enabled && (CI == 64 || CI == 32) && (CO == 32 || CO == 48 || CO == 64);

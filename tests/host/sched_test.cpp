@@ -167,6 +167,17 @@ static void test_pinned_decisions() {
       {4, 32, 960, 480, 32, true, 2},   // 16-bit storage: the wide kernel takes nearly everything
       {5, 32, 480, 960, 34, true, 2},
   };
+  {  // weight-gradient channel tiles (input, output): 32-wide input tiles only where they save >= 20 % of padded work
+    struct T { int cin_p, cout_p, CI, CO; };
+    const T tiles[] = {{96, 48, 32, 48}, {88, 168, 32, 64}, {48, 32, 64, 32}, {32, 32, 32, 32}, {64, 64, 64, 64},
+                       {120, 64, 64, 64}, {480, 480, 64, 64}, {160, 48, 64, 48}};
+    for (const T& t : tiles) {
+      int CI = 0, CO = 0;
+      wg_tiles(t.cin_p, t.cout_p, true, &CI, &CO);
+      CHECK(CI == t.CI && CO == t.CO, "pinned weight-gradient tiles for %d x %d: %d x %d (expected %d x %d)", t.cin_p, t.cout_p, CI, CO, t.CI,
+            t.CO);
+    }
+  }
   for (const D& d : pins) {
     const WideCfg c = wide_config(d.mode, d.N, d.K, d.rows, d.H, d.H, 0);
     CHECK((c.nf != 0) == d.wide && (!d.wide || c.nf == d.nf), "pinned decision mode %d N %d %d->%d @%d: nf %d (expected %s nf %d)",
