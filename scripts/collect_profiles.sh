@@ -36,5 +36,10 @@ done
 rm -rf "$OUT/trace"
 python3 "$R/scripts/pmc_traffic.py" "$OUT" 3 > /dev/null 2>&1
 unset MIMO_WGRAD_STREAM
+# PMC_INSTALL_DIR (repo-relative, e.g. profiles/r04/final): put the fresh counter summary where bench.py looks for it (on the
+# box's scratch copy of the repo), so that the final bench line below carries the traffic of THIS build
+if [ -n "${PMC_INSTALL_DIR:-}" ] && [ -f "$OUT/pmc_traffic.json" ]; then
+  mkdir -p "$R/$PMC_INSTALL_DIR" && cp "$OUT/pmc_traffic.json" "$R/$PMC_INSTALL_DIR/pmc_traffic.json"
+fi
 cd "$R" && python3 bench.py $BENCH_ARGS --steps ${FINAL_STEPS:-20} --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json"

@@ -11,7 +11,7 @@ case "$PART" in
   A)
     mkdir -p gpurun_out/r04_final
     MIMO_PARITY_LOG=$R/gpurun_out/r04_final/parity_errors.txt python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/r04_final/pytest.txt
-    bash scripts/collect_profiles.sh r04_final
+    PMC_INSTALL_DIR=profiles/r04/final bash scripts/collect_profiles.sh r04_final
     ;;
   B)
     bash scripts/collect_other_configs.sh
