@@ -134,6 +134,8 @@ struct WideCfg {
   int TR, TC;
 };
 
+static inline int wide_grid_x(int numTiles, int cotiles);
+
 // Which decomposition a split16 3x3 convolution runs on.  `rows` = output channels of the launch (forward: Cout;
 // data gradient: the layer's padded input channels), Ho x Wo its output domain.
 // force: -1 = never, 0 = by the cost rule, 1 = whenever the geometry is supported.
@@ -170,9 +172,24 @@ static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, 
     const double eff_o = double(Ho) * Wo / (double(cdiv(Ho, TRo)) * cdiv(Wo, TCo) * 256);
     const int tail = cin_p - 32 * (cdiv(cin_p, 32) - 1);
     const double k_o = 32.0 * (cdiv(cin_p, 32) - 1) + ((tail <= 16 && !s16) ? 64.0 / 3.0 : 32.0);
-    const double t_w = double(k16) * (cotiles * nf * 32) / eff * (1.0 + (nf == 2 ? 1.2 : 0.2) / (k16 / (s16 ? 32 : 16)));
+    double t_w = double(k16) * (cotiles * nf * 32) / eff * (1.0 + (nf == 2 ? 1.2 : 0.2) / (k16 / (s16 ? 32 : 16)));
     // (16-bit storage modes, one MFMA per product: the 256-pixel kernel is bound by its staging there, x 1.45)
-    const double t_o = (s16 ? 1.45 : 1.15) * k_o * rup(rows, 16) / eff_o;
+    double t_o = (s16 ? 1.45 : 1.15) * k_o * rup(rows, 16) / eff_o;
+    // Both kernels are persistent grids of (pixel-tile columns x channel tiles) workgroups that all walk the same number
+    // of tiles: a launch whose tile count just exceeds one round leaves CUs without a workgroup (4 images per GPU,
+    // 480 -> 240 data gradient at 64x64: 36 wide tiles x 8 channel tiles = 18 x 8 = 144 workgroups of 2 tiles each, 136 us
+    // against 104 us on the 256-pixel kernel's 230 workgroups; round 4).  Price both by the CUs they occupy.
+    {
+      const int cu_w = wide_grid_x(tiles, cotiles) * cotiles;
+      const int nf_o = conv_pick_nfrag(rows);
+      const int cot_o = cdiv(cdiv(rows, 16), nf_o);
+      const int tiles_o = N * cdiv(Ho, TRo) * cdiv(Wo, TCo);
+      int gx_o = 256 / cot_o > 0 ? 256 / cot_o : 1;
+      if (gx_o > tiles_o) gx_o = tiles_o;
+      const int cu_o = cdiv(tiles_o, cdiv(tiles_o, gx_o)) * cot_o;
+      t_w *= 256.0 / (cu_w < 256 ? cu_w : 256);
+      t_o *= 256.0 / (cu_o < 256 ? cu_o : 256);
+    }
     // the wide kernel is persistent with one workgroup per CU and nothing overlaps its pipeline fill: it needs a
     // (pixel tile, channel tile) pair for every CU and >= 8 K chunks of work per workgroup (at 4 images per GPU the
     // 64x64 layers have 128 pairs and 30->30 at 256x256 two 2-chunk tiles per workgroup: measured 4.5 % of the step)

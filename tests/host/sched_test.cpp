@@ -164,6 +164,8 @@ static void test_pinned_decisions() {
       {0, 32, 32, 32, 258, true, 1},    // 30->30 data gradient
       {1, 4, 32, 30, 256, false, 0},    // 4 images per GPU: two 2-chunk tiles per workgroup do not pay for a persistent kernel
       {1, 4, 240, 240, 64, false, 0},   // ... and 32 pixel tiles x 4 channel tiles leave half the CUs idle
+      {0, 32, 240, 480, 66, true, 2},   // up2.c1 data gradient at batch 32: wide
+      {0, 4, 240, 480, 66, false, 0},   // ... at 4 images per GPU its 36 x 8 tiles fill 144 workgroups of 2 tiles: the 256-pixel kernel's 230 win (136 -> 104 us)
       {4, 32, 960, 480, 32, true, 2},   // 16-bit storage: the wide kernel takes nearly everything
       {5, 32, 480, 960, 34, true, 2},
   };
