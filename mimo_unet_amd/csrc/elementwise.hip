@@ -1306,31 +1306,31 @@ __global__ __launch_bounds__(kBnReduceThreads) void bnrelu_bwd_reduce_kernel(
             a2.w += g[j].w * (zz[j].w - mu.w) * is.w;
           }
       }
-    }
-    const int P = SRC == GS_POOL ? 0 : N * H * W;
-    PixIter it = pix_iter(t.p, t.pstep, H, W);
-    for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
-      const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
-      float d0 = 0.f, d1 = 0.f;
-      float4 g = f4zero();
-      if constexpr (SRC != GS_POOL) g = relu_grad4<SRC, TZ, TA>(src, hl, mask, C, p, it, t.q, H, W, v, sc, sh, &d0, &d1);
-      a1 = f4add(a1, g);
-      a2.x += g.x * (v.x - mu.x) * is.x;
-      a2.y += g.y * (v.y - mu.y) * is.y;
-      a2.z += g.z * (v.z - mu.z) * is.z;
-      a2.w += g.w * (v.w - mu.w) * is.w;
-      if constexpr (SRC == GS_HEAD) {  // the head's input is this tensor's activation (no dropout on this path)
-        const float4 av = bn_relu4(v, sc, sh);
-        hw0.x = fmaf(d0, av.x, hw0.x);
-        hw0.y = fmaf(d0, av.y, hw0.y);
-        hw0.z = fmaf(d0, av.z, hw0.z);
-        hw0.w = fmaf(d0, av.w, hw0.w);
-        hw1.x = fmaf(d1, av.x, hw1.x);
-        hw1.y = fmaf(d1, av.y, hw1.y);
-        hw1.z = fmaf(d1, av.z, hw1.z);
-        hw1.w = fmaf(d1, av.w, hw1.w);
-        hb0 += d0;
-        hb1 += d1;
+    } else {
+      const int P = N * H * W;
+      PixIter it = pix_iter(t.p, t.pstep, H, W);
+      for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
+        const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
+        float d0 = 0.f, d1 = 0.f;
+        const float4 g = relu_grad4<SRC, TZ, TA>(src, hl, mask, C, p, it, t.q, H, W, v, sc, sh, &d0, &d1);
+        a1 = f4add(a1, g);
+        a2.x += g.x * (v.x - mu.x) * is.x;
+        a2.y += g.y * (v.y - mu.y) * is.y;
+        a2.z += g.z * (v.z - mu.z) * is.z;
+        a2.w += g.w * (v.w - mu.w) * is.w;
+        if constexpr (SRC == GS_HEAD) {  // the head's input is this tensor's activation (no dropout on this path)
+          const float4 av = bn_relu4(v, sc, sh);
+          hw0.x = fmaf(d0, av.x, hw0.x);
+          hw0.y = fmaf(d0, av.y, hw0.y);
+          hw0.z = fmaf(d0, av.z, hw0.z);
+          hw0.w = fmaf(d0, av.w, hw0.w);
+          hw1.x = fmaf(d1, av.x, hw1.x);
+          hw1.y = fmaf(d1, av.y, hw1.y);
+          hw1.z = fmaf(d1, av.z, hw1.z);
+          hw1.w = fmaf(d1, av.w, hw1.w);
+          hb0 += d0;
+          hb1 += d1;
+        }
       }
     }
   }
