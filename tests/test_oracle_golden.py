@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle import mimo_oracle as O
-from tests.helpers import AMP_CASES, amp_reference, cfg_from_meta, grads_rel_l2, load_npz, rel_err, state_from
+from tests.helpers import (ADAM_FLIP_RMS, AMP_CASES, adam_flip_statistic, amp_reference, cfg_from_meta, grads_rel_l2, is_prebn_bias,
+                           load_npz, rel_err, state_from)
 
 TOL = 2e-5  # oracle and reference run the same torch leaf ops; only op order differs
 
@@ -70,6 +71,34 @@ def test_train_steps_match_reference(name):
             assert float(d.max()) <= 0.2 * budget + 1e-5 * float(np.abs(ref).max()), (k, float(d.max()))
             assert float(np.sqrt((d ** 2).mean())) <= 0.01 * budget, (k, float(np.sqrt((d ** 2).mean())))
     np.testing.assert_allclose(ts.loss_buffer.buffer.numpy(), fx["final/loss_buffer"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,lo,hi", [("cfg1_step.npz", 0.05, 0.16), ("mini_s2_step.npz", 0.0, 0.05)])
+def test_adam_sign_flip_statistic_of_the_reference_itself(name, lo, hi):
+    """Where the GPU tests' bound on the final parameters comes from (helpers.ADAM_FLIP_RMS = 0.2): the restatement run in
+    fp64 against the reference's fp32 fixture — the same network, the same steps, only the rounding differs — already moves
+    rms(|final parameter - fixture|) / (steps * lr) to 0.12 on cfg1's worst tensors (Adam's normalised update turns a
+    rounding-level gradient difference near zero into a +-lr step).  A HIP result within 0.2 is as close to the fixture as
+    exact arithmetic is."""
+    fx = load_npz(name)
+    cfg = cfg_from_meta(fx["meta"])
+    steps, lr, wd = int(fx["meta"][8]), float(fx["lr"]), float(fx["wd"])
+    st = {k: (v.double() if v.is_floating_point() else v) for k, v in state_from(fx, "init/").items()}
+    ts = O.TrainState(cfg=cfg, st=st, loss_kind=str(fx["loss_kind"]), lr=lr, weight_decay=wd,
+                      loss_buffer=O.LossBuffer(cfg.num_subnetworks, float(fx["temperature"]), 10))
+    for it in range(steps):
+        t = lambda k: torch.from_numpy(fx[k]).double() if k in fx else None
+        O.train_step(ts, t(f"s{it}/image"), t(f"s{it}/label"), t(f"s{it}/mask"), torch.from_numpy(fx[f"s{it}/perms"]))
+    worst = 0.0
+    for k, v in fx.items():
+        n = k[len("final/"):]
+        if not k.startswith("final/") or k == "final/loss_buffer" or n.endswith(("num_batches_tracked", "running_mean", "running_var")):
+            continue
+        if is_prebn_bias(n) or v.size < 256:
+            continue
+        worst = max(worst, adam_flip_statistic(ts.st[n].numpy(), v, steps * lr))
+    assert lo <= worst <= hi, worst
+    assert worst < ADAM_FLIP_RMS
 
 
 def test_bn_buffers_after_first_step():
