@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := mimo_unet_amd/csrc
-SRCS := $(CSRC)/conv3x3.hip $(CSRC)/conv_bf16x3.hip $(CSRC)/conv_wide.hip $(CSRC)/wgrad_split.hip $(CSRC)/elementwise.hip $(CSRC)/optim.hip $(CSRC)/plan.hip $(CSRC)/ops_api.hip
+SRCS := $(CSRC)/conv3x3.hip $(CSRC)/conv_thin.hip $(CSRC)/conv_bf16x3.hip $(CSRC)/conv_wide.hip $(CSRC)/wgrad_split.hip $(CSRC)/elementwise.hip $(CSRC)/optim.hip $(CSRC)/plan.hip $(CSRC)/ops_api.hip
 OBJS := $(SRCS:.hip=.o)
 LIB := mimo_unet_amd/libmimo_hip.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function

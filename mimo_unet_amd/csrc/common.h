@@ -86,6 +86,15 @@ struct ConvLaunch {
 int conv3x3_split_fuses_input(int mode, int wide, int Ho, int Wo);
 // returns number of partial-stat rows (spatial blocks) through *rows when stats != nullptr
 int conv3x3_launch(const ConvLaunch& a, int* rows, hipStream_t stream);
+// plain-FMA kernels for the image convolution (conv_thin.hip; cin = the logical input channels, 1..4, stored in channels
+// [0, cin) of x): the forward on the same ConvLaunch (a.w, the inference epilogue, one BatchNorm partial row per workgroup),
+// and the weight gradient from an fp32 dz into torch's OIHW layout (partial: wgrad_thin_scratch floats)
+int conv3x3_thin_ok(int cin, int cout_p);
+int conv3x3_thin_launch(const ConvLaunch& a, int cin, int* rows, hipStream_t stream);
+size_t wgrad_thin_scratch(int cin, int cout_p);
+int wgrad_thin_ok(int cin, int cout_p, int N, int H, int W);  // the weight gradient too (few channels, many tiles)
+int wgrad_thin_launch(const float* x, int ldx, const float* dz, int lddz, int N, int H, int W, int cin, int cout, int cout_p,
+                      float* partial, float* dw, hipStream_t stream);
 // split 16-bit variant (conv_bf16x3.hip): same ConvLaunch, reads a.wpk instead of a.w.
 // mode 0: split16 data gradient (bf16 pairs, pre-split input); 1: split16 forward (fp16 pairs);
 // 2: bf16 forward (one MFMA per product); 3: bf16 data gradient

@@ -112,7 +112,7 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   float* bp = t.get<float>(cout_pad);
   int* rm = t.ints(ident_map(cout_pad, cout));
   int* cm = t.ints(ident_map(cin_p, cin));
-  const int rows_cap = std::max(conv3x3_stat_rows(n, h, wd), conv3x3_ws_stat_rows(n, h, wd));
+  const int rows_cap = std::max(std::max(conv3x3_stat_rows(n, h, wd), conv3x3_ws_stat_rows(n, h, wd)), 2048);
   float* partial = t.get<float>((size_t)rows_cap * 2 * cout_pad);
   double* sums = t.get<double>((size_t)kMaxChunks * 2 * cout_pad);
   if (!wf || !bp || !rm || !cm || !partial || !sums) {
@@ -164,7 +164,10 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   a.pair = pair;
   a.wide = wide;
   int rows = 0;
-  if (split)
+  // (an image convolution — <= 4 input channels in an 8-channel pixel — runs on the plain-FMA kernel, as in the plan)
+  if (!mixed && cin_p < 16 && conv3x3_thin_ok(cin, cout_p))
+    MIMO_TRY(conv3x3_thin_launch(a, cin, &rows, st));
+  else if (split)
     MIMO_TRY(conv3x3_bf16x3_launch(a, fmode, &rows, st));
   else
     MIMO_TRY(conv3x3_launch(a, &rows, st));
@@ -272,6 +275,20 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
   const bool mixed = is_mixed(precision), f16s = precision == MIMO_PREC_FP16_MIXED;
   const bool split = precision == MIMO_PREC_SPLIT16 || precision == MIMO_PREC_BF16 || mixed;
   const bool bf16 = precision == MIMO_PREC_BF16;
+  if (!mixed && cin_p < 16 && wgrad_thin_ok(cin, cout_p, n, h, wd)) {  // the image convolution's kernel, as in the plan
+    float* part = t.get<float>(wgrad_thin_scratch(cin, cout_p));
+    if (!part) {
+      set_error("mimo_op_conv3x3_wgrad: allocation failed");
+      return MIMO_ERR_HIP;
+    }
+    MIMO_TRY(wgrad_thin_launch(x, cin_p, dz, cout_p, n, h, wd, cin, cout, cout_p, part, dw, st));
+    if (dbias) {
+      hipLaunchKernelGGL(colsum_naive_kernel, dim3(cout), dim3(256), 0, st, dz, (int64_t)n * h * wd, cout_p, cout, dbias);
+      MIMO_KERNEL_CHECK();
+    }
+    MIMO_HIP_CHECK(hipStreamSynchronize(st));
+    return MIMO_OK;
+  }
   WgradLaunch a;
   a.x = x;
   a.dz = dz;

@@ -83,6 +83,7 @@ struct ConvBN {
   float *wf = nullptr, *wd = nullptr, *bias_p = nullptr;
   void *wf16 = nullptr, *wd16 = nullptr;  // split-bf16 packed weights (MIMO_PREC_SPLIT16)
   bool fwd_split = false, dg_split = false, wg_split = false;
+  bool thin = false;  // image convolution (<= 4 input channels) on the plain-FMA kernels of conv_thin.hip
   int fwd_wide = 0, dg_wide = 0;  // != 0: the launch runs on conv_wide.hip, value = packed weight rows (conv3x3_wide_rows)
   int *cin_map = nullptr, *fwd_row_map = nullptr, *dg_row_map = nullptr, *dg_col_map = nullptr;
   float* z = nullptr;
@@ -409,6 +410,12 @@ struct mimo_plan {
     L.fwd_split = mfma16 && L.cin_p >= (mixed ? 8 : 16);
     L.dg_split = mfma16 && (mixed || L.cout_p >= 16);
     L.dtz = L.fwd_split ? st : ST_F32;
+    {
+      bool ident = true;  // (the packed image: logical channel i in padded channel i)
+      for (int i = 0; i < Cin; ++i) ident = ident && i < (int)in_chmap.size() && in_chmap[i] == i;
+      L.thin = !L.fwd_split && ident && conv3x3_thin_ok(Cin, L.cout_p);
+      if (L.thin && train_bufs) cap_slab = std::max(cap_slab, wgrad_thin_scratch(Cin, L.cout_p));
+    }
     if (L.wg_split && !L.dg_split) any_mixed_dz = true;
     if (cfg.precision == MIMO_PREC_SPLIT16 || mixed) {  // decomposition per layer and direction (sched::wide_config)
       if (L.fwd_split) L.fwd_wide = conv3x3_wide_rows(fwd_mode(), n, L.cin_p, L.cout_p, h, w);
@@ -882,6 +889,8 @@ struct mimo_plan {
     int pr = prof_begin(MIMO_PROF_CONV_FWD, st);
     if (L.fwd_split)
       MIMO_TRY(conv3x3_bf16x3_launch(a, fwd_mode(), &rows, st));
+    else if (L.thin)
+      MIMO_TRY(conv3x3_thin_launch(a, L.Cin, &rows, st));
     else
       MIMO_TRY(conv3x3_launch(a, &rows, st));
     prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);
@@ -1180,15 +1189,18 @@ struct mimo_plan {
       dz_idx = (dz_idx + 1) % wg_bufs;
       if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
     }
+    // the image convolution's weight gradient on the plain-FMA kernel reads dz as fp32 (no data gradient wanted: nothing
+    // else reads this dz)
+    const bool thin_wg = L.thin && !mixed && !need_dgrad && wgrad_thin_ok(L.Cin, L.cout_p, L.N, L.H, L.W);
     pr = prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
     MIMO_TRY(bn_bwd_apply_launch(src, this->st, L.z, L.dtz, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
-                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, (L.dg_split && !mixed) ? 1 : 0,
+                                 L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, (L.dg_split && !mixed && !thin_wg) ? 1 : 0,
                                  fwd_training ? nullptr : s_partial, &rows, st));
     prof_end(pr, 0.0, (8.0 + src_b) * (double)P * L.cout_p, st);
     // dz storage: bf16 hi|lo pairs when the data-gradient kernel is the bf16-pair one (then the weight
     // gradient is too); fp32 otherwise, with a split copy for a bf16-pair weight gradient
     const float* dz_wg = dz;
-    if (L.wg_split && !L.dg_split) {
+    if (L.wg_split && !L.dg_split && !thin_wg) {
       float* dzs = s_dzs2[b];
       MIMO_TRY(split_pairs_launch(dz, dzs, P, L.cout_p, st));
       dz_wg = dzs;
@@ -1253,7 +1265,9 @@ struct mimo_plan {
     // 16-bit storage: activations and dz plain NHWC 16-bit; the image convolution's input stays fp32
     wg.store = !mixed ? 0 : (L.fwd_split ? (f16 ? 2 : 1) : (f16 ? 4 : 3));
     pr = prof_begin(MIMO_PROF_CONV_WGRAD, ws);
-    if (L.wg_split)
+    if (thin_wg)
+      MIMO_TRY(wgrad_thin_launch(L.in, L.ld_in, dz, L.cout_p, L.N, L.H, L.W, L.Cin, L.Cout, L.cout_p, s_wslab, grads + L.off_w, ws));
+    else if (L.wg_split)
       MIMO_TRY(wgrad_split_launch(wg, ws));
     else
       MIMO_TRY(wgrad_launch(wg, ws));
@@ -1262,8 +1276,9 @@ struct mimo_plan {
       MIMO_HIP_CHECK(hipEventRecord(ev_wg[b], wg_stream));
       wg_pending[b] = true;
     }
-    MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
-                                 grads + L.off_w, ws));
+    if (!thin_wg)  // (the plain-FMA kernel's launch reduces its own partials)
+      MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
+                                   grads + L.off_w, ws));
     return MIMO_OK;
   }
 

@@ -73,8 +73,8 @@ def report(d):
     fn = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[0]
     rows = list(csv.DictReader(open(fn)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    convs = [r for r in rows if ("conv3x3_" in r["Kernel_Name"] or "wgrad_split" in r["Kernel_Name"] or "wgrad_mfma" in r["Kernel_Name"])
-             and "pack" not in r["Kernel_Name"]]
+    convs = [r for r in rows if ("conv3x3_" in r["Kernel_Name"] or "wgrad_split" in r["Kernel_Name"] or "wgrad_mfma" in r["Kernel_Name"]
+                                 or "wgrad_thin_kernel" in r["Kernel_Name"]) and "pack" not in r["Kernel_Name"]]
     labels = open(os.path.join(d, "labels.txt")).read().split("\n")[:-1]
     assert len(convs) == len(labels), (len(convs), len(labels))
     # MIMO_LAYER_BENCH_STAT: min (default: burst speed of a cool chip) | median | tail (mean of the last quarter of

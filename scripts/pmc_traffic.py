@@ -23,7 +23,9 @@ def cls(k):
     if "conv3x3_ws_kernel" in k or "conv3x3_bf16x3_kernel" in k or "conv3x3_wide_kernel" in k:
         mode = int(k.split("<")[1].split(",")[2 if "bf16x3" in k else 1].strip(" >"))  # MODE template argument
         return "conv3x3_fwd" if mode in (1, 2, 4, 6) else "conv3x3_dgrad"
-    return "conv3x3_wgrad" if "wgrad_split" in k else None
+    if "conv3x3_thin_fwd_kernel" in k:  # the image convolution's plain-FMA kernels (conv_thin.hip)
+        return "conv3x3_fwd"
+    return "conv3x3_wgrad" if ("wgrad_split" in k or "wgrad_thin_kernel" in k) else None
 
 
 F, W = load(D + "pmc_FETCH_SIZE.csv"), load(D + "pmc_WRITE_SIZE.csv")

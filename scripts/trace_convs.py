@@ -33,7 +33,7 @@ step = rows[adam[-2]:adam[-1]]
 
 
 def is_conv(k):
-    return ("conv3x3_" in k or "conv_image_" in k or "wgrad_split" in k or "wgrad_kernel" in k or "wgrad_mfma" in k) and "reduce" not in k \
+    return ("conv3x3_" in k or "conv_image_" in k or "wgrad_split" in k or "wgrad_kernel" in k or "wgrad_mfma" in k or "wgrad_thin_kernel" in k) and "reduce" not in k \
         and "group_sum" not in k and "pack" not in k
 
 

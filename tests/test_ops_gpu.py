@@ -39,6 +39,8 @@ CONV_CASES = [
     (2, 32, 32, 2, 30), (2, 32, 32, 3, 21), (1, 64, 64, 30, 30), (2, 16, 16, 45, 30), (1, 32, 48, 90, 45),
     (1, 16, 16, 120, 240), (2, 20, 12, 21, 42), (1, 50, 70, 8, 8), (3, 6, 7, 16, 33), (1, 2, 2, 8, 16),
     (1, 3, 5, 4, 4), (1, 128, 128, 4, 60),
+    # the image convolution's plain-FMA kernels (conv_thin.hip: 1..4 input channels; 8 x 32-pixel tiles, edges)
+    (2, 20, 12, 1, 12), (1, 9, 33, 2, 30), (3, 17, 70, 2, 21),
     # last 32-channel chunk with <= 16 channels on the persistent kernel: tap-paired K steps (three chunks; one chunk)
     (1, 40, 40, 75, 30), (2, 24, 24, 13, 75),
     # shapes of the wide decomposition (conv_wide.hip: 512-pixel tiles, 16-channel chunks; forced on the small cases by

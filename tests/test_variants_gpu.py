@@ -23,6 +23,7 @@ VARIANTS = {
         "MIMO_POOL_FUSED": "0",            # separate MaxPool2d pass after BatchNorm + ReLU
         "MIMO_FUSE_BN_IN": "0",            # the activation between the two convolutions of a block materialised
         "MIMO_FUSE_BWD_SRC": "0",          # pool_bwd / head_bwd as separate kernels writing the gradient tensors
+        "MIMO_CONV_THIN": "0",             # the image convolution on the fp32 MFMA kernels / the split weight gradient
     },
     "specialised_kernels_plain": {
         "MIMO_CONV_WIDE": "0",             # 256-pixel kernels everywhere ...
@@ -32,6 +33,7 @@ VARIANTS = {
         "MIMO_WGRAD_SPLIT_MODE": "0",      # fixed split count of the weight gradient
     },
     "conv_wide_forced": {"MIMO_CONV_WIDE": "2"},  # every supported convolution on conv_wide.hip
+    "image_conv_wgrad_forced": {"MIMO_CONV_THIN": "2"},  # 1-2-channel weight gradients on conv_thin.hip at every size
 }
 
 
