@@ -83,7 +83,7 @@ def report(d):
     every = {}
     for lab, r in zip(labels, convs):
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        k = r["Kernel_Name"].split("(")[0].replace("void mimo::", "")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void mimo::", "")
         every.setdefault(lab, []).append((us, k))
     best = {}
     for lab, v in every.items():

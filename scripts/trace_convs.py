@@ -56,7 +56,7 @@ tot = {}
 for (l, kind), r in zip(seq, convs):
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     fl = 18.0 * l[1] * l[2] * N * l[3] * l[4]
-    k = r["Kernel_Name"].split("(")[0].replace("void mimo::", "")
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void mimo::", "")
     print(f"{l[0]:12s} {kind:5s} {l[1]:4d}->{l[2]:4d} @{l[3]:3d}  {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s   {k}")
     t = tot.setdefault(kind, [0.0, 0.0])
     t[0] += us
