@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const float* __restrict
                                                          int lddz, int N, int H, int W, int Cv, int tilesY, int tilesX,
                                                          int numTiles, float* __restrict__ partial) {
   constexpr int CP = Px<CIN>::N;
-  constexpr int kG = 8;  // dz values of a tile per thread fetched together (Cv >= 8: all of them)
+  constexpr int kG = 4;  // dz values of a tile per thread fetched together (8: two waves per SIMD, 94 us; 4: three, 86 us; 2: four, 92 us)
   __shared__ __attribute__((aligned(16))) float xs[2][kHaloPix * CP];
   __shared__ float4 red[256];
   const ThinMap t = thin_map(Cv);

@@ -178,7 +178,9 @@ static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, 
     // Both kernels are persistent grids of (pixel-tile columns x channel tiles) workgroups that all walk the same number
     // of tiles: a launch whose tile count just exceeds one round leaves CUs without a workgroup (4 images per GPU,
     // 480 -> 240 data gradient at 64x64: 36 wide tiles x 8 channel tiles = 18 x 8 = 144 workgroups of 2 tiles each, 136 us
-    // against 104 us on the 256-pixel kernel's 230 workgroups; round 4).  Price both by the CUs they occupy.
+    // against 104 us on the 256-pixel kernel's 230 workgroups; round 4).  Price both by the CUs they occupy — when that is
+    // fewer than three quarters of them: the batch-32 fit above already carries the ordinary few-percent quantisation
+    // (with the factor applied always, four batch-32 decisions flipped for a net +0.02 ms).
     {
       const int cu_w = wide_grid_x(tiles, cotiles) * cotiles;
       const int nf_o = conv_pick_nfrag(rows);
@@ -187,8 +189,8 @@ static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, 
       int gx_o = 256 / cot_o > 0 ? 256 / cot_o : 1;
       if (gx_o > tiles_o) gx_o = tiles_o;
       const int cu_o = cdiv(tiles_o, cdiv(tiles_o, gx_o)) * cot_o;
-      t_w *= 256.0 / (cu_w < 256 ? cu_w : 256);
-      t_o *= 256.0 / (cu_o < 256 ? cu_o : 256);
+      if (cu_w < 192) t_w *= 256.0 / cu_w;
+      if (cu_o < 192) t_o *= 256.0 / cu_o;
     }
     // the wide kernel is persistent with one workgroup per CU and nothing overlaps its pipeline fill: it needs a
     // (pixel tile, channel tile) pair for every CU and >= 8 K chunks of work per workgroup (at 4 images per GPU the
