@@ -491,3 +491,19 @@ def test_oracle_mixed_precision_emulation_inserts_the_storage_roundings():
     cos = torch.nn.functional.cosine_similarity(res["16-mixed"][2], res["fp32"][2], dim=0).item()
     assert cos > 0.97
     assert O._STORE16 is None and O._CONV_OPERANDS == "fp32"  # context managers restored the defaults
+
+
+def test_every_environment_switch_is_documented():
+    """README.md's switch table is the interface of the A/B switches: every MIMO_* variable the library, the host mirror or
+    bench.py reads is listed there, and nothing is listed that no code reads."""
+    import glob
+    import re
+    code = set()
+    for f in glob.glob(os.path.join(ROOT, "mimo_unet_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mimo_unet_amd", "csrc", "*.h")):
+        code |= set(re.findall(r'getenv\("(MIMO_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in glob.glob(os.path.join(ROOT, "mimo_unet_amd", "**", "*.py"), recursive=True) + [os.path.join(ROOT, "bench.py")]:
+        code |= set(re.findall(r'environ[^\n]*?"(MIMO_[A-Z0-9_]+)"', open(f).read()))
+    doc = set(re.findall(r"`(MIMO_[A-Z0-9_]+)`", open(os.path.join(ROOT, "README.md")).read()))
+    test_only = {"MIMO_PARITY_LOG"}  # read by tests/helpers.py only
+    assert code - doc == set(), sorted(code - doc)
+    assert doc - code - test_only == set(), sorted(doc - code - test_only)
