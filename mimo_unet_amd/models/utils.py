@@ -13,25 +13,27 @@ _PINNED_RING = {}   # (k, device) -> {"slots": [[pinned int64 buffer, event of i
 _PINNED_DEPTH = 16  # uploads in flight per (k, device) before a draw waits for the oldest one
 
 
-def _cpu_randperm_on_device(k: int, device) -> torch.Tensor:
-    """`torch.randperm(k)` from the CPU generator — the reference draws the per-subnetwork shuffles there
-    (utils.py:31-34) and the parity tests replay its generator streams — delivered to `device` WITHOUT blocking the
-    host.  Indexing a GPU tensor with a pageable CPU index makes torch upload it with a blocking copy, which on ROCm
-    first drains the stream: one host / GPU synchronisation per training step, the host then never runs ahead of the
-    GPU and every step starts with an idle GPU (0.3-0.5 ms; found in round 3 with scripts/host_phases.py).  Here the
-    permutation is drawn straight into a pinned buffer (same generator, same values) and uploaded asynchronously; a
-    ring of buffers with one event each keeps a buffer from being redrawn before its upload has run."""
+def _cpu_randperms_on_device(k: int, count: int, device) -> torch.Tensor:
+    """`count` consecutive `torch.randperm(k)` draws from the CPU generator as one [count, k] tensor on `device` — the
+    reference draws the per-subnetwork shuffles there, one after the other (utils.py:31-34), and the parity tests replay
+    its generator streams — delivered WITHOUT blocking the host.  Indexing a GPU tensor with a pageable CPU index makes
+    torch upload it with a blocking copy, which on ROCm first drains the stream: one host / GPU synchronisation per
+    training step, the host then never runs ahead of the GPU and every step starts with an idle GPU (0.3-0.5 ms; found in
+    round 3 with scripts/host_phases.py).  Here the permutations are drawn straight into the rows of one pinned buffer
+    (same generator, same order, same values) and uploaded with one asynchronous copy; a ring of buffers with one event
+    each keeps a buffer from being redrawn before its upload has run."""
     if device is None or torch.device(device).type != "cuda":
-        return torch.randperm(k)
-    ring = _PINNED_RING.setdefault((k, str(torch.device(device))), {"slots": [], "next": 0})
+        return torch.stack([torch.randperm(k) for _ in range(count)], dim=0)
+    ring = _PINNED_RING.setdefault((k, count, str(torch.device(device))), {"slots": [], "next": 0})
     if len(ring["slots"]) < _PINNED_DEPTH:
-        ring["slots"].append([torch.empty(k, dtype=torch.int64).pin_memory(), None])
+        ring["slots"].append([torch.empty(count, k, dtype=torch.int64).pin_memory(), None])
         slot = ring["slots"][-1]
     else:
         slot = ring["slots"][ring["next"]]
         ring["next"] = (ring["next"] + 1) % _PINNED_DEPTH
         slot[1].synchronize()  # returns at once unless the host is more than _PINNED_DEPTH draws ahead of the GPU
-    torch.randperm(k, out=slot[0])
+    for s in range(count):
+        torch.randperm(k, out=slot[0][s])
     dev = slot[0].to(device, non_blocking=True)
     slot[1] = torch.cuda.Event()
     slot[1].record(torch.cuda.current_stream(device))  # the stream the upload was enqueued on
@@ -41,11 +43,16 @@ def _cpu_randperm_on_device(k: int, device) -> torch.Tensor:
 def draw_subnetwork_permutations(batch: int, num_subnetworks: int, input_repetition_probability: float = 0.0,
                                  batch_repetitions: int = 1, device=None) -> torch.Tensor:
     """[S, batch*reps] int64 gather indices: a main permutation of the batch, of which the first
-    (1 - irp) share is re-shuffled independently per subnetwork (utils.py:27-36)."""
-    main = torch.randperm(batch, device=device).repeat(batch_repetitions)
+    (1 - irp) share is re-shuffled independently per subnetwork (utils.py:27-36).  One upload and one gather for all S
+    rows (round 4: S uploads, S gathers, S concatenations and a stack were ~8 five-microsecond launches per step)."""
+    main = torch.randperm(batch, device=device)
+    if batch_repetitions != 1:
+        main = main.repeat(batch_repetitions)
     k = int(main.shape[0] * (1.0 - input_repetition_probability))
-    rows = [torch.cat((main[:k][_cpu_randperm_on_device(k, main.device)], main[k:]), dim=0) for _ in range(num_subnetworks)]
-    return torch.stack(rows, dim=0)
+    rows = main[:k][_cpu_randperms_on_device(k, num_subnetworks, main.device)]  # [S, k]
+    if k == main.shape[0]:
+        return rows
+    return torch.cat((rows, main[k:].unsqueeze(0).expand(num_subnetworks, -1)), dim=1)
 
 
 def gather_subnetworks(t: Optional[torch.Tensor], perms: torch.Tensor) -> Optional[torch.Tensor]:
