@@ -1,4 +1,5 @@
-# Builds libmimo_hip.so (gfx950) and the oracle's C helpers.  `python -c "import __graft_entry__ as g; g.build()"` calls this.
+# Builds libmimo_hip.so (gfx950).  `python -c "import __graft_entry__ as g; g.build()"` calls this.  (The oracle is pure
+# Python on torch's CPU operators and the reference has no native sources: nothing else to compile.)
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := mimo_unet_amd/csrc

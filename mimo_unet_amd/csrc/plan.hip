@@ -70,6 +70,11 @@ struct Act {
   // z_ld) and apply scale / shift + ReLU themselves (round 4; Up blocks without dropout in split16)
   const float *z = nullptr, *z_scale = nullptr, *z_shift = nullptr;
   int z_ld = 0;
+  // per forward call: the readers really go through z (set by dc_forward).  False — and `a` is written by the
+  // BatchNorm + ReLU pass as on any other block — whenever a multiplier acts on the activated tensor in this call: a
+  // caller-supplied Dropout2d mask on a block built with rate 0 (mimo_forward_args.drop_masks is honoured on every
+  // block), or an element-wise final-dropout mask on a decoder output
+  bool z_live = false;
 };
 
 struct ConvBN {
@@ -844,7 +849,8 @@ struct mimo_plan {
     return pack_jobs_launch(pack_jobs, with_dgrad ? n_all_jobs : n_fwd_jobs, pack_max_total, params, st);
   }
 
-  int convbn_forward(ConvBN& L, bool training, const float* mask, hipStream_t st) {
+  // elide: the activated tensor of this layer is not written in this call (its readers apply BatchNorm + ReLU to z)
+  int convbn_forward(ConvBN& L, bool training, const float* mask, bool elide, hipStream_t st) {
     // inference: BN(eval) + ReLU (+ channel-dropout) in the conv epilogue — not for the fp32-kernel image convolution
     // of the 16-bit storage modes, whose output type differs from the activation type
     const bool fused = fwd_no_grad && !(mixed && !L.fwd_split);
@@ -907,7 +913,7 @@ struct mimo_plan {
                                         cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
       }
     }
-    if (!fused && !(L.act_elided && training)) {
+    if (!fused && !elide) {
       pr = prof_begin(MIMO_PROF_BN_RELU_FWD, st);
       if (L.pool_out)
         MIMO_TRY(bn_relu_pool_fwd_launch(L.z, L.dtz, L.cout_p, L.a, this->st, L.ld_a, L.scale, L.shift, mask, L.Cout, L.cout_p, L.N,
@@ -935,8 +941,9 @@ struct mimo_plan {
     dc->out.z_shift = dc->c2.shift;
   }
 
-  int dc_forward(DoubleConv* dc, bool training, hipStream_t st) {
+  int dc_forward(DoubleConv* dc, bool training, hipStream_t st, bool elem_mask_on_output = false) {
     const int h = dc->c1.H, w = dc->c1.W;
+    dc->out.z_live = dc->c2.act_elided && dc->out.z && training && !fwd_no_grad && !dc->mask && !elem_mask_on_output;
     const int blk = prof_begin(kProfTierBase + 2 * tier_of(h), st);
     if (dc->kind == IN_POOL) {
       Act* s = dc->src0;
@@ -945,7 +952,7 @@ struct mimo_plan {
     } else if (dc->kind == IN_UPCAT) {
       Act *sk = dc->src0, *lo = dc->src1;
       const int pr = prof_begin(MIMO_PROF_UPCAT_FWD, st);
-      const bool lz = lo->z && training && !fwd_no_grad;  // the low-resolution tensor through its BatchNorm + ReLU
+      const bool lz = lo->z_live;  // the low-resolution tensor through its BatchNorm + ReLU
       MIMO_TRY(upcat_fwd_launch(dc->skip_in_place ? nullptr : sk->a, this->st, sk->ld, sk->Cp, lz ? lo->z : lo->a,
                                 lz ? lo->z_ld : lo->ld, lo->Cp, N, h, w, lo->H, lo->W, dc->in_buf, st, lz ? lo->z_scale : nullptr,
                                 lz ? lo->z_shift : nullptr));
@@ -953,8 +960,8 @@ struct mimo_plan {
       prof_end(pr, 0.0, 4.0 * lo->Cp * ((double)N * h * w + (double)N * lo->H * lo->W), st);
     }
 
-    MIMO_TRY(convbn_forward(dc->c1, training, nullptr, st));
-    MIMO_TRY(convbn_forward(dc->c2, training, dc->mask, st));
+    MIMO_TRY(convbn_forward(dc->c1, training, nullptr, dc->c1.act_elided && training, st));
+    MIMO_TRY(convbn_forward(dc->c2, training, dc->mask, dc->out.z_live, st));
     prof_end(blk, 0.0, 0.0, st);
     return MIMO_OK;
   }
@@ -1049,7 +1056,10 @@ struct mimo_plan {
     elem_masks.clear();
     MIMO_HIP_CHECK(hipGraphLaunch(*exec, st));
     MIMO_HIP_CHECK(hipMemcpyAsync(args->out, g_out, (size_t)N * S * Co * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
-    for (size_t i = 0; i < dcs.size(); ++i) dcs[i]->mask = args->drop_masks ? args->drop_masks[i] : nullptr;
+    for (size_t i = 0; i < dcs.size(); ++i) {
+      dcs[i]->mask = args->drop_masks ? args->drop_masks[i] : nullptr;
+      dcs[i]->out.z_live = false;  // (only eval-mode forwards replay a graph: every activated tensor was written)
+    }
     out = args->out;
     fwd_done = true;
     fwd_training = training_call;
@@ -1115,7 +1125,8 @@ struct mimo_plan {
     MIMO_TRY(dc_forward(up2, training, st));
     MIMO_TRY(dc_forward(up3, training, st));
     for (int s = 0; s < S; ++s) {
-      MIMO_TRY(dc_forward(up4[s], training, st));
+      // (an element-wise final dropout on a block whose output is elided by construction: this call materialises it)
+      MIMO_TRY(dc_forward(up4[s], training, st, elem_masks[1 + s] || elem_rng_on[1 + s]));
       const Act& o = up4[s]->out;
       // final_dropouts[s]: in place, the head (forward and weight gradient) is the only reader
       if (elem_masks[1 + s] || elem_rng_on[1 + s]) {
@@ -1125,11 +1136,7 @@ struct mimo_plan {
       }
       const int blk = prof_begin(kProfTierBase, st);
       const int pr = prof_begin(MIMO_PROF_HEAD_FWD, st);
-      const bool oz = o.z && training && !fwd_no_grad;
-      if (o.z && (elem_masks[1 + s] || elem_rng_on[1 + s])) {
-        set_error("mimo_forward: element-wise final dropout on a plan built with final_dropout_rate = 0");
-        return MIMO_ERR_INVALID;
-      }
+      const bool oz = o.z_live;
       MIMO_TRY(head_fwd_launch(oz ? o.z : o.a, this->st, oz ? o.z_ld : o.ld, params + heads[s].off_w, params + heads[s].off_b, f, Co,
                                N, S, s, H * W, args->out, st, d_status, oz ? o.z_scale : nullptr, oz ? o.z_shift : nullptr));
       prof_end(pr, 0.0, 4.0 * (double)N * H * W * (pad_channels(f) + Co), st);
@@ -1441,11 +1448,12 @@ struct mimo_plan {
           }
           const int blk = prof_begin(kProfTierBase + 1, st);
           const int pr = prof_begin(MIMO_PROF_HEAD_BWD, st);
-          // (z through scale / shift + ReLU gives the activated values whichever way the forward ran: identical bits)
+          // (the tensor the forward's head read: z through scale / shift + ReLU, or the materialised — possibly masked — one)
           const Act& o = dc->out;
-          MIMO_TRY(head_bwd_launch(o.z ? o.z : o.a, this->st, o.z ? o.z_ld : o.ld, params + heads[s].off_w, f, fp, Co, N, S, s, H * W,
+          const bool oz = o.z_live;
+          MIMO_TRY(head_bwd_launch(oz ? o.z : o.a, this->st, oz ? o.z_ld : o.ld, params + heads[s].off_w, f, fp, Co, N, S, s, H * W,
                                    out, dout, dloss, label, lmask, lperm, cfg.loss_kind, cfg.eps_min, cfg.eps_max, dc->out.da,
-                                   s_partial, &rows, st, o.z_scale, o.z_shift));
+                                   s_partial, &rows, st, oz ? o.z_scale : nullptr, oz ? o.z_shift : nullptr));
           prof_end(pr, 0.0, 4.0 * (double)N * H * W * (2.0 * fp + Co + Co / 2), st);
           MIMO_TRY(head_bwd_stats_launch(s_partial, rows, f, fp, Co, grads + heads[s].off_w, grads + heads[s].off_b, colsum(), st));
           if (em || elem_rng_on[1 + s]) {

@@ -28,12 +28,27 @@ def cls(k):
     return "conv3x3_wgrad" if ("wgrad_split" in k or "wgrad_thin_kernel" in k) else None
 
 
+# Kernels whose global reads are 16 B per lane (global_load_dwordx4 / LDS-DMA dwordx4 / float4 per thread): the access
+# pattern the guide's gfx950 correction is calibrated on (FETCH_SIZE tallies such a read at HALF its bytes -> x2).  Every
+# other kernel (statistics / reductions over partial rows, packing, torch's own kernels: 4- or 8-byte loads) is
+# uncalibrated: counted x1 in `step_bytes` and x2 in `step_bytes_upper`.
+WIDE_READERS = ("conv3x3_", "wgrad_split", "wgrad_thin_kernel", "bn_relu", "bnrelu_bwd_reduce", "bn_bwd_apply", "upcat_fwd",
+                "up_bwd", "pool_bwd", "head_fwd", "head_bwd_kernel", "loss_fwd", "adam_kernel", "amp_step_kernel", "maxpool_fwd",
+                "fold_slice", "split_pairs", "train_epilogue", "val_epilogue", "elem_mask_mul", "wgrad_group_sum", "wgrad_reduce")
+
+
+def read_factor(kernel):
+    return 2.0 if any(t in kernel for t in WIDE_READERS) else 1.0
+
+
 F, W = load(D + "pmc_FETCH_SIZE.csv"), load(D + "pmc_WRITE_SIZE.csv")
-agg, tot_r, tot_w = {}, 0.0, 0.0
+agg, tot_r, tot_w, narrow_r = {}, 0.0, 0.0, 0.0
 for k, (n, c) in F.items():
     if "rocclr" in k:
         continue  # one-off zero fills at plan creation
-    r = c["FETCH_SIZE"] * 1024 * 2  # KB; x2: gfx950 tallies a wide coalesced read at half its bytes
+    r = c["FETCH_SIZE"] * 1024 * read_factor(k)  # KB; x2 where gfx950 tallies a wide coalesced read at half its bytes
+    if read_factor(k) == 1.0:
+        narrow_r += r
     w = W.get(k, (0, {"WRITE_SIZE": 0.0}))[1]["WRITE_SIZE"] * 1024
     tot_r, tot_w = tot_r + r, tot_w + w
     c_ = cls(k)
@@ -45,7 +60,8 @@ for k, (n, c) in F.items():
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
                  "--warmup 1 --no-cpu-baseline; FETCH_SIZE in KB x2 (gfx950: a wide coalesced read is tallied at half its "
                  "bytes, MI355X_MICROARCH.md HBM section), WRITE_SIZE in KB; summed over the executed steps",
-       "csrc_hash": csrc_hash(), "steps": steps, "step_bytes": round((tot_r + tot_w) / steps), "total_gb_per_step": {"read": round(tot_r / steps / 1e9, 2), "write": round(tot_w / steps / 1e9, 2)},
+       "csrc_hash": csrc_hash(), "steps": steps, "step_bytes": round((tot_r + tot_w) / steps),
+       "step_bytes_upper": round((tot_r + narrow_r + tot_w) / steps), "uncalibrated_read_gb_per_step": round(narrow_r / steps / 1e9, 3), "total_gb_per_step": {"read": round(tot_r / steps / 1e9, 2), "write": round(tot_w / steps / 1e9, 2)},
        "classes": {c_: {"launches_per_step": a["launches"] / steps, "read_bytes_per_launch": round(a["read"] / a["launches"]),
                         "write_bytes_per_launch": round(a["write"] / a["launches"]),
                         "bytes_per_launch": round((a["read"] + a["write"]) / a["launches"])} for c_, a in agg.items()}}

@@ -84,10 +84,12 @@ def amp_reference(amp_name, src_name, mode):
 # Final parameters after a few Adam steps: Adam turns rounding-level gradient differences into sign-level update
 # differences, so |ours - reference| per element is bounded by 2 * steps * lr ("budget", two runs with opposite signs), and
 # its rms over a tensor measures how many elements flipped.  The reference's OWN fp32 rounding already moves that
-# statistic: the oracle run in fp64 against the fp32 fixtures gives rms / budget = 0.12 on cfg1's worst tensors (0.02 on
-# the mini fixtures) — tests/test_oracle_golden.py::test_adam_sign_flip_statistic_of_the_reference_itself.  A bound below
-# that would test luck, not parity: 0.2 for tensors with >= 256 elements (fewer: rms ~ max, one flip).
-ADAM_FLIP_RMS = 0.2
+# statistic: the oracle run in fp64 against the fp32 fixtures gives rms / budget = 0.121 on cfg1's worst tensor, 0.019 on
+# mini_s2's, 0.161 on mini_gauss's (tests/test_oracle_golden.py::test_adam_sign_flip_statistic_of_the_reference_itself pins
+# those).  A bound below that would test luck, not parity; one far above it would hide a regression: per
+# fixture, ~1.5x the reference's own statistic with a floor for the near-exact fixture — for tensors with >= 256 elements
+# (fewer: rms ~ max, one flip).
+ADAM_FLIP_RMS = {"cfg1_step.npz": 0.2, "mini_s2_step.npz": 0.08, "mini_gauss_step.npz": 0.25}
 
 
 def adam_flip_statistic(ours, ref, budget):

@@ -91,6 +91,7 @@ def test_train_steps_match_reference_golden(name, precision):
         opt.step()
     sd = model.state_dict()
     budget = steps * lr
+    flip_worst = ("", 0.0)
     for k, v in fx.items():
         if not k.startswith("final/") or k == "final/loss_buffer":
             continue
@@ -106,7 +107,12 @@ def test_train_steps_match_reference_golden(name, precision):
             d = np.abs(ours - v)
             assert d.max() <= 2.02 * budget + 1e-5 * np.abs(v).max(), (name_, d.max())  # two runs, opposite signs
             # rms: how many elements flipped — bounded by what the reference's own fp32 rounding does to it (helpers.ADAM_FLIP_RMS)
-            assert adam_flip_statistic(ours, v, budget) <= (ADAM_FLIP_RMS if d.size >= 256 else 1.0), (name_, adam_flip_statistic(ours, v, budget))
+            fs = adam_flip_statistic(ours, v, budget)
+            if d.size >= 256 and fs > flip_worst[1]:
+                flip_worst = (name_, fs)
+            assert fs <= (ADAM_FLIP_RMS[name] if d.size >= 256 else 1.0), (name_, fs)
+    report(f"{name} [{precision}]: Adam sign-flip statistic after {steps} steps: worst {flip_worst[1]:.3f} at {flip_worst[0]} "
+           f"(bound {ADAM_FLIP_RMS[name]}; the reference's own fp32 rounding: see tests/helpers.py)")
     np.testing.assert_allclose(model.loss_buffer.buffer.cpu().numpy(), fx["final/loss_buffer"], rtol=TOL, atol=1e-6)
 
 
@@ -526,6 +532,57 @@ def test_bn_relu_in_the_second_convolutions_loaders_is_bit_identical(geom, monke
             assert torch.equal(x, y)
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("kind", ["dropout2d", "final"])
+def test_caller_masks_on_blocks_built_without_dropout_are_honoured_in_both_directions(kind, monkeypatch):
+    """`mimo_forward_args.drop_masks[i]` / `elem_masks[j]` are honoured on every block, also on one the
+    plan was built with rate 0 for — there the output activation is elided by construction (its readers apply BatchNorm +
+    ReLU to z), and round 4's forward dropped the multiplier while the backward still applied it.  Now such a call
+    materialises the tensor: the step equals the oracle's step with the same multipliers (reference: Dropout2d /
+    nn.Dropout after the block, components.py:29, model.py:277-281) and is bit-identical to MIMO_FUSE_BN_IN=0."""
+    N, H, W = 2, 64, 64
+    S = 2
+    ocfg = (O.NetConfig(2, 2, S, 16, core_dropout_rate=0.5, decoder_dropout_rate=0.5) if kind == "dropout2d" else
+            O.NetConfig(2, 2, S, 16, final_dropout_rate=0.5))
+    cfg0 = O.NetConfig(2, 2, S, 16)  # what the HIP plan is built for: no dropout anywhere
+    st = O.init_state(cfg0, 31)
+    g = torch.Generator().manual_seed(32)
+    image, label = torch.rand(N, 2, H, W, generator=g), torch.rand(N, 1, H, W, generator=g)
+    perms = O.draw_perms(N, S, generator=g)
+    specs = O.double_conv_specs(cfg0)  # (prefix, cin, mid, cout) in the engine's order
+    omasks, hmask, hemask = {}, {}, {}
+    if kind == "dropout2d":
+        for j, (prefix, _, _, cout) in enumerate(specs):
+            if prefix.startswith(("core.up", "decoder.up4s")):  # the blocks whose outputs are elided
+                m = (torch.rand(N, cout, generator=g) > 0.5).float() * 2.0
+                omasks[prefix], hmask[j] = m, m
+            elif prefix.startswith("core."):  # the oracle's rate applies to the whole core: all-ones there
+                omasks[prefix] = torch.ones(N, cout)
+    else:
+        for s_ in range(S):
+            m = (torch.rand(N, 16, H, W, generator=g) > 0.5).float() * 2.0
+            omasks[f"decoder.final_dropouts.{s_}"], hemask[f"final{s_}"] = m, m
+    ts = O.TrainState(cfg=ocfg, st={k: v.clone() for k, v in st.items()}, loss_buffer=O.LossBuffer(S, 0.3, 10))
+    ref = O.train_step(ts, image, label, None, perms, masks=omasks, apply_optimizer=False)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MIMO_FUSE_BN_IN", flag)
+        m = build_model(cfg0, st)
+        m.train()
+        m.model.mask_override = hmask or None
+        m.model.elem_mask_override = hemask or None
+        o = m.training_step_with_perms(image.cuda(), label.cuda(), None, perms.cuda())
+        o["loss"].backward()
+        grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in m.named_parameters()}
+        res.append((o["loss"].detach().cpu(), o["preds"].cpu(), m.model.flat_gradients().clone().cpu()))
+        e_out = rel_err(o["preds"].view(N, S, 1, H, W).cpu(), ref["out"][:, :, :1])
+        e_loss = abs(float(o["loss"]) - float(ref["total"])) / abs(float(ref["total"]))
+        worst = check_grads(grads, ref["grads"], tol=5e-3)  # a 16-channel net: one ReLU flip is a few 1e-3 of a tensor
+        report(f"{kind} multipliers on rate-0 blocks, MIMO_FUSE_BN_IN={flag}: out {e_out:.1e} loss {e_loss:.1e} worst grad {worst}")
+        assert e_out < TOL and e_loss < TOL
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("geom", [(2, 2, 2, 30, 2, 256, 256, 0.0), (3, 2, 3, 10, 3, 100, 100, 0.2), (1, 2, 1, 8, 2, 50, 70, 0.0)],

@@ -73,13 +73,14 @@ def test_train_steps_match_reference(name):
     np.testing.assert_allclose(ts.loss_buffer.buffer.numpy(), fx["final/loss_buffer"], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("name,lo,hi", [("cfg1_step.npz", 0.05, 0.16), ("mini_s2_step.npz", 0.0, 0.05)])
+@pytest.mark.parametrize("name,lo,hi", [("cfg1_step.npz", 0.05, 0.16), ("mini_s2_step.npz", 0.0, 0.05),
+                                        ("mini_gauss_step.npz", 0.1, 0.2)])
 def test_adam_sign_flip_statistic_of_the_reference_itself(name, lo, hi):
-    """Where the GPU tests' bound on the final parameters comes from (helpers.ADAM_FLIP_RMS = 0.2): the restatement run in
-    fp64 against the reference's fp32 fixture — the same network, the same steps, only the rounding differs — already moves
-    rms(|final parameter - fixture|) / (steps * lr) to 0.12 on cfg1's worst tensors (Adam's normalised update turns a
-    rounding-level gradient difference near zero into a +-lr step).  A HIP result within 0.2 is as close to the fixture as
-    exact arithmetic is."""
+    """Where the GPU tests' per-fixture bounds on the final parameters come from (helpers.ADAM_FLIP_RMS): the restatement run
+    in fp64 against the reference's fp32 fixture — the same network, the same steps, only the rounding differs — already
+    moves rms(|final parameter - fixture|) / (steps * lr) to 0.12 on cfg1's worst tensor, 0.16 on mini_gauss's, 0.02 on
+    mini_s2's (Adam's normalised update turns a rounding-level gradient difference near zero into a +-lr step).  A HIP
+    result within ~1.5x of that is as close to the fixture as exact arithmetic is."""
     fx = load_npz(name)
     cfg = cfg_from_meta(fx["meta"])
     steps, lr, wd = int(fx["meta"][8]), float(fx["lr"]), float(fx["wd"])
@@ -98,7 +99,7 @@ def test_adam_sign_flip_statistic_of_the_reference_itself(name, lo, hi):
             continue
         worst = max(worst, adam_flip_statistic(ts.st[n].numpy(), v, steps * lr))
     assert lo <= worst <= hi, worst
-    assert worst < ADAM_FLIP_RMS
+    assert worst < ADAM_FLIP_RMS[name]
 
 
 def test_bn_buffers_after_first_step():
