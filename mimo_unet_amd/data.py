@@ -50,9 +50,14 @@ class _Slot:
 class DevicePrefetcher:
     """Iterate `batches` (dicts of host tensors; non-tensor values pass through) as device-resident dicts.
 
-    depth: batches uploaded ahead of the one being consumed (2 = double buffer in front of the step)."""
+    depth: batches uploaded ahead of the one being consumed (2 = double buffer in front of the step).
+    pinned: None = look at the first batch (`Tensor.is_pinned()` per tensor, once: on ROCm that query costs ~10 ms for a
+    pageable tensor — measured, profiles/r05/data_path.txt — so it cannot be asked every step) and assume the loader keeps
+    doing what it did; True / False = the caller states what the loader yields (`DataLoader(pin_memory=...)`).  A wrong
+    assumption is slow, not wrong: a pageable tensor taken for pinned is uploaded by torch's blocking copy, a pinned one
+    taken for pageable goes through the staging ring."""
 
-    def __init__(self, batches: Iterable[Dict[str, Any]], device="cuda", depth: int = 2):
+    def __init__(self, batches: Iterable[Dict[str, Any]], device="cuda", depth: int = 2, pinned: Optional[bool] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("DevicePrefetcher uploads to an AMD GPU; got device " + str(device))
@@ -63,11 +68,23 @@ class DevicePrefetcher:
         self.batches, self.depth = batches, int(depth)
         self.copy_stream = torch.cuda.Stream(self.device)
         self._slots: List[_Slot] = [_Slot() for _ in range(self.depth + 1)]
-        self.blocking_waits = 0  # times the host had to wait for the GPU (an upload slot still in flight)
+        self._pinned: Dict[str, bool] = {}
+        self._pinned_default = pinned
+        # times the host waited for an upload slot still in flight: it was `depth` batches ahead of the copy stream (the
+        # bounded run-ahead working as designed when the GPU is the bottleneck; never inside the first `depth` batches)
+        self.throttle_waits = 0
         self.staged_copies = 0   # host tensors that were pageable and went through the pinned ring
 
     def __len__(self) -> int:
         return len(self.batches)  # type: ignore[arg-type]
+
+    def _is_pinned(self, key: str, v: torch.Tensor) -> bool:
+        if self._pinned_default is not None:
+            return self._pinned_default
+        known = self._pinned.get(key)
+        if known is None:
+            known = self._pinned[key] = bool(v.is_pinned())
+        return known
 
     # -- one upload -------------------------------------------------------------------------------------------------
     def _upload(self, slot: _Slot, batch: Dict[str, Any]) -> Dict[str, Any]:
@@ -84,7 +101,7 @@ class DevicePrefetcher:
         if slot.uploaded is not None and not slot.uploaded.query():
             # the staging buffer of this slot is still being read by its previous upload: the host is more than
             # `depth` batches ahead of the copy stream
-            self.blocking_waits += 1
+            self.throttle_waits += 1
             slot.uploaded.synchronize()
         out: Dict[str, Any] = {}
         with torch.cuda.stream(self.copy_stream):
@@ -96,12 +113,12 @@ class DevicePrefetcher:
                     continue
                 if v.is_cuda:
                     slot.dev[k].copy_(v, non_blocking=True)
-                elif v.is_pinned() and v.is_contiguous():
+                elif self._is_pinned(k, v) and v.is_contiguous():
                     slot.dev[k].copy_(v, non_blocking=True)
                     slot.host[k] = v  # keep the loader's pinned tensor alive until the copy has run
                 else:
                     h = slot.host.get(k)
-                    if h is None or h.shape != v.shape or h.dtype != v.dtype or not h.is_pinned():
+                    if h is None or h.shape != v.shape or h.dtype != v.dtype or h is v:
                         h = torch.empty(v.shape, dtype=v.dtype).pin_memory()
                     h.copy_(v)
                     slot.host[k] = h

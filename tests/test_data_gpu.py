@@ -114,8 +114,8 @@ def test_steps_fed_from_host_memory_contain_no_blocking_call(pinned):
     host_s = time.perf_counter() - t0
     torch.cuda.synchronize()
     report(f"3 steps fed from {'pinned' if pinned else 'pageable'} host batches behind a 0.4 s spin kernel: host returned "
-           f"after {host_s * 1e3:.1f} ms, steps that found the gate complete: {blocked}, prefetcher waits {pf.blocking_waits}")
-    assert blocked == 0 and pf.blocking_waits == 0
+           f"after {host_s * 1e3:.1f} ms, steps that found the gate complete: {blocked}, prefetcher waits {pf.throttle_waits}")
+    assert blocked == 0 and pf.throttle_waits == 0
 
 
 def test_host_fed_loop_runs_ahead_like_the_resident_loop():
