@@ -132,7 +132,12 @@ struct WgradLaunch {
   int cin_p, cout_p;      // valid channel extents in x / dz (multiples of 4)
   int cin_pad, cout_pad;  // multiples of 32
   int splits;
-  int np = 3;  // split kernels: MFMAs per product block — 3 (hi/lo pairs, fp32-class) or 1 (bf16 compute)
+  // split kernels: MFMAs per product block — 3 (bf16 hi/lo pairs both sides), 1 (bf16 compute), or 2 (round 5,
+  // wave-specialised kernel, store 0: the activation as one fp16 value, dz as a scaled fp16 pair; needs dz_absmax)
+  int np = 3;
+  // np == 2: device word holding the bits of max |dz| of this tensor as a float (bn_bwd_apply / split_pairs write it);
+  // the kernel scales dz by wg_dz_scale(*dz_absmax) and wgrad_reduce_launch divides the result by it again
+  const unsigned* dz_absmax = nullptr;
   // split kernels, operand storage: 0 = activations fp32 + dz pre-split bf16 pair records; 1 / 2 = activations and dz
   // plain NHWC bf16 / fp16 (ldx, lddz in elements); 3 / 4 = activations fp32 (the packed image) + dz plain bf16 / fp16
   int store = 0;
@@ -142,7 +147,18 @@ struct WgradLaunch {
   const float* in_scale = nullptr;
   const float* in_shift = nullptr;
 };
+// the power of two 2^(14 - floor(log2 max|dz|)) (inverse: its reciprocal) from the float bits of max |dz|: scaled values lie
+// below 2^15 (fp16's largest finite value is 65504); an all-zero tensor scales by 2^126
+__host__ __device__ __forceinline__ float wg_dz_scale(unsigned absmax_bits, bool inverse) {
+  int e = (int)((absmax_bits >> 23) & 0xffu);  // biased exponent
+  e = e < 16 ? 16 : e > 254 ? 254 : e;
+  const unsigned f = (unsigned)(inverse ? e - 14 : 268 - e);
+  union { unsigned u; float v; } c;
+  c.u = f << 23;
+  return c.v;
+}
 int wgrad_launch(const WgradLaunch& a, hipStream_t stream);
+int wgrad_split_has_np2(int cin_p, int cout_p);
 // 1 when wgrad_split_launch runs this geometry on a kernel that can apply WgradLaunch::in_scale / in_shift in its loader
 int wgrad_split_fuses_input(int cin_p, int cout_p, int store, int np);
 // split-bf16 variant (wgrad_split.hip): cin_pad / cout_pad must be multiples of its (CI, CO) tile
@@ -153,8 +169,9 @@ int wgrad_pick_splits(int N, int H, int W, int cin_pad, int cout_pad);
 // extra floats the reduction needs behind the splits*9*cin_pad*cout_pad partial slabs
 size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad);
 // dW[co][ci][kh][kw] (torch OIHW) = sum over splits of partial[..][tap][cin_map^-1(ci)][co]
+// dz_absmax != nullptr: the slabs carry the factor wg_dz_scale(*dz_absmax) (WgradLaunch::np == 2), removed here
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map,
-                        int cin_p, int cin, int cout, float* dw, hipStream_t stream);
+                        int cin_p, int cin, int cout, float* dw, hipStream_t stream, const unsigned* dz_absmax = nullptr);
 
 // All weight repacks of a step in ONE launch (a per-layer launch each cost more in dispatch gaps than in
 // work): a device table of jobs, blockIdx.y = job.  kind 0: fp32 [tap][rows_pad][cols]; 1 / 2: fp16 / bf16

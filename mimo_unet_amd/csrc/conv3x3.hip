@@ -402,7 +402,7 @@ __global__ void wgrad_group_sum_kernel(const float* __restrict__ partial, int sp
 
 __device__ __forceinline__ void wgrad_reduce_tile(const float* __restrict__ partial, int splits, int cin_pad, int cout_pad,
                                                   const int* __restrict__ cin_map, int cin_p, int cin, int cout,
-                                                  float* __restrict__ dw, int block) {
+                                                  float* __restrict__ dw, int block, float mul) {
   // 8 output channels per pass: a 9 KB LDS tile, so the kernel fits next to the 145-159 KB workgroups of
   // the persistent convolution kernels it runs beside (side stream) instead of waiting for their CUs
   constexpr int PITCH = 289;  // 32*9 + 1
@@ -463,15 +463,17 @@ __device__ __forceinline__ void wgrad_reduce_tile(const float* __restrict__ part
       if (co0 + co >= cout || cip >= cin_p) continue;
       const int ci = cin_map ? cin_map[cip] : (cip < cin ? cip : -1);
       if (ci < 0) continue;
-      dw[((size_t)(co0 + co) * cin + ci) * 9 + tap] = tile[co * PITCH + j];
+      dw[((size_t)(co0 + co) * cin + ci) * 9 + tap] = tile[co * PITCH + j] * mul;  // (mul: a power of two or 1, exact)
     }
   }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int cin_pad,
                                                            int cout_pad, const int* __restrict__ cin_map, int cin_p,
-                                                           int cin, int cout, float* __restrict__ dw) {
-  wgrad_reduce_tile(partial, splits, cin_pad, cout_pad, cin_map, cin_p, cin, cout, dw, (int)blockIdx.x);
+                                                           int cin, int cout, float* __restrict__ dw,
+                                                           const unsigned* __restrict__ dz_absmax) {
+  wgrad_reduce_tile(partial, splits, cin_pad, cout_pad, cin_map, cin_p, cin, cout, dw, (int)blockIdx.x,
+                    dz_absmax ? wg_dz_scale(*dz_absmax, true) : 1.f);
 }
 
 // scratch (floats) the reduction needs behind the `splits` slabs of the wgrad kernels
@@ -485,7 +487,7 @@ size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad) {
 }
 
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map, int cin_p,
-                        int cin, int cout, float* dw, hipStream_t stream) {
+                        int cin, int cout, float* dw, hipStream_t stream, const unsigned* dz_absmax) {
   const size_t slab = (size_t)9 * cin_pad * cout_pad;
   const float* src = partial;
   int n = splits;
@@ -503,7 +505,7 @@ int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_
     n = groups;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, n, cin_pad, cout_pad, cin_map, cin_p,
-                     cin, cout, dw);
+                     cin, cout, dw, dz_absmax);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

@@ -38,6 +38,11 @@
 #include "common.h"
 #include "tile_sched.h"
 
+#ifndef MIMO_WIDE_DEFER
+#define MIMO_WIDE_DEFER 1  // 0: the per-tile epilogue runs between the tiles as in rounds 3-4 (A/B builds)
+#endif
+#define WD_DEFER_ENABLED (MIMO_WIDE_DEFER != 0)
+
 namespace mimo {
 
 namespace {
@@ -62,6 +67,7 @@ __device__ __forceinline__ float dpp_xor1(float x) {
 }
 
 constexpr float kWideF16Scale = 256.f;  // forward weights are packed x 2^8 (as conv_bf16x3.hip)
+
 constexpr int kXPitch = 80;             // bytes per input row: [hi 16 | lo 16] 16-bit values + 16 pad
 constexpr int kMaxPix = sched::kWideMaxPix;
 constexpr int kXBytes = kMaxPix * kXPitch;  // 51200
@@ -110,8 +116,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
   constexpr int WPHB = WU * 256 * 16;        // bytes per weight buffer (rounded up to whole DMA rounds)
   constexpr int NWB = TPP == 3 ? 3 : 2;      // weight buffers
   constexpr int EPIB = FWD ? 3 * NB * 4 : 0;  // per-channel epilogue constants: bias, inference scale, shift
-  static_assert(2 * kXBytes + NWB * WPHB + EPIB <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kXBytes + NWB * WPHB + EPIB];
+  // deferred epilogue (see the consumers): the lane-private BatchNorm partial sums live in LDS (16 floats per consumer
+  // lane), not in 16 registers next to the 64 saved accumulators
+  constexpr bool DEFER = NF == 1 && MODE == 0 && !EPI && WD_DEFER_ENABLED;  // (the forward: measured slower, see DEFER below)
+  constexpr int SUMB = (DEFER && FWD) ? 4 * 2 * 256 * 8 : 0;
+  static_assert(2 * kXBytes + NWB * WPHB + EPIB + SUMB <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kXBytes + NWB * WPHB + EPIB + SUMB];
   unsigned char* const xs = lds;
   unsigned char* const ws = lds + 2 * kXBytes;
   float* const epi = reinterpret_cast<float*>(lds + 2 * kXBytes + NWB * WPHB);
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       for (int i = 0; i < 16; ++i) acc[m][nf][i] = 0.f;
   // BatchNorm partial sums over all tiles of this persistent workgroup.  Lane (px, h) holds, of channel quad j of tile
   // nf (channels 8 j + 4 h .. + 3), the two channels 2 (px & 1) .. + 1 — summed over its own and its neighbour's pixels
-  f32x2 s1[NF][4], s2[NF][4];
+  f32x2 s1[NF][4], s2[NF][4];  // (DEFER: in LDS until the end, `lsum`)
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
@@ -443,8 +453,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       s1[nf][j] = f32x2{0.f, 0.f};
       s2[nf][j] = f32x2{0.f, 0.f};
     }
+  typedef typename std::conditional<S16, ET, float>::type OT_;  // element type of the output tensor
   const bool odd = px & 1;
+  // DEFER (round 5; 32-channel instances of the split16 training forward / data gradient): the epilogue of tile t does not
+  // run between the tiles — where the four consumer waves of every CU push 64 KB each at the same moment and the matrix
+  // pipe idles until the burst has drained (profiles/r04/thin_role_ablation.txt: 19-25 % of a thin layer) — but as 16
+  // pieces (one 16-byte store each) inside the first phase of tile t + 1, one per slot, interleaved with that slot's
+  // MFMAs: the finished accumulators move to `sav`, the new tile's first MFMAs start from a zero C operand.  Same
+  // values, same order of the BatchNorm sums: bit-identical results.
+  // The partial BatchNorm sums of a lane live in LDS (`lsum`, 16 floats per lane) instead of 16 registers.
+  f32x2* const lsum = reinterpret_cast<f32x2*>(lds + 2 * kXBytes + NWB * WPHB + EPIB) + (tid & 255);  // [quad][moment][lane]
+  if (SUMB) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lsum[i * 256] = f32x2{0.f, 0.f};
+  }
+  // The stores are BUFFER stores on a descriptor of the tile's image: a lane whose pixel lies outside the image (or a
+  // padded channel quad) carries an offset past the descriptor's range and the hardware drops its store — no branch, no
+  // address select, and the offsets are 32-bit.
+  f32x16 sav[DEFER ? MF : 1];
+  unsigned sv_off[DEFER ? MF : 1];  // byte offset of the lane's pixel of fragment m (channel quad 0) in the image, or kNoStore
+  __amdgpu_buffer_rsrc_t sv_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0, 0x00020000);
+  constexpr unsigned kNoStore = 0x7fff0000u;  // beyond any image the launch accepts (conv3x3_wide_launch)
+  f32x4 ep_b = f32x4{0.f, 0.f, 0.f, 0.f}, ep_t4 = ep_b, ep_q4 = ep_b;
+  (void)sav; (void)sv_off; (void)sv_rsrc; (void)ep_b; (void)ep_t4; (void)ep_q4;
 
+  const f32x16 kZero16 = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  (void)kZero16;
   V8 af[2][SM][2], wf[2][NF][2];  // [register set][fragment][hi, lo]
 
   // weights of tap T (within the phase) -> register set WS_
@@ -462,7 +496,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     af[AS_][i][0] = *reinterpret_cast<const V8*>(p_);                                                \
     af[AS_][i][1] = *reinterpret_cast<const V8*>(p_ + 32);                                           \
   }
-#define WC_MFMA(AS_, WS_, S)                                                                         \
+#define WC_MFMA(AS_, WS_, S) WC_MFMA_Z(AS_, WS_, S, false)
+  // Z: the first MFMA of each accumulator tile starts from a zero C operand (first tap of a tile in the DEFER path)
+#define WC_MFMA_Z(AS_, WS_, S, Z)                                                                    \
   if (abl & 8) {                                                                                     \
     _Pragma("unroll") for (int i = 0; i < SM; ++i) {                                                 \
       asm volatile("" ::"v"(af[AS_][i][0]), "v"(af[AS_][i][1]));                                     \
@@ -475,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       if (S16) { /* the row's halves are channels 0-15 and 16-31 of the chunk */                     \
         acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][1], af[AS_][i][1], acc[(S) * SM + i][nf]);        \
       } else { /* (hi, lo) pairs: lo.hi + hi.lo + hi.hi */                                           \
-        acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][0], af[AS_][i][1], acc[(S) * SM + i][nf]);        \
+        acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][0], af[AS_][i][1], (Z) ? kZero16 : acc[(S) * SM + i][nf]); \
         acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][1], af[AS_][i][0], acc[(S) * SM + i][nf]);        \
       }                                                                                              \
       acc[(S) * SM + i][nf] = mfma32(wf[WS_][nf][0], af[AS_][i][0], acc[(S) * SM + i][nf]);          \
@@ -559,6 +595,99 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       _Pragma("unroll") for (int nf = 0; nf < NF; ++nf)                                              \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) acc[m][nf][i_] = 0.f;                      \
   }
+  // ---- deferred epilogue (DEFER) ----
+  // tile TI is complete: its accumulators move to `sav`; per fragment the lane's store address (quad 0) and whether its
+  // pixel counts.  (The accumulators themselves are not cleared: the next tile's first MFMAs take a zero C operand.)
+#define WC_SNAPSHOT(TI)                                                                              \
+  {                                                                                                  \
+    int t_ = vbx + (TI) * gx;                                                                        \
+    const int tx_ = t_ % tilesX;                                                                     \
+    t_ /= tilesX;                                                                                    \
+    const int ty_ = t_ % tilesY;                                                                     \
+    const int n_ = t_ / tilesY;                                                                      \
+    const int y0_ = ty_ * TR, x0_ = tx_ * TC;                                                        \
+    sv_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<OT_*>(a.y) + (size_t)n_ * a.Ho * a.Wo * a.ldy, 0, \
+                                                a.Ho * a.Wo * a.ldy * (int)sizeof(OT_), 0x00020000); \
+    _Pragma("unroll") for (int m = 0; m < MF; ++m) {                                                 \
+      const int oy = y0_ + (prc[m] >> 16), ox = x0_ + (prc[m] & 0xffff);                             \
+      sv_off[m] = (oy < a.Ho && ox < a.Wo) ? (unsigned)(((oy * a.Wo + ox) * a.ldy + co0 + 4 * h) * (int)sizeof(OT_)) : kNoStore; \
+      sav[m] = acc[m][0];                                                                            \
+    }                                                                                                \
+  }
+  // piece K = (channel quad j = K / 4, fragment m = K % 4) of the saved tile: scale / bias, one 16-byte store, the
+  // BatchNorm sums in WC_EPILOGUE's order (over m for a quad, then the DPP reduce-scatter step)
+#define WC_PIECE(K)                                                                                  \
+  {                                                                                                  \
+    const int j_ = (K) >> 2, m_ = (K) & 3;                                                           \
+    if (FWD) ep_b = *reinterpret_cast<const f32x4*>(epi + 8 * j_ + 4 * h);                           \
+    if (m_ == 0) {                                                                                   \
+      ep_t4 = f32x4{0.f, 0.f, 0.f, 0.f};                                                             \
+      ep_q4 = ep_t4;                                                                                 \
+    }                                                                                                \
+    f32x4 v = f32x4{sav[m_][4 * j_], sav[m_][4 * j_ + 1], sav[m_][4 * j_ + 2], sav[m_][4 * j_ + 3]};  \
+    if (F16) v = v * (1.f / kWideF16Scale);                                                          \
+    if (FWD) v = v + ep_b;                                                                           \
+    /* a padded channel quad (co0 + 8 j >= cout_store: wave-uniform; cout_store is a multiple of 8) is not stored */ \
+    const unsigned vo_ = co0 + 8 * j_ < a.cout_store ? sv_off[m_] : kNoStore;                        \
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sv_rsrc, (int)vo_, 8 * j_ * (int)sizeof(OT_), 0); \
+    if (STATS) {                                                                                     \
+      const bool in_ = sv_off[m_] != kNoStore;                                                       \
+      const f32x4 w_ = f32x4{in_ ? v[0] : 0.f, in_ ? v[1] : 0.f, in_ ? v[2] : 0.f, in_ ? v[3] : 0.f}; \
+      ep_t4 += w_;                                                                                   \
+      ep_q4 += w_ * w_;                                                                              \
+      if (m_ == MF - 1) {                                                                            \
+        const float k0_ = odd ? ep_t4[2] : ep_t4[0], k1_ = odd ? ep_t4[3] : ep_t4[1];                \
+        const float g0_ = odd ? ep_t4[0] : ep_t4[2], g1_ = odd ? ep_t4[1] : ep_t4[3];                \
+        lsum[(2 * j_) * 256] += f32x2{k0_ + dpp_xor1(g0_), k1_ + dpp_xor1(g1_)};                     \
+        const float l0_ = odd ? ep_q4[2] : ep_q4[0], l1_ = odd ? ep_q4[3] : ep_q4[1];                \
+        const float h0_ = odd ? ep_q4[0] : ep_q4[2], h1_ = odd ? ep_q4[1] : ep_q4[3];                \
+        lsum[(2 * j_ + 1) * 256] += f32x2{l0_ + dpp_xor1(h0_), l1_ + dpp_xor1(h1_)};                 \
+      }                                                                                              \
+    }                                                                                                \
+  }
+  // a slot of the first phase of a tile that also carries a piece: its fragment reads (+ the piece's bias read), then
+  // its MFMAs with the piece's vector instructions between them, the store last
+#define WC_PIN_P(NREADS)                                                                             \
+  __builtin_amdgcn_sched_group_barrier(0x100, (NREADS), 0);                                          \
+  _Pragma("unroll") for (int q_ = 0; q_ < 3 * SM * NF; ++q_) {                                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
+    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                                               \
+  }                                                                                                  \
+  __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+  // the slots of one phase; PIECES: the phase is the first of a tile and carries the deferred epilogue of the previous one
+#define WC_BODY(P, FIRST, PIECES)                                                                    \
+  _Pragma("unroll") for (int t = 0; t < TPP; ++t)                                                    \
+    _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                              \
+      const int g_ = t * NSLOT + s;                                                                  \
+      const int ws_ = (t & 1) ? (P) : ((P) ^ 1);                                                     \
+      if (!(t == TPP - 1 && s == NSLOT - 1)) {                                                       \
+        if (s + 1 < NSLOT) {                                                                         \
+          WC_READ_A((g_ + 1) & 1, t, s + 1)                                                          \
+        } else {                                                                                     \
+          WC_READ_W(ws_ ^ 1, t + 1)                                                                  \
+          WC_READ_A((g_ + 1) & 1, t + 1, 0)                                                          \
+        }                                                                                            \
+        WC_MFMA_Z(g_ & 1, ws_, s, (PIECES) && t == 0)                                                \
+        const bool piece_ = (PIECES) && g_ < 4 * MF;                                                 \
+        if (piece_) {                                                                                \
+          WC_PIECE(g_)                                                                               \
+        }                                                                                            \
+        /* (sched_group_barrier takes literal counts: one call per case) */                          \
+        if (piece_) { /* never in the FIRST phase */                                                 \
+          if (s + 1 < NSLOT) {                                                                       \
+            WC_PIN_P(2 * SM + (FWD ? 1 : 0))                                                         \
+          } else {                                                                                   \
+            WC_PIN_P(2 * NF + 2 * SM + (FWD ? 1 : 0))                                                \
+          }                                                                                          \
+        } else if ((FIRST) && g_ == 0) { /* the phase's opening reads sit in front of this slot too */ \
+          WC_PIN(2 * NF + 2 * SM + 2 * SM)                                                           \
+        } else if (s + 1 < NSLOT) {                                                                  \
+          WC_PIN(2 * SM)                                                                             \
+        } else {                                                                                     \
+          WC_PIN(2 * NF + 2 * SM)                                                                    \
+        }                                                                                            \
+      }                                                                                              \
+    }
   // One phase.  On entry the previous phase's last slot is pending (pixel set 1, weight set P): it is multiplied
   // behind the barrier, under the first reads of this phase.  Slots alternate the pixel sets (an even number per
   // phase), taps alternate the weight sets (an odd number per phase, so consecutive phases swap P).
@@ -572,39 +701,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     __syncthreads(); /* this phase is staged; the buffers of the previous one are released */        \
     WC_READ_W((P) ^ 1, 0)                                                                            \
     WC_READ_A(0, 0, 0)                                                                               \
+    bool pieces_ = false;                                                                            \
     if (!(FIRST)) {                                                                                  \
       WC_MFMA(1, P, NSLOT - 1)                                                                       \
       WC_PIN(2 * NF + 2 * SM)                                                                        \
       if (tile_done) {                                                                               \
-        WC_EPILOGUE(ti)                                                                              \
+        if (DEFER) {                                                                                 \
+          WC_SNAPSHOT(ti)                                                                            \
+          pieces_ = true;                                                                            \
+        } else {                                                                                     \
+          WC_EPILOGUE(ti)                                                                            \
+        }                                                                                            \
         ++ti;                                                                                        \
       }                                                                                              \
     }                                                                                                \
-    _Pragma("unroll") for (int t = 0; t < TPP; ++t)                                                  \
-      _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                            \
-        const int g_ = t * NSLOT + s;                                                                \
-        const int ws_ = (t & 1) ? (P) : ((P) ^ 1);                                                   \
-        if (!(t == TPP - 1 && s == NSLOT - 1)) {                                                     \
-          if (s + 1 < NSLOT) {                                                                       \
-            WC_READ_A((g_ + 1) & 1, t, s + 1)                                                        \
-          } else {                                                                                   \
-            WC_READ_W(ws_ ^ 1, t + 1)                                                                \
-            WC_READ_A((g_ + 1) & 1, t + 1, 0)                                                        \
-          }                                                                                          \
-          WC_MFMA(g_ & 1, ws_, s)                                                                    \
-          /* a slot of the FIRST phase's head has the phase's opening reads in front of it too */    \
-          if ((FIRST) && g_ == 0) {                                                                  \
-            WC_PIN(2 * NF + 2 * SM + 2 * SM)                                                         \
-          } else if (s + 1 < NSLOT) {                                                                \
-            WC_PIN(2 * SM)                                                                           \
-          } else {                                                                                   \
-            WC_PIN(2 * NF + 2 * SM)                                                                  \
-          }                                                                                          \
-        }                                                                                            \
-      }                                                                                              \
+    if (DEFER && pieces_) {                                                                          \
+      WC_BODY(P, FIRST, true)                                                                        \
+    } else {                                                                                         \
+      WC_BODY(P, FIRST, false)                                                                       \
+    }                                                                                                \
     tile_done = r_ == PARTS - 1 && (j_ + 1) % nchunks == 0;                                          \
     ++ph;                                                                                            \
     wslot = wslot + 1 == NWB ? 0 : wslot + 1;                                                        \
+  }
+  // the last tile: nothing follows that its epilogue could hide under
+#define WC_FINAL_EPILOGUE(TI)                                                                        \
+  if (DEFER) {                                                                                       \
+    WC_SNAPSHOT(TI)                                                                                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4 * MF; ++k_) {                                          \
+      WC_PIECE(k_)                                                                                   \
+    }                                                                                                \
+  } else {                                                                                           \
+    WC_EPILOGUE(TI)                                                                                  \
   }
 
   int ph = 0, ti = 0, wslot = 0;
@@ -621,7 +749,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     } else {
       WC_MFMA(1, 0, NSLOT - 1)
     }
-    WC_EPILOGUE(ti)
+    WC_FINAL_EPILOGUE(ti)
+  }
+  if (SUMB) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1[0][j] = lsum[(2 * j) * 256];
+      s2[0][j] = lsum[(2 * j + 1) * 256];
+    }
   }
   __syncthreads();  // matches the producers' last barrier
   if (STATS) {
@@ -657,6 +792,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
 #undef WC_READ_A
 #undef WC_MFMA
 #undef WC_EPILOGUE
+#undef WC_FINAL_EPILOGUE
+#undef WC_SNAPSHOT
+#undef WC_PIECE
+#undef WC_PIN_P
+#undef WC_BODY
+#undef WC_MFMA_Z
 #undef WC_PIN
 #undef WC_PHASE
 }
@@ -683,6 +824,10 @@ int conv3x3_wide_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t st
   const sched::WideCfg c = sched::wide_config(mode, a.N, a.cin_p, a.cout_store, a.Ho, a.Wo, 1);
   if (!a.wpk || c.nf == 0 || c.rows_pad != a.wide || a.ldx % 4 != 0 || a.ldy % 4 != 0 || a.Hi < 2 || a.Wi < 2) {
     set_error("conv3x3 wide: weights packed for %d rows, launch geometry gives %d (nf %d)", a.wide, c.rows_pad, c.nf);
+    return MIMO_ERR_INVALID;
+  }
+  if ((int64_t)a.Ho * a.Wo * a.ldy * 4 >= (int64_t)0x7fff0000) {  // 32-bit store offsets of the deferred epilogue (kNoStore)
+    set_error("conv3x3 wide: output image of %d x %d x %d exceeds the kernel's 32-bit offsets", a.Ho, a.Wo, a.ldy);
     return MIMO_ERR_INVALID;
   }
   if ((int64_t)a.Hi * a.Wi * a.ldx * 4 > (int64_t)INT32_MAX) {  // 32-bit per-unit source offsets (WD_OFFS)

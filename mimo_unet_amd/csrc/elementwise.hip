@@ -1417,8 +1417,12 @@ __global__ __launch_bounds__(kColsumThreads) void bn_bwd_stats_kernel(const floa
                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                       float* __restrict__ dbias_zero,
                                                                       double* __restrict__ scratch, int scratch_cols,
-                                                                      int* __restrict__ tickets, int* __restrict__ status) {
+                                                                      int* __restrict__ tickets, int* __restrict__ status,
+                                                                      unsigned* __restrict__ absmax_reset) {
   __shared__ double red[2048];
+  // the word the apply pass that follows accumulates max |dz| into (two-MFMA weight gradient): cleared here, one launch
+  // ahead of its writers and behind every reader of the previous backward (the plan joins its weight-gradient stream)
+  if (absmax_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *absmax_reset = 0u;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s1, s2;
   if (!grid_colsum2(partial, rows, (size_t)2 * Cp, c, Cp + c, c < Cp, true, red, scratch, scratch_cols, tickets, &s1, &s2)) return;
@@ -1436,10 +1440,12 @@ __global__ __launch_bounds__(kColsumThreads) void bn_bwd_stats_kernel(const floa
 }
 
 int bn_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int64_t count, int training, float* c1, float* c2,
-                        float* dgamma, float* dbeta, float* dbias_zero, const ColsumScratch& cs, hipStream_t st) {
+                        float* dgamma, float* dbeta, float* dbias_zero, const ColsumScratch& cs, hipStream_t st,
+                        unsigned* absmax_reset) {
   const int groups = ceil_div(Cp, 64);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(groups, colsum_chunks(rows)), dim3(kColsumThreads), 0, st, partial, rows, C, Cp,
-                     (double)count, training, c1, c2, dgamma, dbeta, dbias_zero, cs.sums, groups * 64, cs.tickets, cs.status);
+                     (double)count, training, c1, c2, dgamma, dbeta, dbias_zero, cs.sums, groups * 64, cs.tickets, cs.status,
+                     absmax_reset);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1474,14 +1480,40 @@ __device__ __forceinline__ void st_split4(float* base, size_t p, int Cp, int q, 
   *reinterpret_cast<bf16x4_ew*>(d + 2 * rc) = lo;
 }
 
-__global__ void split_pairs_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cv, int64_t P) {
-  const PQ t = pixquad(Cv);
-  if (!t.active) return;
-  for (int64_t p = t.p; p < P; p += t.pstep) st_split4(dst, (size_t)p, 4 * Cv, t.q, ld4(src + (size_t)p * 4 * Cv + 4 * t.q));
+// max over the workgroup of a non-negative per-thread value -> one atomic max per workgroup on the value's float bits
+// (non-negative floats order like unsigned integers; a maximum does not depend on the order of its operands: deterministic)
+__device__ __forceinline__ void block_absmax_to(unsigned* slot, float v) {
+  __shared__ float wmax[8];
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) v = fmaxf(v, __shfl_xor(v, d));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = wmax[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, wmax[i]);
+    if (m > 0.f) atomicMax(slot, __float_as_uint(m));
+  }
+}
+__device__ __forceinline__ float absmax4(float m, float4 r) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
 }
 
-int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStream_t st) {
-  hipLaunchKernelGGL(split_pairs_kernel, pq_grid(Cp / 4, P), dim3(256), 0, st, src, dst, Cp / 4, P);
+__global__ void split_pairs_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cv, int64_t P,
+                                   unsigned* __restrict__ absmax) {
+  const PQ t = pixquad(Cv);
+  float amax = 0.f;
+  if (t.active)
+    for (int64_t p = t.p; p < P; p += t.pstep) {
+      const float4 r = ld4(src + (size_t)p * 4 * Cv + 4 * t.q);
+      st_split4(dst, (size_t)p, 4 * Cv, t.q, r);
+      amax = absmax4(amax, r);
+    }
+  if (absmax) block_absmax_to(absmax, amax);
+}
+
+int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStream_t st, unsigned* absmax) {
+  if (absmax) MIMO_HIP_CHECK(hipMemsetAsync(absmax, 0, sizeof(unsigned), st));
+  hipLaunchKernelGGL(split_pairs_kernel, pq_grid(Cp / 4, P), dim3(256), 0, st, src, dst, Cp / 4, P, absmax);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1491,11 +1523,13 @@ __global__ void bn_bwd_apply_kernel(const GradSrc src, const TZ* __restrict__ z,
                                     const float* __restrict__ shift, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ mask, int C,
                                     const float* __restrict__ c1, const float* __restrict__ c2, int Cv, int N, int H,
-                                    int W, TA* __restrict__ dz, int split_out, float* __restrict__ partial) {
+                                    int W, TA* __restrict__ dz, int split_out, float* __restrict__ partial,
+                                    unsigned* __restrict__ absmax) {
   __shared__ float4 red[256];
   const PQ t = pixquad(Cv);
   const int Cp = 4 * Cv;
   float4 acc = f4zero();
+  float amax = 0.f;  // max |dz| of this thread's elements (absmax != nullptr: the two-MFMA weight gradient scales dz by it)
   HeadLane hl = {};
   if constexpr (SRC == GS_HEAD) hl = head_lane(src.head, t.q, t.active);
   if (t.active) {
@@ -1512,6 +1546,7 @@ __global__ void bn_bwd_apply_kernel(const GradSrc src, const TZ* __restrict__ z,
       else
         st4(dz + (size_t)p * Cp + 4 * t.q, r);
       acc = f4add(acc, r);
+      amax = absmax4(amax, r);
     };
     if constexpr (SRC == GS_POOL) {
       const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, P = N * Hc * Wc;
@@ -1535,6 +1570,7 @@ __global__ void bn_bwd_apply_kernel(const GradSrc src, const TZ* __restrict__ z,
       }
     }
   }
+  if (absmax) block_absmax_to(absmax, amax);
   if (!partial) return;  // training mode: the bias gradient is exactly zero, no column sums wanted
   const float4 s = quad_block_sum(acc, t, red);
   if (t.pl == 0 && t.q < Cv) st4(partial + (size_t)blockIdx.x * Cp + 4 * t.q, s);
@@ -1543,7 +1579,7 @@ __global__ void bn_bwd_apply_kernel(const GradSrc src, const TZ* __restrict__ z,
 int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int ldz,
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
                         int C, const float* c1, const float* c2, int Cp, int N, int H, int W, void* dz, int split_out,
-                        float* partial, int* rows, hipStream_t st) {
+                        float* partial, int* rows, hipStream_t st, unsigned* absmax) {
   MIMO_TRY(check_grad_src(src, dta, dtz));
   const int Cv = Cp / 4;
   const int64_t units = src.kind == GS_POOL ? (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) : (int64_t)N * H * W;
@@ -1555,7 +1591,7 @@ int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int
   }
 #define APPLY_LAUNCH(TZ, TA, SRC)                                                                                              \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<TZ, TA, SRC>), grid, dim3(256), 0, st, src, (const TZ*)z, ldz, scale, shift, mean, invstd, \
-                     mask, C, c1, c2, Cv, N, H, W, (TA*)dz, split_out, partial)
+                     mask, C, c1, c2, Cv, N, H, W, (TA*)dz, split_out, partial, absmax)
   if (src.kind == GS_POOL) {
     APPLY_LAUNCH(float, float, GS_POOL);
   } else if (src.kind == GS_HEAD) {

@@ -95,6 +95,29 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// NP == 2 kernels: a bf16 (hi, lo) record pair of 8 channels -> v = hi + lo (exact in fp32) -> v * mul (a power of two) ->
+// fp16 (hi, lo): hi = RNE(v), lo = RNE(v - hi).  Element order of the 16-byte units is kept.
+__device__ __forceinline__ void wg_dz_pair_to_f16(f32x4 hi_raw, f32x4 lo_raw, float mul, f32x4* out_hi, f32x4* out_lo) {
+  typedef unsigned int u32x4_w __attribute__((ext_vector_type(4)));
+  typedef _Float16 f16x2_w __attribute__((ext_vector_type(2)));
+  const u32x4_w h = __builtin_bit_cast(u32x4_w, hi_raw), l = __builtin_bit_cast(u32x4_w, lo_raw);
+  u32x4_w oh, ol;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float f0 = (__uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16)) * mul;
+    const float f1 = (__uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u)) * mul;
+    f16x2_w a, b;
+    a[0] = (_Float16)f0;
+    a[1] = (_Float16)f1;
+    b[0] = (_Float16)(f0 - (float)a[0]);
+    b[1] = (_Float16)(f1 - (float)a[1]);
+    oh[e] = __builtin_bit_cast(unsigned int, a);
+    ol[e] = __builtin_bit_cast(unsigned int, b);
+  }
+  *out_hi = __builtin_bit_cast(f32x4, oh);
+  *out_lo = __builtin_bit_cast(f32x4, ol);
+}
+
 template <int MI, int NI, int WM, int WN, int WK, int NP, int OM>
 __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
@@ -341,7 +364,14 @@ static int wgrad_ws_tr(int CI, int om) { return sched::wg_ws_tr(CI, wgrad_s16(om
 template <int NP, int NI, int CI_, int TR_, int OM, bool FIN = false>
 __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, int tilesY, int tilesX, int numTiles) {
   static_assert(OM == 0 || NP == 1, "16-bit storage: one MFMA per product");
-  static_assert(!FIN || (OM == 0 && NP == 3), "fused input BatchNorm + ReLU: split16 only");
+  static_assert(!FIN || (OM == 0 && NP >= 2), "fused input BatchNorm + ReLU: split16 only");
+  // NP == 2 (round 5): TWO MFMAs per product on fp16 operands — the activation as ONE fp16 value (11 significant bits: 2^-12
+  // per element, an error that stays in this layer's weight gradient), dz as an fp16 (hi, lo) pair: a.dz_hi + a.dz_lo — a
+  // third fewer MFMAs and three instead of four transposed fragment reads per pair, the two things that bound this kernel
+  // (profiles/r04/wgrad_read_pipeline.txt).  dz still arrives as bf16 pair records (the data gradient keeps its arithmetic);
+  // the producers turn every (hi, lo) bf16 pair into v = hi + lo (exact in fp32), scale it by the power of two that puts
+  // the layer's largest |dz| (WgradLaunch::dz_absmax, written by the BatchNorm backward) into [2^14, 2^15), and split v
+  // again into an fp16 pair (22 bits: nothing of the 16 is lost); the slabs carry that factor and the reduction removes it.
   constexpr bool X16 = OM == 1 || OM == 2, D16 = OM >= 1;  // operand storage, see wg_mfma above
   // consumer wave = 16 ci x CO co (MI = 1, NI = CO/16 = 2, 3 or 4): an A fragment (re-read for every tap)
   // feeds 3*NI MFMAs; at NI = 4, 52 instead of 80 transposed LDS reads per 108 MFMAs of a 32x32 arrangement.
@@ -360,7 +390,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   constexpr int XA = (MIMO_WGRAD_ABLATE & 2) ? 1 : (MIMO_WGRAD_ABLATE & 1) ? (kWsAPix * QA / 2 + 255) / 256 : (kWsAPix * QA + 255) / 256;
   constexpr int XD = (MIMO_WGRAD_ABLATE & 4) ? 1 : (kWsDPix * QD + 255) / 256;
 #else
-  constexpr int XA = (kWsAPix * QA + 255) / 256, XD = (kWsDPix * QD + 255) / 256;  // per producer thread
+  constexpr int XA = (kWsAPix * QA + 255) / 256;  // per producer thread
+  constexpr int XD = NP == 2 ? 2 * ((kWsDPix * (CO / 8) + 255) / 256) : (kWsDPix * QD + 255) / 256;
 #endif
   constexpr int ABYTES = kWsAPix * PA, DBYTES = kWsDPix * PD, BUFBYTES = ABYTES + DBYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFBYTES];
@@ -404,6 +435,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     }
 #pragma unroll
     for (int k = 0; k < XD; ++k) {
+      if constexpr (NP == 2) {
+        // pair units: unit 2 kp = the hi plane, 2 kp + 1 = the lo plane of the SAME 8 channels of one pixel (the thread
+        // re-splits the pair), kp over (pixel, 8-channel group)
+        const int kp = k >> 1, is_lo = k & 1;
+        const int u = min(ptid + kp * 256, kWsDPix * (CO / 8) - 1);
+        const int pix = u / (CO / 8), c8 = u - pix * (CO / 8);
+        d_r[k] = pix / kWgTC;
+        d_c[k] = pix % kWgTC;
+        const int ch = co0 + 8 * c8, rc = min(32, a.cout_p - (ch & ~31));
+        d_ch[k] = ch < a.cout_p ? (ch >> 5) * 64 + is_lo * rc + (ch & 31) : -1;
+        d_dst[k] = ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + is_lo * 2 * CO + c8 * 16;
+      } else {
       const int u = min(ptid + k * 256, kWsDPix * QD - 1);  // units past the tile repeat its last unit (see a_dst)
       const int pix = u / QD, qq = u - pix * QD;
       const int half = D16 ? 0 : qq / (CO / 8), c8 = qq - half * (CO / 8);  // pre-split dz: 8 channels of the hi or lo plane
@@ -414,7 +457,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
                     ? (D16 ? ch : (ch >> 5) * 64 + half * rc + (ch & 31))  // plain NHWC / pair records, in 16-bit units
                     : -1;
       d_dst[k] = ABYTES + pix * PD + ((pix >> 3) & 1) * 32 + half * 2 * CO + c8 * 16;
+      }
     }
+    // NP == 2: the power of two that scales this layer's dz into fp16 range (see the kernel comment)
+    const float dz_mul = NP == 2 ? wg_dz_scale(*a.dz_absmax, false) : 1.f;
+    (void)dz_mul;
     f32x4 in_sc = f32x4{0.f, 0.f, 0.f, 0.f}, in_sh = f32x4{0.f, 0.f, 0.f, 0.f};
     if (FIN && a_ch[0] >= 0) {  // (channels past cin_p are loaded from the zero page and must stay zero: relu(0 * 0 + 0))
       in_sc = *reinterpret_cast<const f32x4*>(a.in_scale + a_ch[0]);
@@ -461,6 +508,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       *reinterpret_cast<f32x4*>(DST) = (V);                                                         \
     } else if (OM != 0) { /* fp32 image operand in a 16-bit mode: one rounding, no lo part */       \
       *reinterpret_cast<bf16x4*>(DST) = wg_round4<OM>(V);                                           \
+    } else if (NP == 2) { /* one fp16 value per activation */                                      \
+      f16x4_w h_;                                                                                   \
+      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                              \
+        h_[e_] = (_Float16)(FIN ? fmaxf(fmaf((V)[e_], in_sc[e_], in_sh[e_]), 0.f) : (V)[e_]);       \
+      *reinterpret_cast<f16x4_w*>(DST) = h_;                                                        \
     } else {                                                                                        \
       bf16x4 hi_, lo_;                                                                              \
       _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                            \
@@ -479,7 +531,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       unsigned char* d_ = base_ + a_dst[k_];                                                        \
       WS_SPLIT_STORE(XA_[k_], d_, CI)                                                               \
     }                                                                                               \
-    _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                             \
+    if (NP == 2) { /* bf16 (hi, lo) records -> scaled fp16 (hi, lo) */                              \
+      _Pragma("unroll") for (int k_ = 0; k_ + 1 < XD; k_ += 2) {                                    \
+        f32x4 oh_, ol_;                                                                             \
+        wg_dz_pair_to_f16(XD_[k_], XD_[k_ + 1], dz_mul, &oh_, &ol_);                                \
+        *reinterpret_cast<f32x4*>(base_ + d_dst[k_]) = oh_;                                         \
+        *reinterpret_cast<f32x4*>(base_ + d_dst[k_ + 1]) = ol_;                                     \
+      }                                                                                             \
+    } else _Pragma("unroll") for (int k_ = 0; k_ < XD; ++k_) {                                      \
       *reinterpret_cast<f32x4*>(base_ + d_dst[k_]) = XD_[k_]; /* plain copy */                      \
     }                                                                                               \
   }
@@ -538,8 +597,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       // r.  One MFMA per product (16-bit storage, bf16 mode): a tap is NI MFMAs = 16 * NI cycles of matrix-pipe time,
       // far below the ~130-cycle latency of a transposed LDS read -> two taps ahead (round 3: with one tap ahead that
       // path waited for LDS at every tap, 598 -> 789 TFLOP/s on the class).  Three MFMAs per product: one tap ahead.
-      constexpr int kDepth = NP == 3 ? 1 : 2;
-      bf16x8 bh[2][NI], bl[NP == 3 ? 2 : 1][NI], ah[kDepth + 1][MI], al[NP == 3 ? kDepth + 1 : 1][MI];
+      constexpr int kDepth = NP >= 2 ? 1 : 2;
+      bf16x8 bh[2][NI], bl[NP >= 2 ? 2 : 1][NI], ah[kDepth + 1][MI], al[NP == 3 ? kDepth + 1 : 1][MI];
       // the fragment addresses of all TR x taps steps are loop-invariant; hoisted out of the tile loop they would take
       // ~45 registers (spills) — an opaque copy of the lane's row index per tile keeps them recomputed in place
       int rowk_ = rowk;
@@ -549,7 +608,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
     const unsigned char* d0_ = ds_ + ((R) * kWgTC + rowk_) * PD + dcol;              \
     _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                              \
       bh[SLOT][ni] = tr_read8(d0_ + ni * 32, d0_ + ni * 32 + 4 * PD);                \
-      if (NP == 3) bl[SLOT][ni] = tr_read8(d0_ + ni * 32 + 2 * CO, d0_ + ni * 32 + 2 * CO + 4 * PD); \
+      if (NP >= 2) bl[SLOT][ni] = tr_read8(d0_ + ni * 32 + 2 * CO, d0_ + ni * 32 + 2 * CO + 4 * PD); \
     }                                                                                \
   }
 #define WS_READ_A1(SLOT, R, TAP)                                                     \
@@ -565,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
 #define WS_TILE1(T0, NT)                                                             \
   {                                                                                  \
     constexpr int kSteps = kWsTR * (NT);                                             \
-    constexpr int kRB = (NP == 3 ? 4 : 2) * NI, kRA = (NP == 3 ? 4 : 2) * MI;        \
+    constexpr int kRB = (NP >= 2 ? 4 : 2) * NI, kRA = (NP == 3 ? 4 : 2) * MI;        \
     WS_READ_B(0, 0)                                                                  \
     _Pragma("unroll") for (int s_ = 0; s_ < kDepth; ++s_)                            \
       WS_READ_A1(s_ % (kDepth + 1), s_ / (NT), (T0) + s_ % (NT))                     \
@@ -581,11 +640,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                              \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                          \
           f32x4 c = acc[tt][mi][ni];                                                 \
-          if (NP == 3) {                                                             \
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s_ % (kDepth + 1)][mi], bh[r_ & 1][ni], c, 0, 0, 0); \
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s_ % (kDepth + 1)][mi], bl[r_ & 1][ni], c, 0, 0, 0); \
-          }                                                                          \
-          acc[tt][mi][ni] = wg_mfma<OM>(ah[s_ % (kDepth + 1)][mi], bh[r_ & 1][ni], c); \
+          if (NP == 3) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s_ % (kDepth + 1)][mi], bh[r_ & 1][ni], c, 0, 0, 0); \
+          if (NP == 3) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s_ % (kDepth + 1)][mi], bl[r_ & 1][ni], c, 0, 0, 0); \
+          if (NP == 2) c = wg_mfma<2>(ah[s_ % (kDepth + 1)][mi], bl[r_ & 1][ni], c);  /* fp16: a . dz_lo */ \
+          acc[tt][mi][ni] = wg_mfma<(NP == 2 ? 2 : OM)>(ah[s_ % (kDepth + 1)][mi], bh[r_ & 1][ni], c); \
         }                                                                            \
       if (rb_ && ra_) {                                                              \
         __builtin_amdgcn_sched_group_barrier(0x100, kRB + kRA, 0);                   \
@@ -640,10 +698,18 @@ int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int 
   return sched::wg_pick_splits(N, H, W, cin_pad, cout_pad, CI, CO, wgrad_ws_enabled(), mode, wgrad_s16(store));
 }
 
+// 1 when this geometry runs on the kernel that has the two-MFMA (fp16) instances: WgradLaunch::np = 2
+int wgrad_split_has_np2(int cin_p, int cout_p) {
+  const bool on = !(getenv("MIMO_WGRAD_NP") && atoi(getenv("MIMO_WGRAD_NP")) == 3);  // =3: three bf16 MFMAs (rounds 1-4); read per plan / call
+  int CI, CO;
+  wgrad_split_tiles(cin_p, cout_p, &CI, &CO);
+  return on && wgrad_use_ws(CI, CO) ? 1 : 0;
+}
+
 int wgrad_split_fuses_input(int cin_p, int cout_p, int store, int np) {
   int CI, CO;
   wgrad_split_tiles(cin_p, cout_p, &CI, &CO);
-  return wgrad_use_ws(CI, CO) && store == 0 && np == 3 ? 1 : 0;
+  return wgrad_use_ws(CI, CO) && store == 0 && np >= 2 ? 1 : 0;
 }
 
 int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
@@ -654,7 +720,11 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
     return MIMO_ERR_INVALID;
   }
   const bool ws = wgrad_use_ws(CI, CO);
-  if (a.in_scale && !(ws && a.store == 0 && a.np == 3 && a.in_shift)) {
+  if (a.np == 2 && !(ws && a.store == 0 && a.dz_absmax)) {
+    set_error("wgrad_split: two MFMAs per product need the wave-specialised kernel, fp32 storage and WgradLaunch::dz_absmax");
+    return MIMO_ERR_INVALID;
+  }
+  if (a.in_scale && !(ws && a.store == 0 && a.np >= 2 && a.in_shift)) {
     set_error("wgrad_split: this geometry cannot apply the input BatchNorm + ReLU in its loader (wgrad_split_fuses_input)");
     return MIMO_ERR_INVALID;
   }
@@ -670,7 +740,7 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
   if (ws) {
     grid = dim3(grid.x * grid.y);  // 1-D, decoded XCD-aware inside the kernel
 #define WS_LAUNCH3(NP_, NI_, CI_, TR_, OM_)                                                                             \
-  if constexpr ((NP_) == 3 && (OM_) == 0) {                                                                             \
+  if constexpr ((NP_) >= 2 && (OM_) == 0) {                                                                             \
     if (a.in_scale)                                                                                                     \
       hipLaunchKernelGGL((wgrad_split_ws_kernel<NP_, NI_, CI_, TR_, OM_, true>), grid, dim3(512), 0, stream, a, tilesY, tilesX, numTiles); \
     else                                                                                                                \
@@ -687,6 +757,8 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
     default:                                     \
       if (a.np == 1) {                           \
         WS_LAUNCH3(1, NI_, CI_, TR_, 0);         \
+      } else if (a.np == 2) {                    \
+        WS_LAUNCH3(2, NI_, CI_, TR_, 0);         \
       } else {                                   \
         WS_LAUNCH3(3, NI_, CI_, TR_, 0);         \
       }                                          \

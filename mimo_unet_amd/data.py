@@ -36,6 +36,18 @@ from typing import Any, Dict, Iterable, Iterator, List, Optional
 import torch
 
 
+def _host_copy(dst: torch.Tensor, src: torch.Tensor) -> None:
+    """pageable -> pinned staging copy on the calling thread.  Not `dst.copy_(src)`: torch parallelises large host copies
+    over its intra-op thread pool, and waking that pool once per tensor and step from an otherwise GPU-bound loop cost
+    5-20 ms per step on the 256-core GPU boxes (measured: cfg3 at 4 images per GPU 4.6 -> 24 ms per step,
+    profiles/r05/data_path.txt); one memmove of a contiguous tensor is 0.3 ms per 3 MB and releases the GIL."""
+    if src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype:
+        import ctypes
+        ctypes.memmove(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size())
+    else:
+        dst.copy_(src)
+
+
 class _Slot:
     __slots__ = ("host", "dev", "uploaded", "consumed", "spec")
 
@@ -51,11 +63,10 @@ class DevicePrefetcher:
     """Iterate `batches` (dicts of host tensors; non-tensor values pass through) as device-resident dicts.
 
     depth: batches uploaded ahead of the one being consumed (2 = double buffer in front of the step).
-    pinned: None = look at the first batch (`Tensor.is_pinned()` per tensor, once: on ROCm that query costs ~10 ms for a
-    pageable tensor — measured, profiles/r05/data_path.txt — so it cannot be asked every step) and assume the loader keeps
-    doing what it did; True / False = the caller states what the loader yields (`DataLoader(pin_memory=...)`).  A wrong
-    assumption is slow, not wrong: a pageable tensor taken for pinned is uploaded by torch's blocking copy, a pinned one
-    taken for pageable goes through the staging ring."""
+    pinned: None = look at the first batch (`Tensor.is_pinned()` per tensor) and assume the loader keeps doing what it
+    did; True / False = the caller states what the loader yields (`DataLoader(pin_memory=...)`).  A wrong assumption is
+    slow, not wrong: a pageable tensor taken for pinned is uploaded by torch's blocking copy, a pinned one taken for
+    pageable goes through the staging ring."""
 
     def __init__(self, batches: Iterable[Dict[str, Any]], device="cuda", depth: int = 2, pinned: Optional[bool] = None):
         self.device = torch.device(device)
@@ -120,7 +131,7 @@ class DevicePrefetcher:
                     h = slot.host.get(k)
                     if h is None or h.shape != v.shape or h.dtype != v.dtype or h is v:
                         h = torch.empty(v.shape, dtype=v.dtype).pin_memory()
-                    h.copy_(v)
+                    _host_copy(h, v)
                     slot.host[k] = h
                     self.staged_copies += 1
                     slot.dev[k].copy_(h, non_blocking=True)

@@ -27,3 +27,17 @@ for name, shape in (("cfg3 batch 32 image", (32, 2, 256, 256)), ("cfg3 batch 4 i
         torch.cuda.synchronize()
     print(f"  pinned -> device, non_blocking + sync     {t(lambda: up(pin, True)):8.3f} ms")
     print(f"  pageable -> device (torch's blocking copy){t(lambda: up(page, False)):8.3f} ms")
+
+
+# the staging copy inside a loop that does other things between copies (torch's intra-op thread pool asleep when it is called)
+import ctypes
+page, pin = torch.rand(4, 2, 256, 256), torch.rand(4, 2, 256, 256).pin_memory()
+for name, f in (("dst.copy_(src), default threads", lambda: pin.copy_(page)),
+                ("ctypes.memmove", lambda: ctypes.memmove(pin.data_ptr(), page.data_ptr(), page.numel() * 4))):
+    ts = []
+    for _ in range(10):
+        time.sleep(0.005)
+        t0 = time.perf_counter()
+        f()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print(f"2.1 MB staging copy after 5 ms of other work, {name}: median {sorted(ts)[5]:.3f} ms, max {max(ts):.3f} ms ({torch.get_num_threads()} torch threads)")

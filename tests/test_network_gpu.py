@@ -578,7 +578,10 @@ def test_caller_masks_on_blocks_built_without_dropout_are_honoured_in_both_direc
         res.append((o["loss"].detach().cpu(), o["preds"].cpu(), m.model.flat_gradients().clone().cpu()))
         e_out = rel_err(o["preds"].view(N, S, 1, H, W).cpu(), ref["out"][:, :, :1])
         e_loss = abs(float(o["loss"]) - float(ref["total"])) / abs(float(ref["total"]))
-        worst = check_grads(grads, ref["grads"], tol=5e-3)  # a 16-channel net: one ReLU flip is a few 1e-3 of a tensor
+        # a 16-channel net at 64 x 64 with half of several blocks' channels dropped: single ReLU / max-pool flips move a
+        # tensor by up to ~5e-3 of its scale (observed 5.2e-3 on one BatchNorm bias); what this test is after — a multiplier
+        # applied in one direction only — moves the masked blocks' gradients by O(1)
+        worst = check_grads(grads, ref["grads"], tol=2e-2)
         report(f"{kind} multipliers on rate-0 blocks, MIMO_FUSE_BN_IN={flag}: out {e_out:.1e} loss {e_loss:.1e} worst grad {worst}")
         assert e_out < TOL and e_loss < TOL
     for x, y in zip(*res):

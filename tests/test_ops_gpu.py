@@ -55,7 +55,9 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv3x3_forward_dgrad_wgrad(case, precision):
     """fp32: f32-input MFMA (exact fp32 products).  split16: fp16 hi/lo forward (~2^-22 per product),
-    bf16 hi/lo data and weight gradients (~1e-5 per product) -> tolerance 1e-4.  bf16: operands rounded to
+    bf16 hi/lo data gradient (~1e-5 per product) -> tolerance 1e-4; weight gradient (round 5, where the geometry has the
+    wave-specialised kernel): the activation as ONE fp16 value (2^-12 per element, random sign) times an fp16 (hi, lo) pair
+    of dz -> 3e-4 of the tensor's scale (observed <= 1.5e-4, profiles/r05/parity_errors.txt).  bf16: operands rounded to
     bf16 (2^-9 each), fp32 accumulation -> 2e-2 of the tensor's scale."""
     L = _lib()
     prec = L.PRECISIONS[precision]
@@ -101,7 +103,9 @@ def test_conv3x3_forward_dgrad_wgrad(case, precision):
     errs["bgrad"] = rel_err(dbd.cpu(), br.grad)
     report("conv", precision, case, {k: f"{v:.2e}" for k, v in errs.items()})
     stat_tol = TOL if precision != "bf16" else 2e-2  # the statistics are sums of the (bf16-product) outputs
-    bad = {k: v for k, v in errs.items() if not v < (TOL if k == "bgrad" else stat_tol if k in ("sum", "sumsq") else tol)}
+    wg_tol = 3e-4 if precision == "split16" else tol
+    bad = {k: v for k, v in errs.items()
+           if not v < (TOL if k == "bgrad" else stat_tol if k in ("sum", "sumsq") else wg_tol if k == "wgrad" else tol)}
     assert not bad, bad
 
 
@@ -331,3 +335,44 @@ def test_storage_mode_conv_kernels_against_rounded_reference(case, mode):
     report(f"{mode} storage kernels", case, f"z {ez / ulp:.2f} ulp ({100 * same:.2f} % identical), dx {edx / ulp:.2f} ulp, dW {e_dw:.1e}, "
            f"sums {e_s1:.1e} / {e_s2:.1e}")
     assert ez <= 1.01 * ulp and same > 0.98 and edx <= 1.01 * ulp and e_dw < 5e-6 and e_s1 < 1e-5 and e_s2 < 1e-5
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 64, 1e-6), (1, 96, 80, 30, 30, 1.0), (2, 32, 32, 120, 60, 3e-9), (1, 40, 40, 45, 30, 1e4)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_two_mfma_weight_gradient_scaling_and_accuracy(case, monkeypatch):
+    """Round 5: the wave-specialised weight gradient multiplies the activation as one fp16 value with dz
+    as an fp16 (hi, lo) pair — two MFMAs per product — after scaling dz by the power of two that puts the layer's largest
+    |dz| into [2^14, 2^15).  Against the fp64 gradient of the reference convolution (components.py:23,26): gradients of
+    realistic magnitude (1e-6: the loss is a mean over millions of pixels), tiny and huge ones, a heavy-tailed dz (a few
+    elements 1e4 x the rest: the scale follows the maximum, the bulk keeps >= 8 significant bits in the hi part alone), and
+    an all-zero dz; the three-MFMA bf16 arithmetic of rounds 1-4 (MIMO_WGRAD_NP=3) on the same inputs as yardstick."""
+    L = _lib()
+    lib = L.load()
+    N, H, W, Ci, Co, mag = case
+    g = torch.Generator().manual_seed(int(N * H + Ci))
+    x = torch.randn(N, Ci, H, W, generator=g).abs() * 1.5  # post-ReLU activations
+    dz = torch.randn(N, Co, H, W, generator=g) * mag
+    dz.view(-1)[torch.randint(0, dz.numel(), (16,), generator=g)] *= 1e4  # heavy tail
+    w64 = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    O.conv3x3_reflect(x.double(), w64, None).backward(dz.double())
+    ref = w64.grad
+    cip, cop = pad8(Ci), pad8(Co)
+    xd, dzd = to_nhwc(x, cip), to_nhwc(dz, cop)
+    st = L.current_stream()
+    errs = {}
+    for np_ in ("2", "3"):
+        monkeypatch.setenv("MIMO_WGRAD_NP", np_)
+        dwd = torch.full((Co, Ci, 3, 3), float("nan"), device="cuda")
+        dbd = torch.full((Co,), float("nan"), device="cuda")
+        L.check(lib.mimo_op_conv3x3_wgrad(xd.data_ptr(), dzd.data_ptr(), dwd.data_ptr(), dbd.data_ptr(), N, H, W, Ci, cip, Co, cop,
+                                          L.PRECISIONS["split16"], st), "conv wgrad")
+        errs[np_] = rel_err(dwd.cpu(), ref)
+        assert torch.isfinite(dwd).all()
+    report(f"two-MFMA weight gradient {case}: error vs fp64 {errs['2']:.2e} (three bf16 MFMAs: {errs['3']:.2e})")
+    assert errs["2"] < 3e-4 and errs["3"] < 1e-4
+    monkeypatch.setenv("MIMO_WGRAD_NP", "2")
+    zero = torch.zeros_like(dzd)
+    dwd = torch.full((Co, Ci, 3, 3), float("nan"), device="cuda")
+    L.check(lib.mimo_op_conv3x3_wgrad(xd.data_ptr(), zero.data_ptr(), dwd.data_ptr(), dbd.data_ptr(), N, H, W, Ci, cip, Co, cop,
+                                      L.PRECISIONS["split16"], st), "conv wgrad")
+    assert float(dwd.abs().max()) == 0.0
