@@ -459,7 +459,7 @@ def main():
                    "optimizer": "adam(lr=1e-3) fused", "final_loss": round(final_loss, 5),
                    "inputs": ("resident in HBM" if prefetcher is None else
                               f"{args.host_batches} host tensors every step -> DevicePrefetcher(depth=2): "
-                              f"{prefetcher.throttle_waits} throttle waits, {prefetcher.staged_copies} staged copies"),
+                              f"the step waited for its worker {prefetcher.starved} times, {prefetcher.pageable_uploads} tensors from pageable memory"),
                    # host time to enqueue one step on an idle GPU (rank 0): well below ms_per_step = the GPU, not the launch path, bounds the step
                    "host_enqueue_ms_per_step": None if host_enqueue_ms is None else round(host_enqueue_ms, 3),
                    "streams": ("weight gradients on the caller's stream" if os.environ.get("MIMO_WGRAD_STREAM") == "0" else

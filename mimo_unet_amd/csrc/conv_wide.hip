@@ -627,7 +627,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
     f32x4 v = f32x4{sav[m_][4 * j_], sav[m_][4 * j_ + 1], sav[m_][4 * j_ + 2], sav[m_][4 * j_ + 3]};  \
     if (F16) v = v * (1.f / kWideF16Scale);                                                          \
     if (FWD) v = v + ep_b;                                                                           \
-    /* a padded channel quad (co0 + 8 j >= cout_store: wave-uniform; cout_store is a multiple of 8) is not stored */ \
+    /* a padded channel quad is not stored (co0 + 8 j >= cout_store: wave-uniform — sched::wide_config keeps launches whose  \
+       stored channels are not a multiple of 8, the 4-channel image gradient, off this kernel) */    \
     const unsigned vo_ = co0 + 8 * j_ < a.cout_store ? sv_off[m_] : kNoStore;                        \
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sv_rsrc, (int)vo_, 8 * j_ * (int)sizeof(OT_), 0); \
     if (STATS) {                                                                                     \
@@ -824,6 +825,10 @@ int conv3x3_wide_launch(const ConvLaunch& a, int mode, int* rows, hipStream_t st
   const sched::WideCfg c = sched::wide_config(mode, a.N, a.cin_p, a.cout_store, a.Ho, a.Wo, 1);
   if (!a.wpk || c.nf == 0 || c.rows_pad != a.wide || a.ldx % 4 != 0 || a.ldy % 4 != 0 || a.Hi < 2 || a.Wi < 2) {
     set_error("conv3x3 wide: weights packed for %d rows, launch geometry gives %d (nf %d)", a.wide, c.rows_pad, c.nf);
+    return MIMO_ERR_INVALID;
+  }
+  if (mode == 0 && a.cout_store % 8 != 0) {
+    set_error("conv3x3 wide data gradient: %d stored channels (a multiple of 8 is needed)", a.cout_store);
     return MIMO_ERR_INVALID;
   }
   if ((int64_t)a.Ho * a.Wo * a.ldy * 4 >= (int64_t)0x7fff0000) {  // 32-bit store offsets of the deferred epilogue (kNoStore)

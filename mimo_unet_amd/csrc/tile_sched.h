@@ -144,6 +144,9 @@ static inline WideCfg wide_config(int mode, int N, int cin_p, int rows, int Ho, 
   const bool s16 = mode >= 4 && mode <= 7;  // 16-bit storage modes: 32-channel chunks, one MFMA per product
   if (force < 0 || !(mode == 0 || mode == 1 || s16) || rows < 1 || cin_p < 16 || Ho < 2 || Wo < 2) return c;
   if (s16 && cin_p % 8 != 0) return c;
+  // the split16 data gradient's 32-channel instance stores whole pairs of channel quads (its deferred epilogue tests
+  // co0 + 8 j < stored channels per wave, not per lane): the 4-channel image gradient stays on the 256-pixel kernel
+  if (mode == 0 && rows % 8 != 0) return c;
   // the kernel carries per-unit source offsets (iy * Wi + ix) * ld * element size as 32-bit integers: a layer whose
   // input image (padded-domain gradients: + 2 rows / columns; ld >= cin_p) reaches 2 GiB stays on the 256-pixel kernel
   // (pixel pitch taken as up to twice the wider channel count: a channel slice of a concat buffer; the launch checks

@@ -95,24 +95,20 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// NP == 2 kernels: a bf16 (hi, lo) record pair of 8 channels -> v = hi + lo (exact in fp32) -> v * mul (a power of two) ->
-// fp16 (hi, lo): hi = RNE(v), lo = RNE(v - hi).  Element order of the 16-byte units is kept.
+// NP == 2 kernels: a bf16 (hi, lo) record pair of 8 channels -> the SAME pair as fp16 values, scaled by `mul` (a power of two):
+// hi * mul and lo * mul each have 8 significant bits, so both conversions are exact (no re-splitting, any rounding mode) for
+// every element within 2^-21 of the layer's largest |dz| — below that the lo part runs into fp16's subnormals and loses bits
+// of a value that contributes nothing.  5 vector instructions per element (re-splitting hi + lo: 8).  Element order kept.
 __device__ __forceinline__ void wg_dz_pair_to_f16(f32x4 hi_raw, f32x4 lo_raw, float mul, f32x4* out_hi, f32x4* out_lo) {
   typedef unsigned int u32x4_w __attribute__((ext_vector_type(4)));
-  typedef _Float16 f16x2_w __attribute__((ext_vector_type(2)));
   const u32x4_w h = __builtin_bit_cast(u32x4_w, hi_raw), l = __builtin_bit_cast(u32x4_w, lo_raw);
   u32x4_w oh, ol;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float f0 = (__uint_as_float(h[e] << 16) + __uint_as_float(l[e] << 16)) * mul;
-    const float f1 = (__uint_as_float(h[e] & 0xffff0000u) + __uint_as_float(l[e] & 0xffff0000u)) * mul;
-    f16x2_w a, b;
-    a[0] = (_Float16)f0;
-    a[1] = (_Float16)f1;
-    b[0] = (_Float16)(f0 - (float)a[0]);
-    b[1] = (_Float16)(f1 - (float)a[1]);
-    oh[e] = __builtin_bit_cast(unsigned int, a);
-    ol[e] = __builtin_bit_cast(unsigned int, b);
+    oh[e] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(h[e] << 16) * mul,
+                                                                        __uint_as_float(h[e] & 0xffff0000u) * mul));
+    ol[e] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(l[e] << 16) * mul,
+                                                                        __uint_as_float(l[e] & 0xffff0000u) * mul));
   }
   *out_hi = __builtin_bit_cast(f32x4, oh);
   *out_lo = __builtin_bit_cast(f32x4, ol);
@@ -369,9 +365,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
   // per element, an error that stays in this layer's weight gradient), dz as an fp16 (hi, lo) pair: a.dz_hi + a.dz_lo — a
   // third fewer MFMAs and three instead of four transposed fragment reads per pair, the two things that bound this kernel
   // (profiles/r04/wgrad_read_pipeline.txt).  dz still arrives as bf16 pair records (the data gradient keeps its arithmetic);
-  // the producers turn every (hi, lo) bf16 pair into v = hi + lo (exact in fp32), scale it by the power of two that puts
-  // the layer's largest |dz| (WgradLaunch::dz_absmax, written by the BatchNorm backward) into [2^14, 2^15), and split v
-  // again into an fp16 pair (22 bits: nothing of the 16 is lost); the slabs carry that factor and the reduction removes it.
+  // the producers scale both halves of every (hi, lo) bf16 pair by the power of two that puts the layer's largest |dz|
+  // (WgradLaunch::dz_absmax, written by the BatchNorm backward) into [2^14, 2^15) and convert them to fp16 — exactly, 8
+  // significant bits each (wg_dz_pair_to_f16); the slabs carry that factor and the reduction removes it.
   constexpr bool X16 = OM == 1 || OM == 2, D16 = OM >= 1;  // operand storage, see wg_mfma above
   // consumer wave = 16 ci x CO co (MI = 1, NI = CO/16 = 2, 3 or 4): an A fragment (re-read for every tap)
   // feeds 3*NI MFMAs; at NI = 4, 52 instead of 80 transposed LDS reads per 108 MFMAs of a 32x32 arrangement.

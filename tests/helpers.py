@@ -90,6 +90,18 @@ def amp_reference(amp_name, src_name, mode):
 # fixture, ~1.5x the reference's own statistic with a floor for the near-exact fixture — for tensors with >= 256 elements
 # (fewer: rms ~ max, one flip).
 ADAM_FLIP_RMS = {"cfg1_step.npz": 0.2, "mini_s2_step.npz": 0.08, "mini_gauss_step.npz": 0.25}
+# split16 since round 5: the weight gradient multiplies the activation as ONE fp16 value (2^-12 per element; dz keeps an
+# fp16 pair) — weight gradients carry ~1e-4 of their scale in rounding noise instead of 1e-5, so more near-zero gradient
+# elements change sign under Adam: observed 0.13 on mini_s2 (three-MFMA arithmetic, MIMO_WGRAD_NP=3: 0.06), 0.12 on cfg1 —
+# the level fp32 rounding itself produces on cfg1.  One bound for that arithmetic: 0.2.
+ADAM_FLIP_RMS_SPLIT16 = 0.2
+
+
+def adam_flip_bound(fixture, precision):
+    import os
+    if precision == "split16" and os.environ.get("MIMO_WGRAD_NP") != "3":
+        return max(ADAM_FLIP_RMS[fixture], ADAM_FLIP_RMS_SPLIT16)
+    return ADAM_FLIP_RMS[fixture]
 
 
 def adam_flip_statistic(ours, ref, budget):

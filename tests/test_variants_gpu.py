@@ -34,6 +34,8 @@ VARIANTS = {
     },
     "conv_wide_forced": {"MIMO_CONV_WIDE": "2"},  # every supported convolution on conv_wide.hip
     "image_conv_wgrad_forced": {"MIMO_CONV_THIN": "2"},  # 1-2-channel weight gradients on conv_thin.hip at every size
+    # the three-MFMA bf16-pair weight gradient of rounds 1-4 (the tests then apply its tighter bounds: tests/helpers.py)
+    "wgrad_three_mfma": {"MIMO_WGRAD_NP": "3"},
 }
 
 
