@@ -54,6 +54,20 @@ __device__ __forceinline__ int xcd_virtual_index(int linear, int total) {
 // off == 1: Ho==Hi, X is reflect-padded (forward conv, components.py:23,26)
 // off == 2: Ho==Hi+2, X is zero outside the image (transposed conv producing the gradient on
 //           the reflect-PADDED domain; consumers fold the border back, see fold_* in elementwise.hip)
+// Scale of the fp16 (hi, lo) weight images of the split16 / 16-mixed forward: 2^8 (rounds 1-4: keeps ordinary weights out of
+// fp16's subnormals) while the layer's largest |w| is below 128; from there the power of two that puts max |w| into
+// [2^13, 2^14) — a layer with |w| >= 256 no longer overflows its hi part (round 5: the reference's fp32 Conv2d is finite for
+// any fp32 weight, components.py:23,26).  `wmax_bits` = float bits of max |w| (wabsmax_jobs_launch); inverse: the
+// reciprocal, applied in the convolution's epilogue.  Both are exact powers of two.
+__host__ __device__ __forceinline__ float w16_scale(unsigned wmax_bits, bool inverse) {
+  const int e = (int)((wmax_bits >> 23) & 0xffu) - 127;  // floor(log2 max |w|)
+  int k = e < 7 ? 8 : 13 - e;                            // scale = 2^k
+  k = k < -100 ? -100 : k;
+  union { unsigned u; float v; } c;
+  c.u = (unsigned)(127 + (inverse ? -k : k)) << 23;
+  return c.v;
+}
+
 struct ConvLaunch {
   const float* x;
   float* y;
@@ -81,6 +95,9 @@ struct ConvLaunch {
   // DoubleConv) — so that the activated tensor is never written to HBM
   const float* in_scale = nullptr;
   const float* in_shift = nullptr;
+  // fp16 weight images (modes 1 and 6): device word with the float bits of the layer's max |w| the image was packed with
+  // (w16_scale); nullptr: the image carries the fixed 2^8 (per-operator entry points)
+  const unsigned* wmax = nullptr;
 };
 // 1 when conv3x3_bf16x3_launch(mode) runs this launch on a kernel whose loaders can apply ConvLaunch::in_scale / in_shift
 int conv3x3_split_fuses_input(int mode, int wide, int Ho, int Wo);
@@ -187,8 +204,11 @@ struct PackJob {
   int kind, cout, cin, rows_pad, cols, transposed, total, bias_n;
   int pair;  // kind 1 / 2: tap-paired image of the last chunk (conv3x3_pair_tail)
   int map_rows;  // kind 3 / 4: entries of row_map (rows_pad may exceed it)
+  unsigned* wmax;  // fp16 kinds (1, 3, 5): max |w| of the layer, float bits, monotone (wabsmax_jobs_launch); image scale = w16_scale
 };
 int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream);
+// max |w| of every job with a wmax word (run in front of pack_jobs_launch; the words only ever grow)
+int wabsmax_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream);
 
 // weight packing: torch OIHW -> [9][rows_pad][cols] (see conv3x3.hip)
 int pack_weights_launch(const float* w, float* dst, int cout, int cin, int rows_pad, int cols,

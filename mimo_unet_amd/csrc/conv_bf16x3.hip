@@ -311,6 +311,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
   }
   typedef typename std::conditional<OUT16, ET, float>::type OT;
   OT* yimg = reinterpret_cast<OT*>(a.y) + (size_t)n * a.Ho * a.Wo * a.ldy;
+  const float winv = !F16 ? 1.f : a.wmax ? w16_scale(*a.wmax, true) : 1.f / kF16WeightScale;  // the fp16 image's scale
 #pragma unroll
   for (int m = 0; m < MF; ++m) {
 #pragma unroll
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16x3_kernel(ConvLaunch a, int T
         OT* yp = yimg + ((size_t)oy * a.Wo + ox) * a.ldy + co0 + lr;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
-          float v = acc[m][nf][r4] * (F16 ? 1.f / kF16WeightScale : 1.f) + bv[nf];
+          float v = acc[m][nf][r4] * winv + bv[nf];
           if (a.ep_scale) {
             if (a.status && !isfinite(v)) atomicOr(a.status, 1);  // the ReLU below would drop a NaN
             v = fmaxf(fmaf(v, esc[nf], esh[nf]), 0.f) * emk[nf];
@@ -768,6 +769,8 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
     bv[nf] = (FWD && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + co0 + nf * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float winv = !F16 ? 1.f : a.wmax ? w16_scale(*a.wmax, true) : 1.f / kF16WeightScale;  // the fp16 image's scale
+  (void)winv;
   // tile-relative (row, column) of this lane's pixel in each of its MF fragments; row 0x4000 = not in the tile
   int prc[kWsMaxMF];
 #pragma unroll
@@ -877,7 +880,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
           /* bias, inference epilogue and BatchNorm sums exist on the forward only (CVT); the data   \
              gradient stores its accumulators as they are */                                         \
           f32x4 v = acc[m][nf];                                                                      \
-          if (F16) v = v * (1.f / kF16WeightScale);                                                  \
+          if (F16) v = v * winv;                                                                     \
           if (FWD) v = v + bv[nf];                                                                   \
           const int c_ = co0 + nf * 16 + g * 4;                                                      \
           if (FWD && a.ep_scale) {                                                                   \
@@ -1234,6 +1237,7 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, typename
 __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* __restrict__ params) {
   const PackJob j = jobs[blockIdx.y];
   const float* w = params + j.w_off;
+  const float wscale = j.wmax ? w16_scale(*j.wmax, false) : kF16WeightScale;  // fp16 kinds (1, 3, 5)
   if (blockIdx.x == 0 && j.bias_n > 0)
     for (int i = threadIdx.x; i < j.bias_n; i += blockDim.x) j.bias_dst[i] = params[j.bias_off + i];
   // One thread per (row, column) = one (output channel, input channel) pair: its nine taps are 36 contiguous bytes
@@ -1287,11 +1291,11 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
       if (j.kind == 0) {
         reinterpret_cast<float*>(j.dst)[((size_t)tap * j.rows_pad + row) * j.cols + col] = x;
       } else if (j.kind == 5) {
-        reinterpret_cast<_Float16*>(j.dst)[(((size_t)chunk * 9 + tap) * j.rows_pad + row) * 32 + k] = (_Float16)(x * kF16WeightScale);
+        reinterpret_cast<_Float16*>(j.dst)[(((size_t)chunk * 9 + tap) * j.rows_pad + row) * 32 + k] = (_Float16)(x * wscale);
       } else if (j.kind == 6) {
         reinterpret_cast<__bf16*>(j.dst)[(((size_t)chunk * 9 + tap) * j.rows_pad + row) * 32 + k] = (__bf16)x;
       } else if (j.kind == 3) {
-        const float xs = x * kF16WeightScale;
+        const float xs = x * wscale;
         const _Float16 hi = (_Float16)xs, lo = (_Float16)(xs - (float)hi);
         _Float16* d = reinterpret_cast<_Float16*>(j.dst) + (((size_t)chunk * 9 + tap) * j.rows_pad + row) * 32;
         d[k] = hi;
@@ -1302,7 +1306,7 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
         d[k] = hi;
         d[16 + k] = lo;
       } else if (j.kind == 1) {
-        const float xs = x * kF16WeightScale;
+        const float xs = x * wscale;
         const _Float16 hi = (_Float16)xs, lo = (_Float16)(xs - (float)hi);
         _Float16* d = reinterpret_cast<_Float16*>(j.dst) + (((size_t)chunk * 9 + slot) * j.rows_pad + row) * 64;
         d[kk] = hi;
@@ -1315,6 +1319,38 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
       }
     }
   }
+}
+
+// max |w| of each job's weight tensor into its wmax word (jobs without one: nothing).  A workgroup whose maximum stays below
+// 64 issues no atomic (the scale only changes from 128 up, w16_scale): for ordinary weights this is one read of the parameters.
+__global__ void wabsmax_jobs_kernel(const PackJob* __restrict__ jobs, const float* __restrict__ params) {
+  const PackJob j = jobs[blockIdx.y];
+  if (!j.wmax) return;
+  const float4* w4 = reinterpret_cast<const float4*>(params + j.w_off);  // (tensor offsets are multiples of 4 floats)
+  const int n = j.cout * j.cin * 9, n4 = n / 4;
+  float m = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const float4 v = w4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) m = fmaxf(m, fabsf(params[j.w_off + 4 * n4 + threadIdx.x]));
+  __shared__ float wm[4];
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (m >= 64.f) atomicMax(j.wmax, __float_as_uint(m));  // (non-negative floats order like their bit patterns)
+  }
+}
+
+int wabsmax_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream) {
+  if (njobs <= 0) return MIMO_OK;
+  const int gx = max(1, min(ceil_div(max_total / 9, 256 * 8), 128));
+  hipLaunchKernelGGL(wabsmax_jobs_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev, params);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
 }
 
 int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream) {

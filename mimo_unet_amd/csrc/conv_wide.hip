@@ -454,6 +454,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       s2[nf][j] = f32x2{0.f, 0.f};
     }
   typedef typename std::conditional<S16, ET, float>::type OT_;  // element type of the output tensor
+  const float winv = !F16 ? 1.f : a.wmax ? w16_scale(*a.wmax, true) : 1.f / kWideF16Scale;  // the fp16 weight image's scale
+  (void)winv;
   const bool odd = px & 1;
   // DEFER (round 5; 32-channel instances of the split16 training forward / data gradient): the epilogue of tile t does not
   // run between the tiles — where the four consumer waves of every CU push 64 KB each at the same moment and the matrix
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
         f32x4 t4_ = f32x4{0.f, 0.f, 0.f, 0.f}, q4_ = t4_;                                            \
         _Pragma("unroll") for (int m = 0; m < MF; ++m) {                                             \
           f32x4 v = f32x4{acc[m][nf][4 * j], acc[m][nf][4 * j + 1], acc[m][nf][4 * j + 2], acc[m][nf][4 * j + 3]}; \
-          if (F16) v = v * (1.f / kWideF16Scale); /* fp16 weights are packed x 2^8 */                \
+          if (F16) v = v * winv; /* the fp16 weight image carries a power-of-two scale (w16_scale) */ \
           if (FWD) v = v + b_;                                                                       \
           if (EPI) {                                                                                 \
             if (a.status && yo_[m] >= 0 && !(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]))) \
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
       ep_q4 = ep_t4;                                                                                 \
     }                                                                                                \
     f32x4 v = f32x4{sav[m_][4 * j_], sav[m_][4 * j_ + 1], sav[m_][4 * j_ + 2], sav[m_][4 * j_ + 3]};  \
-    if (F16) v = v * (1.f / kWideF16Scale);                                                          \
+    if (F16) v = v * winv;                                                                           \
     if (FWD) v = v + ep_b;                                                                           \
     /* a padded channel quad is not stored (co0 + 8 j >= cout_store: wave-uniform — sched::wide_config keeps launches whose  \
        stored channels are not a multiple of 8, the 4-channel image gradient, off this kernel) */    \

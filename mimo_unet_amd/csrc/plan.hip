@@ -88,6 +88,7 @@ struct ConvBN {
   float *wf = nullptr, *wd = nullptr, *bias_p = nullptr;
   void *wf16 = nullptr, *wd16 = nullptr;  // split-bf16 packed weights (MIMO_PREC_SPLIT16)
   bool fwd_split = false, dg_split = false, wg_split = false;
+  unsigned* wmax = nullptr;  // fp16 forward weight image: max |w| of the layer, float bits (w16_scale: the image's power-of-two scale)
   unsigned* dz_absmax = nullptr;  // != nullptr: the weight gradient runs two fp16 MFMAs per product (wgrad_split.hip NP == 2)
   bool thin = false;  // image convolution (<= 4 input channels) on the plain-FMA kernels of conv_thin.hip
   int fwd_wide = 0, dg_wide = 0;  // != 0: the launch runs on conv_wide.hip, value = packed weight rows (conv3x3_wide_rows)
@@ -429,6 +430,7 @@ struct mimo_plan {
       if (L.fwd_split) L.fwd_wide = conv3x3_wide_rows(fwd_mode(), n, L.cin_p, L.cout_p, h, w);
       if (L.dg_split) L.dg_wide = conv3x3_wide_rows(dgrad_mode(), n, L.cout_p, L.cin_p, h + 2, w + 2);
     }
+    if (L.fwd_split && (cfg.precision == MIMO_PREC_SPLIT16 || cfg.precision == MIMO_PREC_FP16_MIXED)) MIMO_TRY(dalloc(&L.wmax, 1));
     if (L.fwd_split) {
       uint16_t* q = nullptr;
       MIMO_TRY(dalloc(&q, L.fwd_wide ? conv3x3_wide_weight_elems(L.cin_p, L.fwd_wide)
@@ -786,6 +788,7 @@ struct mimo_plan {
             j.total = mixed ? ceil_div(j.cols, 32) * 9 * j.rows_pad * 32 : ceil_div(j.cols, 16) * 9 * j.rows_pad * 16;
             j.pair = 0;
           }
+          j.wmax = (j.kind == 1 || j.kind == 3 || j.kind == 5) ? L->wmax : nullptr;
           jobs.push_back(j);
           PackJob d{};
           d.w_off = L->off_w;
@@ -849,6 +852,9 @@ struct mimo_plan {
   // every layer's forward weight layout (+ bias copy) and, with_dgrad, the transposed data-gradient layout:
   // one launch over the job table
   int pack_all(bool with_dgrad, hipStream_t st) {
+    // (fp16 forward images: the layers' max |w| first — the scale of an image follows it from |w| >= 128 up, w16_scale)
+    if (cfg.precision == MIMO_PREC_SPLIT16 || cfg.precision == MIMO_PREC_FP16_MIXED)
+      MIMO_TRY(wabsmax_jobs_launch(pack_jobs, n_fwd_jobs, pack_max_total, params, st));
     return pack_jobs_launch(pack_jobs, with_dgrad ? n_all_jobs : n_fwd_jobs, pack_max_total, params, st);
   }
 
@@ -893,6 +899,7 @@ struct mimo_plan {
     int rows = 0;
     const int64_t P = (int64_t)L.N * L.H * L.W;
     a.wpk = L.wf16;
+    a.wmax = L.fwd_split ? L.wmax : nullptr;
     a.pair = (L.fwd_split && !L.fwd_wide) ? conv3x3_pair_tail(fwd_mode(), L.cin_p, L.H, L.W) : 0;
     a.wide = L.fwd_wide;
     int pr = prof_begin(MIMO_PROF_CONV_FWD, st);
