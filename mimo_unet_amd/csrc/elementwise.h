@@ -55,7 +55,7 @@ int bn_fwd_finalize_launch(const double* sums, int chunks, int cout_pad, int C, 
                            hipStream_t st);
 int bn_eval_prepare_launch(int C, int Cp, const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float eps, float* mean, float* invstd, float* scale,
-                           float* shift, hipStream_t st);
+                           float* shift, hipStream_t st, int* status = nullptr);
 // a = relu(z*scale+shift) * mask[n][c]
 // status != nullptr (eval mode): kStatusFwdStats is OR-ed into it when an input element is not finite (fmaxf would drop it)
 int bn_relu_fwd_launch(const void* z, int dtz, int ldz, void* a, int dta, int lda, const float* scale, const float* shift,

@@ -511,7 +511,7 @@ int bn_fwd_finalize_launch(const double* sums, int chunks, int cout_pad, int C, 
 __global__ void bn_eval_prepare_kernel(int C, int Cp, const float* __restrict__ gamma, const float* __restrict__ beta,
                                        const float* __restrict__ running_mean, const float* __restrict__ running_var,
                                        float eps, float* __restrict__ mean, float* __restrict__ invstd,
-                                       float* __restrict__ scale, float* __restrict__ shift) {
+                                       float* __restrict__ scale, float* __restrict__ shift, int* __restrict__ status) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cp) return;
   if (c >= C) {
@@ -524,6 +524,9 @@ __global__ void bn_eval_prepare_kernel(int C, int Cp, const float* __restrict__ 
   const double m = running_mean[c];
   const double is = 1.0 / sqrt((double)running_var[c] + (double)eps);
   const double sc = (double)gamma[c] * is;
+  // running statistics poisoned by an earlier training step (a NaN shift would be dropped by the ReLU's fmaxf: a silently
+  // dead channel in eval mode)
+  if (status && !(isfinite(m) && isfinite(is) && isfinite(sc))) atomicOr(status, kStatusFwdStats);
   mean[c] = (float)m;
   invstd[c] = (float)is;
   scale[c] = (float)sc;
@@ -532,9 +535,9 @@ __global__ void bn_eval_prepare_kernel(int C, int Cp, const float* __restrict__ 
 
 int bn_eval_prepare_launch(int C, int Cp, const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float eps, float* mean, float* invstd, float* scale,
-                           float* shift, hipStream_t st) {
+                           float* shift, hipStream_t st, int* status) {
   hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(ceil_div(Cp, 64)), dim3(64), 0, st, C, Cp, gamma, beta,
-                     running_mean, running_var, eps, mean, invstd, scale, shift);
+                     running_mean, running_var, eps, mean, invstd, scale, shift, status);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -714,6 +717,12 @@ __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
                      fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
 }
 
+__device__ __forceinline__ float4 sel3(int a, float4 x0, float4 x1, float4 x2) { return a == 1 ? x1 : (a == 0 ? x0 : x2); }
+__device__ __forceinline__ float4 blend2(float w0, float4 a, float w1, float4 b) {
+  // no fma contraction (here and in the per-pixel kernel's blend): both kernels then round every product and sum alike
+#pragma clang fp contract(off)
+  return make_float4(w0 * a.x + w1 * b.x, w0 * a.y + w1 * b.y, w0 * a.z + w1 * b.z, w0 * a.w + w1 * b.w);
+}
 template <typename T>
 __global__ void upcat_fwd_kernel(const T* __restrict__ skip, int lds, int csv, const T* __restrict__ low,
                                  int ldl, int clv, int N, int H, int W, int h, int w, int padT, int padL,
@@ -752,13 +761,68 @@ __global__ void upcat_fwd_kernel(const T* __restrict__ skip, int lds, int csv, c
           v10 = bn_relu4(v10, lsc, lsh);
           v11 = bn_relu4(v11, lsc, lsh);
         }
-        v.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
-        v.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
-        v.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
-        v.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+        v = blend2(ly.l0, blend2(lx.l0, v00, lx.l1, v01), ly.l1, blend2(lx.l0, v10, lx.l1, v11));
       }
     }
     st4(out + (size_t)p * ldo + 4 * t.q, v);
+  }
+}
+
+// The common geometry — skip tensor already in place (skip == nullptr), output exactly twice the low-resolution size — with
+// one thread per 2 x 2 OUTPUT block and channel quad (round 5): the four pixels of a block read sources
+// from the 3 x 3 low-resolution neighbourhood of their block only (x2 align_corners: output 2k reads rows k-1 / k, output
+// 2k + 1 rows k / k + 1), so 9 loads (and 9 BatchNorm + ReLU evaluations) serve 4 outputs instead of 16.  Which of the three
+// rows / columns an output takes is read off the same lerp_src() results as in the per-pixel kernel, and the blend keeps its
+// association — horizontal pairs first, then the vertical pair: the same values.
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_fwd2x2_kernel(int csv, const T* __restrict__ low, int ldl, int clv, int N, int h, int w,
+                                    T* __restrict__ out, const float* __restrict__ lo_scale,
+                                    const float* __restrict__ lo_shift) {
+  PQ t = pixquad(clv);
+  if (!t.active) return;
+  const int ldo = 4 * (csv + clv), H = 2 * h, W = 2 * w;
+  const int P = N * h * w;
+  float4 lsc = f4zero(), lsh = f4zero();
+  if (lo_scale) {
+    lsc = ld4(lo_scale + 4 * t.q);
+    lsh = ld4(lo_shift + 4 * t.q);
+  }
+  PixIter it = pix_iter(t.p, t.pstep, h, w);
+  for (int p = t.p; p < P; p += t.pstep, pix_next(it, h, w)) {
+    const int n = it.n, by = it.y, bx = it.x;
+    const int rr[3] = {max(by - 1, 0), by, min(by + 1, h - 1)}, cc[3] = {max(bx - 1, 0), bx, min(bx + 1, w - 1)};
+    const T* b = low + (size_t)n * h * w * ldl + 4 * t.q;
+    float4 v[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[a][c] = ld4(b + ((size_t)rr[a] * w + cc[c]) * ldl);
+    if (lo_scale) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[a][c] = bn_relu4(v[a][c], lsc, lsh);
+    }
+    const Lerp ly[2] = {lerp_src(2 * by, h, H), lerp_src(2 * by + 1, h, H)};
+    const Lerp lx[2] = {lerp_src(2 * bx, w, W), lerp_src(2 * bx + 1, w, W)};
+    // horizontal pairs of every source row, for both output columns
+    float4 hx[3][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int j0 = lx[e].i0 - (bx - 1), j1 = lx[e].i1 - (bx - 1);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        hx[a][e] = blend2(lx[e].l0, sel3(j0, v[a][0], v[a][1], v[a][2]), lx[e].l1, sel3(j1, v[a][0], v[a][1], v[a][2]));
+    }
+    T* o = out + ((size_t)(n * H + 2 * by) * W + 2 * bx) * ldo + 4 * (csv + t.q);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int a0 = ly[d].i0 - (by - 1), a1 = ly[d].i1 - (by - 1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        st4(o + ((size_t)d * W + e) * ldo,
+            blend2(ly[d].l0, sel3(a0, hx[0][e], hx[1][e], hx[2][e]), ly[d].l1, sel3(a1, hx[0][e], hx[1][e], hx[2][e])));
+    }
   }
 }
 
@@ -769,6 +833,13 @@ int upcat_fwd_launch(const void* skip, int dt, int lds, int csp, const void* low
   if (H < 2 * h || W < 2 * w) {
     set_error("upcat: skip smaller than upsampled input");
     return MIMO_ERR_INVALID;
+  }
+  static const bool blocks2x2 = !(getenv("MIMO_UPCAT_2X2") && atoi(getenv("MIMO_UPCAT_2X2")) == 0);
+  if (!skip && H == 2 * h && W == 2 * w && blocks2x2) {
+    MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(upcat_fwd2x2_kernel<T>, pq_grid(clp / 4, (int64_t)N * h * w, 4096), dim3(256), 0, st,
+                                               csp / 4, (const T*)low, ldl, clp / 4, N, h, w, (T*)out, lo_scale, lo_shift));
+    MIMO_KERNEL_CHECK();
+    return MIMO_OK;
   }
   MIMO_ST_DISPATCH(dt, T, hipLaunchKernelGGL(upcat_fwd_kernel<T>, pq_grid(skip ? Cv : clp / 4, (int64_t)N * H * W, 4096), dim3(256), 0,
                                              st, (const T*)skip, lds, csp / 4, (const T*)low, ldl, clp / 4, N, H, W, h, w, padT, padL,

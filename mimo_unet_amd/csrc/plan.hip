@@ -865,7 +865,7 @@ struct mimo_plan {
     const bool fused = fwd_no_grad && !(mixed && !L.fwd_split);
     if (!training && need_derive)
       MIMO_TRY(bn_eval_prepare_launch(L.Cout, L.cout_p, params + L.off_gamma, params + L.off_beta, bnbuf + L.off_rm,
-                                      bnbuf + L.off_rv, cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st));
+                                      bnbuf + L.off_rv, cfg.bn_eps, L.mean, L.invstd, L.scale, L.shift, st, d_status));
     // Training forward only.  (A forward without a graph folds BatchNorm + ReLU into every convolution's epilogue, and an
     // eval-mode forward WITH a graph — FGSM — keeps the separate pass, whose finiteness test feeds the numerics status word:
     // the activated tensors exist in both.  The weight gradient applies scale / shift to z either way: identical values.)

@@ -561,14 +561,25 @@ def test_weights_beyond_the_old_fixed_fp16_scale_stay_finite_and_close():
     model.train()
     out = model.training_step_with_perms(image.cuda(), label.cuda(), None, perms.cuda())
     out["loss"].backward()
-    ts = O.TrainState(cfg=cfg, st={k: v.clone() for k, v in st.items()}, loss_buffer=O.LossBuffer(2, 0.3, 10))
-    ref = O.train_step(ts, image, label, None, perms, apply_optimizer=False)
+    lb_w = torch.ones(2)  # first step: loss-buffer weights are exactly 1
+    ts, ref = _oracle_run(cfg, st, image, label, None, perms, lb_w, "laplace_nll", torch.float32)
+    _, ref64 = _oracle_run(cfg, st, image, label, None, perms, lb_w, "laplace_nll", torch.float64)
     preds = out["preds"].view(N, 2, 1, H, W).cpu()
     assert torch.isfinite(preds).all() and torch.isfinite(model.model.flat_gradients()).all()
     e_out = rel_err(preds, ref["out"][:, :, :1])
-    e_loss = abs(float(out["loss"]) - float(ref["total"])) / abs(float(ref["total"]))
-    grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
-    worst = check_grads(grads, ref["grads"], tol=2e-3)
+    e_loss = abs(float(out["loss"].detach()) - float(ref["total"])) / abs(float(ref["total"]))
+    # gradients: weights of thousands make the backward ill-conditioned (the fp32 oracle itself sits several 1e-3 from the
+    # fp64 one on the early layers) — anchored on fp64 like _oracle_vs_hip: within 2e-3 + 5 x the fp32 oracle's own error
+    worst = ("", 0.0, 0.0)
+    for k, g64 in ref64["grads"].items():
+        if is_prebn_bias(k):
+            continue
+        gh = dict(model.named_parameters())["model." + k].grad.detach().cpu().double()
+        eh = float((gh - g64).norm() / g64.norm())
+        eo = float((ref["grads"][k].double() - g64).norm() / g64.norm())
+        if eh > worst[1]:
+            worst = (k, eh, eo)
+        assert eh <= 2e-3 + 5.0 * eo, (k, eh, eo)
     model.eval()
     with torch.no_grad():
         x5 = torch.stack([image[perms[s]] for s in range(2)], 1)
@@ -1123,10 +1134,12 @@ def test_two_forwards_then_the_first_ones_backward():
 
 @pytest.mark.gpu
 def test_numerics_status_reports_an_fp16_range_overflow_instead_of_silent_nans():
-    """The default split16 forward carries fp16 (hi, lo) pairs: a weight >= 256 (x 2^8 = fp16 inf) poisons the output
-    where the reference's fp32 path does not.  The kernels record non-finite BatchNorm statistics / logits in the plan's
-    status word; `check_numerics` (called by the Lightning epoch-end hooks) turns it into an error that says so, the
-    fp32 mode runs the same weights cleanly, and the word is cleared by the read."""
+    """The default split16 forward carries fp16 (hi, lo) pairs: an ACTIVATION >= 65520 (here: a BatchNorm scale of 3e5)
+    turns into fp16 inf and poisons the next convolution's output where the reference's fp32 path does not.  (Weights are
+    range-safe since round 5: test_weights_beyond_the_old_fixed_fp16_scale_stay_finite_and_close.)  The kernels record
+    non-finite BatchNorm statistics / logits in the plan's status word; `check_numerics` (called by the Lightning epoch-end
+    hooks) turns it into an error that says so, the fp32 mode runs the same parameters cleanly, and the word is cleared
+    by the read."""
     fx = load_npz("mini_s2_step.npz")
     cfg = cfg_from_meta(fx["meta"])
     model = build_model(cfg, state_from(fx, "init/"))
@@ -1136,9 +1149,9 @@ def test_numerics_status_reports_an_fp16_range_overflow_instead_of_silent_nans()
     out = model.training_step({"image": x, "label": lab}, 0)
     assert torch.isfinite(out["loss"]) and model.model.numerics_status() == 0
     model.on_train_epoch_end()  # nothing recorded: no error
-    w = dict(model.model.named_parameters())["core.down2.conv.double_conv.0.weight"]
+    w = dict(model.model.named_parameters())["core.down2.conv.double_conv.1.weight"]
     with torch.no_grad():
-        w[0, 0, 1, 1] = 300.0  # representable in fp32 and bf16, not as fp16 x 2^8
+        w[0] = 3.0e5  # BatchNorm scale of the block's first convolution: activations up to ~1e6, beyond fp16
     out = model.training_step({"image": x, "label": lab}, 0)
     # the loss may well stay finite: training-mode BatchNorm turns the poisoned channel into NaNs and the ReLU's fmaxf
     # drops them — a silently dead channel; the status word is what tells
@@ -1166,7 +1179,7 @@ def test_numerics_status_reports_an_fp16_range_overflow_instead_of_silent_nans()
     assert net.numerics_status() & 1 and net.numerics_status() == 0 and net._evicted_status == 0
     ref = build_model(cfg, state_from(fx, "init/"), precision="fp32")  # (a fresh loss buffer: the first model's holds a NaN)
     with torch.no_grad():
-        dict(ref.model.named_parameters())["core.down2.conv.double_conv.0.weight"][0, 0, 1, 1] = 300.0
+        dict(ref.model.named_parameters())["core.down2.conv.double_conv.1.weight"][0] = 3.0e5
     ref.train()
     out = ref.training_step({"image": x, "label": lab}, 0)
     assert torch.isfinite(out["loss"]) and ref.model.numerics_status() == 0

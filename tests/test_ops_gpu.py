@@ -145,6 +145,29 @@ def test_upsample_cat(case):
     assert e < 1e-6
 
 
+@pytest.mark.parametrize("case", [(2, 8, 16, 16, 16, 8, 8), (1, 8, 8, 100, 100, 50, 50), (3, 32, 64, 64, 48, 32, 24), (1, 8, 24, 4, 4, 2, 2)])
+def test_upsample_into_a_concat_buffer_by_2x2_output_blocks(case):
+    """Round 5: with the skip tensor already in place (skip = NULL) and the output exactly twice the low-resolution size,
+    one thread owns a 2 x 2 output block (9 source loads per 4 outputs).  Same values as the per-pixel kernel (which the
+    call with a skip pointer runs) bit for bit, and F.interpolate(align_corners=True) (components.py:78) to rounding;
+    the skip channels of the buffer are not touched."""
+    L = _lib()
+    lib = L.load()
+    N, Cs, Cl, Hs, Ws, Hl, Wl = case
+    g = torch.Generator().manual_seed(10)
+    skip = torch.randn(N, Cs, Hs, Ws, generator=g)
+    low = torch.randn(N, Cl, Hl, Wl, generator=g)
+    ref = O.up_cat(low, skip)
+    sd, ld_ = to_nhwc(skip, Cs), to_nhwc(low, Cl)
+    per_pixel = torch.full((N, Hs, Ws, Cs + Cl), float("nan"), device="cuda")
+    L.check(lib.mimo_op_upsample_cat(sd.data_ptr(), ld_.data_ptr(), per_pixel.data_ptr(), N, Hs, Ws, Cs, Hl, Wl, Cl, L.current_stream()))
+    blocks = torch.full((N, Hs, Ws, Cs + Cl), 7.0, device="cuda")
+    L.check(lib.mimo_op_upsample_cat(None, ld_.data_ptr(), blocks.data_ptr(), N, Hs, Ws, Cs, Hl, Wl, Cl, L.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(blocks[..., Cs:], per_pixel[..., Cs:]) and bool((blocks[..., :Cs] == 7.0).all())
+    assert rel_err(from_nhwc(blocks, Cs + Cl)[:, Cs:], ref[:, Cs:]) < 1e-6
+
+
 def test_adam_matches_torch():
     L = _lib()
     lib = L.load()
