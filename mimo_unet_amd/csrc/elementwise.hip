@@ -1097,15 +1097,11 @@ int elem_mask_mul_launch(void* a, int dt, int ld, const float* mask, int N, int 
 
 // Input pixel i of an x2 align_corners upsample is read by outputs 2i-1 .. 2i+2 only (2i-2 lands on
 // i-2 / i-1 for every size; checked exhaustively for in <= 300 and 512..2048 on the CPU).
+// Gradient arriving at low-resolution pixel (n, iy, ix), channel quad q: the transposed interpolation over its 4 x 4
+// candidates of the padded-domain data gradient, border folds included.
 template <typename T>
-__global__ void up_bwd_kernel(const T* __restrict__ dxpad, int ldp, int choff, T* __restrict__ da, int ldda,
-                              int N, int H, int W, int h, int w, int padT, int padL, int Cv, int accumulate) {
-  const PQ t = pixquad(Cv, true);
-  if (!t.active) return;
-  const int P = N * h * w;
-  PixIter it = pix_iter(t.p, t.pstep, h, w);
-  for (int p = t.p; p < P; p += t.pstep, pix_next(it, h, w)) {
-    const int n = it.n, iy = it.y, ix = it.x;
+__device__ __forceinline__ float4 up_bwd_pixel(const T* __restrict__ dxpad, int ldp, int choff, int q, int n, int iy, int ix,
+                                               int H, int W, int h, int w, int padT, int padL) {
     float wy[4], wx[4];
     int cy[4], cx[4];
 #pragma unroll
@@ -1117,7 +1113,7 @@ __global__ void up_bwd_kernel(const T* __restrict__ dxpad, int ldp, int choff, T
       cx[k] = min(max(ox, 0), 2 * w - 1) + padL;
     }
     float4 v = f4zero();
-    const T* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + choff + 4 * t.q;
+    const T* base = dxpad + (size_t)n * (H + 2) * (W + 2) * ldp + choff + 4 * q;
     // the 16 candidates themselves (padded-domain pixel of image pixel (y, x) = (y + 1, x + 1)): 16 independent loads,
     // weights 0 where the candidate does not read this input (adds an exact zero, same sum as skipping it)
     {
@@ -1184,11 +1180,27 @@ __global__ void up_bwd_kernel(const T* __restrict__ dxpad, int ldp, int choff, T
         }
       }
     }
+    return v;
+}
+
+template <typename T>
+__global__ void up_bwd_kernel(const T* __restrict__ dxpad, int ldp, int choff, T* __restrict__ da, int ldda,
+                              int N, int H, int W, int h, int w, int padT, int padL, int Cv, int accumulate) {
+  const PQ t = pixquad(Cv, true);
+  if (!t.active) return;
+  const int P = N * h * w;
+  PixIter it = pix_iter(t.p, t.pstep, h, w);
+  for (int p = t.p; p < P; p += t.pstep, pix_next(it, h, w)) {
+    float4 v = up_bwd_pixel(dxpad, ldp, choff, t.q, it.n, it.y, it.x, H, W, h, w, padT, padL);
     T* dst = da + (size_t)p * ldda + 4 * t.q;
     if (accumulate) v = f4add(v, ld4(dst));
     st4(dst, v);
   }
 }
+
+// (Round 5 measured the transposed counterpart of upcat_fwd2x2 — one thread per 2 x 2 block of low-resolution pixels, its
+// four 4 x 4 candidate windows read as one 6 x 6 window, 36 loads per 4 outputs instead of 64: 0.49 -> 0.52 ms per step,
+// slower at 165 registers and three waves per SIMD; profiles/r05/upsampling_2x2.txt.  Not kept.)
 
 int up_bwd_launch(const void* dxpad, int dt, int ldp, int choff, void* da, int ldda, int N, int H, int W, int h, int w,
                   int Cp, int accumulate, hipStream_t st) {
