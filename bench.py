@@ -433,7 +433,7 @@ def main():
         "metric": "train images/sec at 256x256, S=2, fbc=30" if args.config == "cfg3" else f"train images/sec ({args.config})",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": {"fp32": "f32", "split16": "f32 (split into 16-bit hi/lo pairs on the MFMA)",
+        "dtype": {"fp32": "f32", "split16": "f32 (split into 16-bit hi/lo pairs on the MFMA; weight gradient: activation as one fp16 value)",
                   "bf16": "bf16 MFMA operands, f32 accumulate/storage (reduced precision)",
                   "bf16-mixed": "bf16 storage + MFMA operands, f32 accumulate / master weights / statistics (reduced precision)",
                   "16-mixed": "fp16 storage + MFMA operands under a loss scaler, f32 accumulate / master weights / statistics "
@@ -491,7 +491,19 @@ def main():
                                   "algorithmic_bytes_per_launch": 28 * nparam,
                                   "hbm_frac": round(28.0 * nparam / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-        peak = {"fp32": FP32_MFMA_PEAK_TFLOPS, "split16": SPLIT16_PEAK_TFLOPS, "bf16": 2500.0}.get(precision, 2500.0)
+
+        def class_peak(kind):
+            """dense 16-bit MFMA peak / MFMAs per algorithmic product of that class"""
+            if precision == "fp32":
+                return FP32_MFMA_PEAK_TFLOPS
+            if precision == "split16":  # forward / data gradient: three MFMAs; weight gradient (round 5): two fp16 MFMAs
+                return 2500.0 / 2.0 if kind == "conv3x3_wgrad" and os.environ.get("MIMO_WGRAD_NP") != "3" else SPLIT16_PEAK_TFLOPS
+            return 2500.0
+
+        for k, v in kernels.items():
+            v["peak_tflops"] = round(class_peak(k), 1)
+            v["frac"] = round(v["tflops"] / class_peak(k), 4)
+        peak = class_peak(dom)
         traffic = step_traffic = None
         traffic_src = "counter summaries are collected for cfg3 / split16 / batch 32 on one GPU only"
         if args.config == "cfg3" and precision == "split16" and world == 1 and not args.batch:
@@ -509,8 +521,9 @@ def main():
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
             "step_traffic_bytes": step_traffic,
             "arithmetic": {"fp32": "f32-input MFMA",
-                           "split16": "3x 16-bit MFMA per product (fp16 hi/lo forward, bf16 hi/lo gradients), fp32 "
-                                      "accumulate; peak = 2500 TFLOP/s dense 16-bit MFMA / 3",
+                           "split16": "forward / data gradient: 3x 16-bit MFMA per product (fp16 hi/lo forward, bf16 hi/lo data "
+                                      "gradient), peak = 2500 TFLOP/s dense 16-bit MFMA / 3; weight gradient: 2x fp16 MFMA per "
+                                      "product (activation as one fp16 value x dz as an fp16 pair), peak = 2500 / 2; fp32 accumulate",
                            "bf16": "bf16 MFMA operands (one MFMA per product), fp32 accumulate and storage — reduced "
                                    "precision, NOT the fp32 metric",
                            "bf16-mixed": "bf16 storage and MFMA operands (one MFMA per product), fp32 accumulate — reduced "

@@ -42,10 +42,13 @@ enum mimo_status {
 /* Arithmetic of the 3x3 convolutions (BatchNorm statistics, the loss and the optimiser are always fp32; storage is
  * fp32 except in the two *_MIXED modes).
  * MIMO_PREC_FP32: f32-input MFMA everywhere (bit-exact fp32 fma chains).
- * MIMO_PREC_SPLIT16: each fp32 operand is split into a 16-bit hi + lo pair and every product block
- *   is three 16-bit MFMAs with fp32 accumulation: fp16 pairs in the forward convolution (~2^-22 per
- *   product: fp32-class outputs), bf16 pairs (fp32 exponent range, ~1e-5 per product) in the data
- *   and weight gradients.
+ * MIMO_PREC_SPLIT16: each fp32 operand is split into a 16-bit hi + lo pair and every product block of the forward and
+ *   the data gradient is three 16-bit MFMAs with fp32 accumulation: fp16 pairs in the forward convolution (~2^-22 per
+ *   product: fp32-class outputs; the weight image of a layer carries a power-of-two scale that follows its largest |w|,
+ *   so any fp32 weight is in range), bf16 pairs (fp32 exponent range, ~1e-5 per product) in the data gradient.  The
+ *   weight gradient (round 5) is two fp16 MFMAs per product — the activation as ONE fp16 value, dz as an fp16 (hi, lo) pair
+ *   scaled by a power of two taken from max |dz|: 1-4e-4 of a weight-gradient tensor's scale in rounding noise, nothing
+ *   of it reaches other layers (environment MIMO_WGRAD_NP=3: three bf16-pair MFMAs, ~1e-5).
  * MIMO_PREC_BF16: mixed precision in the sense of the reference's `precision="16-mixed"` runs
  *   (scripts/train/train_ndvi.py:71) and of BASELINE config 4: convolution operands are rounded to bf16
  *   on the way into the MFMA (one MFMA per product block, fp32 accumulation); master weights, BatchNorm

@@ -68,6 +68,7 @@ __host__ __device__ __forceinline__ float w16_scale(unsigned wmax_bits, bool inv
   return c.v;
 }
 
+constexpr int kFinSlack = 32;  // zero floats behind ConvLaunch::in_scale / in_shift (a 32-channel chunk may start at cin_p - 8)
 struct ConvLaunch {
   const float* x;
   float* y;
@@ -93,6 +94,7 @@ struct ConvLaunch {
   // tensor z of the producing convolution and the loaders apply its BatchNorm + ReLU on the way into LDS — relu(z *
   // in_scale[c] + in_shift[c]), bn_relu_fwd_kernel's arithmetic (components.py:24-25 between the two convolutions of a
   // DoubleConv) — so that the activated tensor is never written to HBM
+  // Both arrays must be readable (and zero) for kFinSlack floats past cin_p: the loaders read whole 16- / 32-channel chunks
   const float* in_scale = nullptr;
   const float* in_shift = nullptr;
   // fp16 weight images (modes 1 and 6): device word with the float bits of the layer's max |w| the image was packed with

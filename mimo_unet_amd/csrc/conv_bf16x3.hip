@@ -501,8 +501,9 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #define WS_LOAD_SS(SC, SH, STAGE)                                                                    \
   if (FIN) {                                                                                         \
     const int c_ = ((STAGE) % nchunks) * 32 + 4 * (ptid & 7);                                        \
-    SC = *reinterpret_cast<const f32x4*>(c_ < a.cin_p ? a.in_scale + c_ : kZeroPage);                \
-    SH = *reinterpret_cast<const f32x4*>(c_ < a.cin_p ? a.in_shift + c_ : kZeroPage);                \
+    /* UNCONDITIONAL (kFinSlack zero floats behind the layer's channels, plan.hip): exactly two loads per stage */ \
+    SC = *reinterpret_cast<const f32x4*>(a.in_scale + c_);                                           \
+    SH = *reinterpret_cast<const f32x4*>(a.in_shift + c_);                                           \
   }
     // stage j = (tile j / nchunks, chunk j % nchunks)
 #define WS_LOAD_X(K0, K1, STAGE)                                                                     \

@@ -212,8 +212,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(ConvLaunch a, int 
 #define WD_LOAD_SS(SC, SH, CK)                                                                       \
   if (FIN) {                                                                                         \
     const int c_ = (CK) * CKC + 4 * uq;                                                              \
-    SC = *reinterpret_cast<const f32x4*>(c_ < a.cin_p ? a.in_scale + c_ : kZeroPage);                \
-    SH = *reinterpret_cast<const f32x4*>(c_ < a.cin_p ? a.in_shift + c_ : kZeroPage);                \
+    /* UNCONDITIONAL: in_scale / in_shift are allocated with kFinSlack zero floats behind the layer's channels (plan.hip), \
+       so a chunk's quads past cin_p read zeros (relu(0 * 0 + 0) keeps those channels zero) and the stage always issues      \
+       exactly the two loads the counted waits below assume — no select the compiler could turn into a branch */ \
+    SC = *reinterpret_cast<const f32x4*>(a.in_scale + c_);                                           \
+    SH = *reinterpret_cast<const f32x4*>(a.in_shift + c_);                                           \
   }
 #define WD_TILE(TI)                                                                                  \
   {                                                                                                  \

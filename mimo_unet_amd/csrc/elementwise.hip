@@ -1605,8 +1605,10 @@ int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStrea
   return MIMO_OK;
 }
 
+// (plain / folded sources: held to 72 registers = 7 waves per SIMD, the occupancy round 3's grid scan found best — the
+// max |dz| tracking of round 5 had pushed the folded instance to 74 and cost the class 7 %)
 template <typename TZ, typename TA, int SRC>
-__global__ void bn_bwd_apply_kernel(const GradSrc src, const TZ* __restrict__ z, int ldz, const float* __restrict__ scale,
+__global__ __launch_bounds__(256, (SRC == GS_PLAIN || SRC == GS_FOLD) ? 7 : 1) void bn_bwd_apply_kernel(const GradSrc src, const TZ* __restrict__ z, int ldz, const float* __restrict__ scale,
                                     const float* __restrict__ shift, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ mask, int C,
                                     const float* __restrict__ c1, const float* __restrict__ c2, int Cv, int N, int H,

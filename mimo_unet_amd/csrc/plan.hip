@@ -455,8 +455,8 @@ struct mimo_plan {
     if (train_bufs || (mixed && !L.fwd_split)) MIMO_TRY(alloc_act(&L.z, (size_t)n * h * w * L.cout_p, L.dtz));
     MIMO_TRY(dalloc(&L.mean, L.cout_p));
     MIMO_TRY(dalloc(&L.invstd, L.cout_p));
-    MIMO_TRY(dalloc(&L.scale, L.cout_p));
-    MIMO_TRY(dalloc(&L.shift, L.cout_p));
+    MIMO_TRY(dalloc(&L.scale, L.cout_p + kFinSlack));  // (+ zero slack: the next convolution's loaders read whole K chunks)
+    MIMO_TRY(dalloc(&L.shift, L.cout_p + kFinSlack));
     MIMO_TRY(dalloc(&L.c1, L.cout_p));
     MIMO_TRY(dalloc(&L.c2, L.cout_p));
     const size_t act = (size_t)n * h * w * L.cout_p;

@@ -27,6 +27,9 @@ case "$PART" in
       python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline --host-batches $m 2>/dev/null | tail -1 > gpurun_out/r05_b4/bench_b32_host_$m.json
       python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --batch 4 --host-batches $m 2>/dev/null | tail -1 > gpurun_out/r05_b4/bench_b4_host_$m.json
     done
+    for i in 1 2 3; do for v in 3 2; do
+      MIMO_WGRAD_NP=$v python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --batch 4 --profile-steps 0 2>/dev/null | tail -1 | python3 -c "import json,sys; l=json.loads(sys.stdin.read()); print('b4 np=$v', l['value'], l['ms_per_step'])" >> gpurun_out/r05_b4/b4_np_ab.txt
+    done; done
     python3 tests/tools/convergence_probe.py 300 > gpurun_out/r05_b4/convergence.txt 2>&1
     ;;
 esac
