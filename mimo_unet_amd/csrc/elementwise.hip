@@ -1563,23 +1563,17 @@ __device__ __forceinline__ void st_split4(float* base, size_t p, int Cp, int q, 
   *reinterpret_cast<bf16x4_ew*>(d + 2 * rc) = lo;
 }
 
-// max over the workgroup of a non-negative per-thread value -> one atomic max per workgroup on the value's float bits
+// max over a wave of a non-negative per-thread value -> at most one atomic max per wave on the value's float bits
 // (non-negative floats order like unsigned integers; a maximum does not depend on the order of its operands: deterministic)
 __device__ __forceinline__ void block_absmax_to(unsigned* slot, float v) {
-  __shared__ float wmax[8];
+  // per WAVE, no barrier: a butterfly over the 64 lanes, then lane 0 alone.  Most waves do not hold the maximum: one L2 load
+  // instead of an atomic on the one word every wave of the launch would otherwise queue on.  (A first version reduced over
+  // the workgroup through LDS and two barriers: +7 us per apply launch, +0.16 ms per step.)
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) v = fmaxf(v, __shfl_xor(v, d));
-  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float m = wmax[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, wmax[i]);
-    // most workgroups do not hold the maximum: one cached-in-L2 load instead of an atomic on the one word every workgroup
-    // of the launch would otherwise queue on (~1800 same-address atomics cost ~4 us per launch, a quarter of an apply pass
-    // at 4 images per GPU)
-    if (m > 0.f && __float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      atomicMax(slot, __float_as_uint(m));
-  }
+  if ((threadIdx.x & 63) == 0 && v > 0.f &&
+      __float_as_uint(v) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(slot, __float_as_uint(v));
 }
 __device__ __forceinline__ float absmax4(float m, float4 r) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
