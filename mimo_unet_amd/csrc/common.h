@@ -154,9 +154,12 @@ struct WgradLaunch {
   // split kernels: MFMAs per product block — 3 (bf16 hi/lo pairs both sides), 1 (bf16 compute), or 2 (round 5,
   // wave-specialised kernel, store 0: the activation as one fp16 value, dz as a scaled fp16 pair; needs dz_absmax)
   int np = 3;
-  // np == 2: device word holding the bits of max |dz| of this tensor as a float (bn_bwd_apply / split_pairs write it);
-  // the kernel scales dz by wg_dz_scale(*dz_absmax) and wgrad_reduce_launch divides the result by it again
-  const unsigned* dz_absmax = nullptr;
+  // np == 2: dz_absmax_n floats whose maximum is max |dz| of this tensor — one per wave of the launch that wrote dz
+  // (bn_bwd_apply / split_pairs: plain stores, no atomics; kDzMaxSlots is their capacity).  Every workgroup of the weight
+  // gradient reduces them itself (wg_dz_absmax: identical result everywhere), scales dz by wg_dz_scale(max) and
+  // wgrad_reduce_launch divides the result by it again
+  const float* dz_absmax = nullptr;
+  int dz_absmax_n = 0;
   // split kernels, operand storage: 0 = activations fp32 + dz pre-split bf16 pair records; 1 / 2 = activations and dz
   // plain NHWC bf16 / fp16 (ldx, lddz in elements); 3 / 4 = activations fp32 (the packed image) + dz plain bf16 / fp16
   int store = 0;
@@ -168,6 +171,7 @@ struct WgradLaunch {
 };
 // the power of two 2^(14 - floor(log2 max|dz|)) (inverse: its reciprocal) from the float bits of max |dz|: scaled values lie
 // below 2^15 (fp16's largest finite value is 65504); an all-zero tensor scales by 2^126
+constexpr int kDzMaxSlots = 4 * 2048 * 2;  // waves of the largest launch that writes dz (<= 2048 x 2 workgroups of 256 threads)
 __host__ __device__ __forceinline__ float wg_dz_scale(unsigned absmax_bits, bool inverse) {
   int e = (int)((absmax_bits >> 23) & 0xffu);  // biased exponent
   e = e < 16 ? 16 : e > 254 ? 254 : e;
@@ -176,6 +180,17 @@ __host__ __device__ __forceinline__ float wg_dz_scale(unsigned absmax_bits, bool
   c.u = f << 23;
   return c.v;
 }
+#if defined(__HIPCC__)
+// max of the n per-wave maxima, computed redundantly by every wave that calls it (n <= kDzMaxSlots floats, L2-resident:
+// n / 64 coalesced loads per lane and a butterfly) — no hot word that thousands of waves would queue on
+__device__ __forceinline__ float wg_dz_absmax(const float* __restrict__ slots, int n) {
+  float m = 0.f;
+  for (int i = (int)(threadIdx.x & 63); i < n; i += 64) m = fmaxf(m, slots[i]);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+  return m;
+}
+#endif
 int wgrad_launch(const WgradLaunch& a, hipStream_t stream);
 int wgrad_split_has_np2(int cin_p, int cout_p);
 // 1 when wgrad_split_launch runs this geometry on a kernel that can apply WgradLaunch::in_scale / in_shift in its loader
@@ -190,7 +205,8 @@ size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad);
 // dW[co][ci][kh][kw] (torch OIHW) = sum over splits of partial[..][tap][cin_map^-1(ci)][co]
 // dz_absmax != nullptr: the slabs carry the factor wg_dz_scale(*dz_absmax) (WgradLaunch::np == 2), removed here
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map,
-                        int cin_p, int cin, int cout, float* dw, hipStream_t stream, const unsigned* dz_absmax = nullptr);
+                        int cin_p, int cin, int cout, float* dw, hipStream_t stream, const float* dz_absmax = nullptr,
+                        int dz_absmax_n = 0);
 
 // All weight repacks of a step in ONE launch (a per-layer launch each cost more in dispatch gaps than in
 // work): a device table of jobs, blockIdx.y = job.  kind 0: fp32 [tap][rows_pad][cols]; 1 / 2: fp16 / bf16

@@ -471,9 +471,9 @@ __device__ __forceinline__ void wgrad_reduce_tile(const float* __restrict__ part
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int cin_pad,
                                                            int cout_pad, const int* __restrict__ cin_map, int cin_p,
                                                            int cin, int cout, float* __restrict__ dw,
-                                                           const unsigned* __restrict__ dz_absmax) {
+                                                           const float* __restrict__ dz_absmax, int dz_absmax_n) {
   wgrad_reduce_tile(partial, splits, cin_pad, cout_pad, cin_map, cin_p, cin, cout, dw, (int)blockIdx.x,
-                    dz_absmax ? wg_dz_scale(*dz_absmax, true) : 1.f);
+                    dz_absmax ? wg_dz_scale(__float_as_uint(wg_dz_absmax(dz_absmax, dz_absmax_n)), true) : 1.f);
 }
 
 // scratch (floats) the reduction needs behind the `splits` slabs of the wgrad kernels
@@ -487,7 +487,7 @@ size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad) {
 }
 
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map, int cin_p,
-                        int cin, int cout, float* dw, hipStream_t stream, const unsigned* dz_absmax) {
+                        int cin, int cout, float* dw, hipStream_t stream, const float* dz_absmax, int dz_absmax_n) {
   const size_t slab = (size_t)9 * cin_pad * cout_pad;
   const float* src = partial;
   int n = splits;
@@ -505,7 +505,7 @@ int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_
     n = groups;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, n, cin_pad, cout_pad, cin_map, cin_p,
-                     cin, cout, dw, dz_absmax);
+                     cin, cout, dw, dz_absmax, dz_absmax_n);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

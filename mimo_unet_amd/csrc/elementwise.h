@@ -33,10 +33,8 @@ int colsum_vec_launch(const float* partial, int rows, int cols, int C, float* ou
 int bn_fwd_stats_launch(const float* partial, int rows, int cout_pad, int C, int Cp, int64_t count, const float* gamma,
                         const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
                         float* invstd, float* scale, float* shift, const ColsumScratch& cs, hipStream_t st);
-// absmax_reset != nullptr: that word is cleared (the apply pass behind this launch accumulates max |dz| into it)
 int bn_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int64_t count, int training, float* c1, float* c2,
-                        float* dgamma, float* dbeta, float* dbias_zero, const ColsumScratch& cs, hipStream_t st,
-                        unsigned* absmax_reset = nullptr);
+                        float* dgamma, float* dbeta, float* dbias_zero, const ColsumScratch& cs, hipStream_t st);
 int head_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int Co, float* dw, float* db, const ColsumScratch& cs,
                           hipStream_t st);
 
@@ -169,11 +167,13 @@ int bn_bwd_finalize_launch(const double* sums, int chunks, int C, int Cp, int64_
 int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int ldz,
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
                         int C, const float* c1, const float* c2, int Cp, int N, int H, int W, void* dz, int split_out,
-                        float* partial, int* rows, hipStream_t st, unsigned* absmax = nullptr);
+                        float* partial, int* rows, hipStream_t st, float* absmax = nullptr,
+                        int* absmax_n = nullptr);  // absmax: *absmax_n per-wave maxima of |dz| (WgradLaunch::dz_absmax, <= kDzMaxSlots)
 // dst[p] = [hi Cp bf16 | lo Cp bf16] of src[p][Cp] — the storage the bf16-pair convolution kernels read
 // (split_out != 0 above writes dz in this form directly)
-// absmax != nullptr: the float bits of max |src| are left there (WgradLaunch::dz_absmax)
-int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStream_t st, unsigned* absmax = nullptr);
+// absmax != nullptr: *absmax_n per-wave maxima of |src| are left there (WgradLaunch::dz_absmax; capacity kDzMaxSlots floats)
+int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStream_t st, float* absmax = nullptr,
+                       int* absmax_n = nullptr);
 // out[c] = sum over chunks of sums[chunk][c], c < C
 int vec_finalize_launch(const double* sums, int chunks, int cols, int C, float* out, hipStream_t st);
 

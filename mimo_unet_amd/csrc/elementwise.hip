@@ -1500,12 +1500,8 @@ __global__ __launch_bounds__(kColsumThreads) void bn_bwd_stats_kernel(const floa
                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                       float* __restrict__ dbias_zero,
                                                                       double* __restrict__ scratch, int scratch_cols,
-                                                                      int* __restrict__ tickets, int* __restrict__ status,
-                                                                      unsigned* __restrict__ absmax_reset) {
+                                                                      int* __restrict__ tickets, int* __restrict__ status) {
   __shared__ double red[2048];
-  // the word the apply pass that follows accumulates max |dz| into (two-MFMA weight gradient): cleared here, one launch
-  // ahead of its writers and behind every reader of the previous backward (the plan joins its weight-gradient stream)
-  if (absmax_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *absmax_reset = 0u;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   double s1, s2;
   if (!grid_colsum2(partial, rows, (size_t)2 * Cp, c, Cp + c, c < Cp, true, red, scratch, scratch_cols, tickets, &s1, &s2)) return;
@@ -1523,12 +1519,10 @@ __global__ __launch_bounds__(kColsumThreads) void bn_bwd_stats_kernel(const floa
 }
 
 int bn_bwd_stats_launch(const float* partial, int rows, int C, int Cp, int64_t count, int training, float* c1, float* c2,
-                        float* dgamma, float* dbeta, float* dbias_zero, const ColsumScratch& cs, hipStream_t st,
-                        unsigned* absmax_reset) {
+                        float* dgamma, float* dbeta, float* dbias_zero, const ColsumScratch& cs, hipStream_t st) {
   const int groups = ceil_div(Cp, 64);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(groups, colsum_chunks(rows)), dim3(kColsumThreads), 0, st, partial, rows, C, Cp,
-                     (double)count, training, c1, c2, dgamma, dbeta, dbias_zero, cs.sums, groups * 64, cs.tickets, cs.status,
-                     absmax_reset);
+                     (double)count, training, c1, c2, dgamma, dbeta, dbias_zero, cs.sums, groups * 64, cs.tickets, cs.status);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
@@ -1563,24 +1557,22 @@ __device__ __forceinline__ void st_split4(float* base, size_t p, int Cp, int q, 
   *reinterpret_cast<bf16x4_ew*>(d + 2 * rc) = lo;
 }
 
-// max over a wave of a non-negative per-thread value -> at most one atomic max per wave on the value's float bits
-// (non-negative floats order like unsigned integers; a maximum does not depend on the order of its operands: deterministic)
-__device__ __forceinline__ void block_absmax_to(unsigned* slot, float v) {
-  // per WAVE, no barrier: a butterfly over the 64 lanes, then lane 0 alone.  Most waves do not hold the maximum: one L2 load
-  // instead of an atomic on the one word every wave of the launch would otherwise queue on.  (A first version reduced over
-  // the workgroup through LDS and two barriers: +7 us per apply launch, +0.16 ms per step.)
+// max over a wave of a non-negative per-thread value -> the wave's own slot of `slots` (slot index = 4 * workgroup + wave:
+// a plain store, no atomic, no barrier).  Whoever needs the tensor's maximum reduces the slots (wg_dz_absmax, common.h).  Two
+// earlier versions kept ONE word per tensor: an atomic max per workgroup (+4 us per launch: ~1800 same-address atomics
+// queue), then per wave behind a relaxed load of the word (+25 us: the loads queue too — 4.66 -> 5.25 ms per step at 4
+// images per GPU; profiles/r05/wgrad_two_mfma.txt item 5).
+__device__ __forceinline__ void wave_absmax_store(float* slots, float v) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) v = fmaxf(v, __shfl_xor(v, d));
-  if ((threadIdx.x & 63) == 0 && v > 0.f &&
-      __float_as_uint(v) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-    atomicMax(slot, __float_as_uint(v));
+  if ((threadIdx.x & 63) == 0) slots[(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)] = v;
 }
 __device__ __forceinline__ float absmax4(float m, float4 r) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
 }
 
 __global__ void split_pairs_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cv, int64_t P,
-                                   unsigned* __restrict__ absmax) {
+                                   float* __restrict__ absmax) {
   const PQ t = pixquad(Cv);
   float amax = 0.f;
   if (t.active)
@@ -1589,25 +1581,36 @@ __global__ void split_pairs_kernel(const float* __restrict__ src, float* __restr
       st_split4(dst, (size_t)p, 4 * Cv, t.q, r);
       amax = absmax4(amax, r);
     }
-  if (absmax) block_absmax_to(absmax, amax);
+  if (absmax) wave_absmax_store(absmax, amax);
 }
 
-int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStream_t st, unsigned* absmax) {
-  if (absmax) MIMO_HIP_CHECK(hipMemsetAsync(absmax, 0, sizeof(unsigned), st));
-  hipLaunchKernelGGL(split_pairs_kernel, pq_grid(Cp / 4, P), dim3(256), 0, st, src, dst, Cp / 4, P, absmax);
+int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStream_t st, float* absmax, int* absmax_n) {
+  const dim3 grid = pq_grid(Cp / 4, P, 2048);
+  if (absmax && 4 * (int)(grid.x * grid.y) > kDzMaxSlots) {
+    set_error("split_pairs: %d x %d workgroups exceed the max |dz| slots", (int)grid.x, (int)grid.y);
+    return MIMO_ERR_INVALID;
+  }
+  if (absmax_n) *absmax_n = 4 * (int)(grid.x * grid.y);
+  hipLaunchKernelGGL(split_pairs_kernel, grid, dim3(256), 0, st, src, dst, Cp / 4, P, absmax);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }
 
 // (plain / folded sources: held to 72 registers = 7 waves per SIMD, the occupancy round 3's grid scan found best — the
 // max |dz| tracking of round 5 had pushed the folded instance to 74 and cost the class 7 %)
+#ifndef MIMO_APPLY_MINWAVES
+#define MIMO_APPLY_MINWAVES 7
+#endif
+#ifndef MIMO_APPLY_ABSMAX
+#define MIMO_APPLY_ABSMAX 1  // 0: A/B build without the max |dz| tracking (the two-MFMA weight gradient then reads garbage)
+#endif
 template <typename TZ, typename TA, int SRC>
-__global__ __launch_bounds__(256, (SRC == GS_PLAIN || SRC == GS_FOLD) ? 7 : 1) void bn_bwd_apply_kernel(const GradSrc src, const TZ* __restrict__ z, int ldz, const float* __restrict__ scale,
+__global__ __launch_bounds__(256, (SRC == GS_PLAIN || SRC == GS_FOLD) ? MIMO_APPLY_MINWAVES : 1) void bn_bwd_apply_kernel(const GradSrc src, const TZ* __restrict__ z, int ldz, const float* __restrict__ scale,
                                     const float* __restrict__ shift, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ mask, int C,
                                     const float* __restrict__ c1, const float* __restrict__ c2, int Cv, int N, int H,
                                     int W, TA* __restrict__ dz, int split_out, float* __restrict__ partial,
-                                    unsigned* __restrict__ absmax) {
+                                    float* __restrict__ absmax) {
   __shared__ float4 red[256];
   const PQ t = pixquad(Cv);
   const int Cp = 4 * Cv;
@@ -1629,7 +1632,7 @@ __global__ __launch_bounds__(256, (SRC == GS_PLAIN || SRC == GS_FOLD) ? 7 : 1) v
       else
         st4(dz + (size_t)p * Cp + 4 * t.q, r);
       acc = f4add(acc, r);
-      amax = absmax4(amax, r);
+      if (MIMO_APPLY_ABSMAX) amax = absmax4(amax, r);
     };
     if constexpr (SRC == GS_POOL) {
       const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, P = N * Hc * Wc;
@@ -1653,7 +1656,7 @@ __global__ __launch_bounds__(256, (SRC == GS_PLAIN || SRC == GS_FOLD) ? 7 : 1) v
       }
     }
   }
-  if (absmax) block_absmax_to(absmax, amax);
+  if (MIMO_APPLY_ABSMAX && absmax) wave_absmax_store(absmax, amax);
   if (!partial) return;  // training mode: the bias gradient is exactly zero, no column sums wanted
   const float4 s = quad_block_sum(acc, t, red);
   if (t.pl == 0 && t.q < Cv) st4(partial + (size_t)blockIdx.x * Cp + 4 * t.q, s);
@@ -1662,12 +1665,17 @@ __global__ __launch_bounds__(256, (SRC == GS_PLAIN || SRC == GS_FOLD) ? 7 : 1) v
 int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int ldz,
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
                         int C, const float* c1, const float* c2, int Cp, int N, int H, int W, void* dz, int split_out,
-                        float* partial, int* rows, hipStream_t st, unsigned* absmax) {
+                        float* partial, int* rows, hipStream_t st, float* absmax, int* absmax_n) {
   MIMO_TRY(check_grad_src(src, dta, dtz));
   const int Cv = Cp / 4;
   const int64_t units = src.kind == GS_POOL ? (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) : (int64_t)N * H * W;
   const dim3 grid = pq_grid(Cv, units, src.kind == GS_POOL ? 1024 : src.kind == GS_HEAD ? 1280 : kBlocksBnBwd);  // 4 / 5 / 7 per CU
   *rows = grid.x;
+  if (absmax_n) *absmax_n = 4 * (int)(grid.x * grid.y);  // one slot per wave (256-thread workgroups)
+  if (absmax && 4 * (int)(grid.x * grid.y) > kDzMaxSlots) {
+    set_error("bn_bwd_apply: %d x %d workgroups exceed the max |dz| slots", (int)grid.x, (int)grid.y);
+    return MIMO_ERR_INVALID;
+  }
   if (split_out && dta != ST_F32) {
     set_error("bn_bwd_apply: pair-split dz exists for fp32 storage only");
     return MIMO_ERR_INVALID;

@@ -337,16 +337,18 @@ int mimo_op_conv3x3_wgrad(const float* x, const float* dz, float* dw, float* dbi
       return MIMO_ERR_HIP;
     }
     // as in the plan: two fp16 MFMAs per product where the geometry has that kernel, with max |dz| next to the split
-    unsigned* amax = (!bf16 && wgrad_split_has_np2(cin_p, cout_p)) ? t.get<unsigned>(1) : nullptr;
-    MIMO_TRY(split_pairs_launch(dz, dzs, (int64_t)n * h * wd, cout_p, st, amax));
+    float* amax = (!bf16 && wgrad_split_has_np2(cin_p, cout_p)) ? t.get<float>(kDzMaxSlots) : nullptr;
+    int amax_n = 0;
+    MIMO_TRY(split_pairs_launch(dz, dzs, (int64_t)n * h * wd, cout_p, st, amax, &amax_n));
     a.dz = dzs;
     a.np = bf16 ? 1 : amax ? 2 : 3;
     a.dz_absmax = amax;
+    a.dz_absmax_n = amax_n;
     MIMO_TRY(wgrad_split_launch(a, st));
   } else {
     MIMO_TRY(wgrad_launch(a, st));
   }
-  MIMO_TRY(wgrad_reduce_launch(a.partial, a.splits, a.cin_pad, a.cout_pad, cm, cin_p, cin, cout, dw, st, a.dz_absmax));
+  MIMO_TRY(wgrad_reduce_launch(a.partial, a.splits, a.cin_pad, a.cout_pad, cm, cin_p, cin, cout, dw, st, a.dz_absmax, a.dz_absmax_n));
   if (dbias) {
     hipLaunchKernelGGL(colsum_naive_kernel, dim3(cout), dim3(256), 0, st, dz, (int64_t)n * h * wd, cout_p, cout, dbias);
     MIMO_KERNEL_CHECK();

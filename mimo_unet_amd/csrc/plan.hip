@@ -89,7 +89,7 @@ struct ConvBN {
   void *wf16 = nullptr, *wd16 = nullptr;  // split-bf16 packed weights (MIMO_PREC_SPLIT16)
   bool fwd_split = false, dg_split = false, wg_split = false;
   unsigned* wmax = nullptr;  // fp16 forward weight image: max |w| of the layer, float bits (w16_scale: the image's power-of-two scale)
-  unsigned* dz_absmax = nullptr;  // != nullptr: the weight gradient runs two fp16 MFMAs per product (wgrad_split.hip NP == 2)
+  bool wg_np2 = false;  // the weight gradient runs two fp16 MFMAs per product (wgrad_split.hip NP == 2)
   bool thin = false;  // image convolution (<= 4 input channels) on the plain-FMA kernels of conv_thin.hip
   int fwd_wide = 0, dg_wide = 0;  // != 0: the launch runs on conv_wide.hip, value = packed weight rows (conv3x3_wide_rows)
   int *cin_map = nullptr, *fwd_row_map = nullptr, *dg_row_map = nullptr, *dg_col_map = nullptr;
@@ -200,6 +200,7 @@ struct mimo_plan {
   hipEvent_t ev_dz[kDzBufs] = {}, ev_wg[kDzBufs] = {}, ev_join = nullptr;
   bool wg_pending[kDzBufs] = {};
   float* s_dz2[kDzBufs] = {};
+  float* s_dzmax2[kDzBufs] = {};  // per-wave maxima of |dz| of the tensor in s_dz2[i] (two-MFMA weight gradient)
   // split (bf16 hi|lo) copy of dz for layers whose data gradient runs on the fp32 kernel while the weight
   // gradient runs on the bf16-pair kernel (fewer than 16 output channels); null when no layer needs it
   float* s_dzs2[kDzBufs] = {};
@@ -424,8 +425,7 @@ struct mimo_plan {
       if (L.thin && train_bufs) cap_slab = std::max(cap_slab, wgrad_thin_scratch(Cin, L.cout_p));
     }
     if (L.wg_split && !L.dg_split) any_mixed_dz = true;
-    if (cfg.precision == MIMO_PREC_SPLIT16 && L.wg_split && train_bufs && wgrad_split_has_np2(L.cin_p, L.cout_p))
-      MIMO_TRY(dalloc(&L.dz_absmax, 1));
+    L.wg_np2 = cfg.precision == MIMO_PREC_SPLIT16 && L.wg_split && train_bufs && wgrad_split_has_np2(L.cin_p, L.cout_p);
     if (cfg.precision == MIMO_PREC_SPLIT16 || mixed) {  // decomposition per layer and direction (sched::wide_config)
       if (L.fwd_split) L.fwd_wide = conv3x3_wide_rows(fwd_mode(), n, L.cin_p, L.cout_p, h, w);
       if (L.dg_split) L.dg_wide = conv3x3_wide_rows(dgrad_mode(), n, L.cout_p, L.cin_p, h + 2, w + 2);
@@ -736,6 +736,8 @@ struct mimo_plan {
       // With the profiler armed (bench.py's second pass) everything runs on the caller's stream.
       wg_async = !(we && atoi(we) == 0) && !cfg.inference_only;
       for (int i = 0; i < kDzBufs; ++i) s_dz2[i] = s_dz;
+      if (!cfg.inference_only)
+        for (int i = 0; i < kDzBufs; ++i) MIMO_TRY(dalloc(&s_dzmax2[i], kDzMaxSlots));
       if (any_mixed_dz) {
         MIMO_TRY(dalloc(&s_dzs2[0], cap_act));
         for (int i = 1; i < kDzBufs; ++i) s_dzs2[i] = s_dzs2[0];
@@ -1197,8 +1199,7 @@ struct mimo_plan {
     prof_end(pr, 0.0, (4.0 + src_b) * (double)P * L.cout_p, st);
     if (src.kind == GS_HEAD) head_rows = rows;
     MIMO_TRY(bn_bwd_stats_launch(s_partial, rows, L.Cout, L.cout_p, P, fwd_training ? 1 : 0, L.c1, L.c2,
-                                 grads + L.off_gamma, grads + L.off_beta, fwd_training ? grads + L.off_b : nullptr, colsum(), st,
-                                 L.dz_absmax));
+                                 grads + L.off_gamma, grads + L.off_beta, fwd_training ? grads + L.off_b : nullptr, colsum(), st));
     // (with the profiler armed everything runs on the caller's stream: per-kernel times, not overlapped times)
     const bool async = wg_async && !prof_on;
     const int b = dz_idx;
@@ -1211,9 +1212,11 @@ struct mimo_plan {
     // else reads this dz)
     const bool thin_wg = L.thin && !mixed && !need_dgrad && wgrad_thin_ok(L.Cin, L.cout_p, L.N, L.H, L.W);
     pr = prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
+    int dzmax_n = 0;  // per-wave maxima of |dz| that launch leaves (two-MFMA weight gradient)
     MIMO_TRY(bn_bwd_apply_launch(src, this->st, L.z, L.dtz, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
                                  L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, (L.dg_split && !mixed && !thin_wg) ? 1 : 0,
-                                 fwd_training ? nullptr : s_partial, &rows, st, thin_wg ? nullptr : L.dz_absmax));
+                                 fwd_training ? nullptr : s_partial, &rows, st, (L.wg_np2 && !thin_wg) ? s_dzmax2[b] : nullptr,
+                                 &dzmax_n));
     prof_end(pr, 0.0, (8.0 + src_b) * (double)P * L.cout_p, st);
     // dz storage: bf16 hi|lo pairs when the data-gradient kernel is the bf16-pair one (then the weight
     // gradient is too); fp32 otherwise, with a split copy for a bf16-pair weight gradient
@@ -1280,9 +1283,10 @@ struct mimo_plan {
     wg.cout_pad = L.wg_cout_pad;
     wg.splits = L.wg_splits;
     wg.np = (cfg.precision == MIMO_PREC_BF16 || mixed) ? 1 : 3;
-    if (L.dz_absmax && wg.np == 3 && !thin_wg) {  // two fp16 MFMAs per product (wgrad_split.hip NP == 2)
+    if (L.wg_np2 && wg.np == 3 && !thin_wg) {  // two fp16 MFMAs per product (wgrad_split.hip NP == 2)
       wg.np = 2;
-      wg.dz_absmax = L.dz_absmax;
+      wg.dz_absmax = s_dzmax2[b];  // (travels with the dz buffer it describes: same ping-pong index, same events)
+      wg.dz_absmax_n = dzmax_n;
     }
     // 16-bit storage: activations and dz plain NHWC 16-bit; the image convolution's input stays fp32
     wg.store = !mixed ? 0 : (L.fwd_split ? (f16 ? 2 : 1) : (f16 ? 4 : 3));
@@ -1300,7 +1304,7 @@ struct mimo_plan {
     }
     if (!thin_wg)  // (the plain-FMA kernel's launch reduces its own partials)
       MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
-                                   grads + L.off_w, ws, wg.dz_absmax));
+                                   grads + L.off_w, ws, wg.dz_absmax, wg.dz_absmax_n));
     return MIMO_OK;
   }
 

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       }
     }
     // NP == 2: the power of two that scales this layer's dz into fp16 range (see the kernel comment)
-    const float dz_mul = NP == 2 ? wg_dz_scale(*a.dz_absmax, false) : 1.f;
+    const float dz_mul = NP == 2 ? wg_dz_scale(__float_as_uint(wg_dz_absmax(a.dz_absmax, a.dz_absmax_n)), false) : 1.f;
     (void)dz_mul;
     f32x4 in_sc = f32x4{0.f, 0.f, 0.f, 0.f}, in_sh = f32x4{0.f, 0.f, 0.f, 0.f};
     if (FIN && a_ch[0] >= 0) {  // (channels past cin_p are loaded from the zero page and must stay zero: relu(0 * 0 + 0))
@@ -716,7 +716,7 @@ int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream) {
     return MIMO_ERR_INVALID;
   }
   const bool ws = wgrad_use_ws(CI, CO);
-  if (a.np == 2 && !(ws && a.store == 0 && a.dz_absmax)) {
+  if (a.np == 2 && !(ws && a.store == 0 && a.dz_absmax && a.dz_absmax_n > 0 && a.dz_absmax_n <= kDzMaxSlots)) {
     set_error("wgrad_split: two MFMAs per product need the wave-specialised kernel, fp32 storage and WgradLaunch::dz_absmax");
     return MIMO_ERR_INVALID;
   }
