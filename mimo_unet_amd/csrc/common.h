@@ -154,7 +154,7 @@ struct WgradLaunch {
   // split kernels: MFMAs per product block — 3 (bf16 hi/lo pairs both sides), 1 (bf16 compute), or 2 (round 5,
   // wave-specialised kernel, store 0: the activation as one fp16 value, dz as a scaled fp16 pair; needs dz_absmax)
   int np = 3;
-  // np == 2: dz_absmax_n floats whose maximum is max |dz| of this tensor — one per wave of the launch that wrote dz
+  // np == 2: dz_absmax_n floats whose maximum is max |dz| of this tensor — one per workgroup of the launch that wrote dz
   // (bn_bwd_apply / split_pairs: plain stores, no atomics; kDzMaxSlots is their capacity).  Every workgroup of the weight
   // gradient reduces them itself (wg_dz_absmax: identical result everywhere), scales dz by wg_dz_scale(max) and
   // wgrad_reduce_launch divides the result by it again
@@ -171,7 +171,7 @@ struct WgradLaunch {
 };
 // the power of two 2^(14 - floor(log2 max|dz|)) (inverse: its reciprocal) from the float bits of max |dz|: scaled values lie
 // below 2^15 (fp16's largest finite value is 65504); an all-zero tensor scales by 2^126
-constexpr int kDzMaxSlots = 4 * 2048 * 2;  // waves of the largest launch that writes dz (<= 2048 x 2 workgroups of 256 threads)
+constexpr int kDzMaxSlots = 2048 * 2;  // workgroups of the largest launch that writes dz (<= 2048 x 2)
 __host__ __device__ __forceinline__ float wg_dz_scale(unsigned absmax_bits, bool inverse) {
   int e = (int)((absmax_bits >> 23) & 0xffu);  // biased exponent
   e = e < 16 ? 16 : e > 254 ? 254 : e;
@@ -181,7 +181,7 @@ __host__ __device__ __forceinline__ float wg_dz_scale(unsigned absmax_bits, bool
   return c.v;
 }
 #if defined(__HIPCC__)
-// max of the n per-wave maxima, computed redundantly by every wave that calls it (n <= kDzMaxSlots floats, L2-resident:
+// max of the n per-workgroup maxima, computed redundantly by every wave that calls it (n <= kDzMaxSlots floats, L2-resident:
 // n / 64 coalesced loads per lane and a butterfly) — no hot word that thousands of waves would queue on
 __device__ __forceinline__ float wg_dz_absmax(const float* __restrict__ slots, int n) {
   float m = 0.f;

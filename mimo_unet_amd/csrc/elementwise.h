@@ -168,10 +168,10 @@ int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
                         int C, const float* c1, const float* c2, int Cp, int N, int H, int W, void* dz, int split_out,
                         float* partial, int* rows, hipStream_t st, float* absmax = nullptr,
-                        int* absmax_n = nullptr);  // absmax: *absmax_n per-wave maxima of |dz| (WgradLaunch::dz_absmax, <= kDzMaxSlots)
+                        int* absmax_n = nullptr);  // absmax: *absmax_n per-workgroup maxima of |dz| (WgradLaunch::dz_absmax, <= kDzMaxSlots)
 // dst[p] = [hi Cp bf16 | lo Cp bf16] of src[p][Cp] — the storage the bf16-pair convolution kernels read
 // (split_out != 0 above writes dz in this form directly)
-// absmax != nullptr: *absmax_n per-wave maxima of |src| are left there (WgradLaunch::dz_absmax; capacity kDzMaxSlots floats)
+// absmax != nullptr: *absmax_n per-workgroup maxima of |src| are left there (WgradLaunch::dz_absmax; capacity kDzMaxSlots floats)
 int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStream_t st, float* absmax = nullptr,
                        int* absmax_n = nullptr);
 // out[c] = sum over chunks of sums[chunk][c], c < C

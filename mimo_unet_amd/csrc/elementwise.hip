@@ -1557,15 +1557,22 @@ __device__ __forceinline__ void st_split4(float* base, size_t p, int Cp, int q, 
   *reinterpret_cast<bf16x4_ew*>(d + 2 * rc) = lo;
 }
 
-// max over a wave of a non-negative per-thread value -> the wave's own slot of `slots` (slot index = 4 * workgroup + wave:
-// a plain store, no atomic, no barrier).  Whoever needs the tensor's maximum reduces the slots (wg_dz_absmax, common.h).  Two
-// earlier versions kept ONE word per tensor: an atomic max per workgroup (+4 us per launch: ~1800 same-address atomics
-// queue), then per wave behind a relaxed load of the word (+25 us: the loads queue too — 4.66 -> 5.25 ms per step at 4
-// images per GPU; profiles/r05/wgrad_two_mfma.txt item 5).
-__device__ __forceinline__ void wave_absmax_store(float* slots, float v) {
+// max over the workgroup of a non-negative per-thread value -> the workgroup's own slot of `slots` (a plain store, no
+// atomic; one barrier at the end of the kernel).  Whoever needs the tensor's maximum reduces the slots (wg_dz_absmax,
+// common.h).  Earlier versions kept ONE word per tensor: an atomic max per workgroup (+4 us per launch: ~1800 same-address
+// atomics queue), then per wave behind a relaxed load of the word (+25 us: the loads queue too — 4.66 -> 5.25 ms per step
+// at 4 images per GPU); per-wave slots cost the consumers 4 x the loads (profiles/r05/wgrad_two_mfma.txt item 5).
+__device__ __forceinline__ void block_absmax_store(float* slots, float v) {
+  __shared__ float wm[16];
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) v = fmaxf(v, __shfl_xor(v, d));
-  if ((threadIdx.x & 63) == 0) slots[(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)] = v;
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = wm[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, wm[i]);
+    slots[blockIdx.y * gridDim.x + blockIdx.x] = m;
+  }
 }
 __device__ __forceinline__ float absmax4(float m, float4 r) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
@@ -1581,16 +1588,16 @@ __global__ void split_pairs_kernel(const float* __restrict__ src, float* __restr
       st_split4(dst, (size_t)p, 4 * Cv, t.q, r);
       amax = absmax4(amax, r);
     }
-  if (absmax) wave_absmax_store(absmax, amax);
+  if (absmax) block_absmax_store(absmax, amax);
 }
 
 int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStream_t st, float* absmax, int* absmax_n) {
   const dim3 grid = pq_grid(Cp / 4, P, 2048);
-  if (absmax && 4 * (int)(grid.x * grid.y) > kDzMaxSlots) {
+  if (absmax && (int)(grid.x * grid.y) > kDzMaxSlots) {
     set_error("split_pairs: %d x %d workgroups exceed the max |dz| slots", (int)grid.x, (int)grid.y);
     return MIMO_ERR_INVALID;
   }
-  if (absmax_n) *absmax_n = 4 * (int)(grid.x * grid.y);
+  if (absmax_n) *absmax_n = (int)(grid.x * grid.y);
   hipLaunchKernelGGL(split_pairs_kernel, grid, dim3(256), 0, st, src, dst, Cp / 4, P, absmax);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
@@ -1656,7 +1663,7 @@ __global__ __launch_bounds__(256, (SRC == GS_PLAIN || SRC == GS_FOLD) ? MIMO_APP
       }
     }
   }
-  if (MIMO_APPLY_ABSMAX && absmax) wave_absmax_store(absmax, amax);
+  if (MIMO_APPLY_ABSMAX && absmax) block_absmax_store(absmax, amax);
   if (!partial) return;  // training mode: the bias gradient is exactly zero, no column sums wanted
   const float4 s = quad_block_sum(acc, t, red);
   if (t.pl == 0 && t.q < Cv) st4(partial + (size_t)blockIdx.x * Cp + 4 * t.q, s);
@@ -1671,8 +1678,8 @@ int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int
   const int64_t units = src.kind == GS_POOL ? (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) : (int64_t)N * H * W;
   const dim3 grid = pq_grid(Cv, units, src.kind == GS_POOL ? 1024 : src.kind == GS_HEAD ? 1280 : kBlocksBnBwd);  // 4 / 5 / 7 per CU
   *rows = grid.x;
-  if (absmax_n) *absmax_n = 4 * (int)(grid.x * grid.y);  // one slot per wave (256-thread workgroups)
-  if (absmax && 4 * (int)(grid.x * grid.y) > kDzMaxSlots) {
+  if (absmax_n) *absmax_n = (int)(grid.x * grid.y);  // one slot per workgroup
+  if (absmax && (int)(grid.x * grid.y) > kDzMaxSlots) {
     set_error("bn_bwd_apply: %d x %d workgroups exceed the max |dz| slots", (int)grid.x, (int)grid.y);
     return MIMO_ERR_INVALID;
   }

@@ -200,7 +200,7 @@ struct mimo_plan {
   hipEvent_t ev_dz[kDzBufs] = {}, ev_wg[kDzBufs] = {}, ev_join = nullptr;
   bool wg_pending[kDzBufs] = {};
   float* s_dz2[kDzBufs] = {};
-  float* s_dzmax2[kDzBufs] = {};  // per-wave maxima of |dz| of the tensor in s_dz2[i] (two-MFMA weight gradient)
+  float* s_dzmax2[kDzBufs] = {};  // per-workgroup maxima of |dz| of the tensor in s_dz2[i] (two-MFMA weight gradient)
   // split (bf16 hi|lo) copy of dz for layers whose data gradient runs on the fp32 kernel while the weight
   // gradient runs on the bf16-pair kernel (fewer than 16 output channels); null when no layer needs it
   float* s_dzs2[kDzBufs] = {};
@@ -1212,7 +1212,7 @@ struct mimo_plan {
     // else reads this dz)
     const bool thin_wg = L.thin && !mixed && !need_dgrad && wgrad_thin_ok(L.Cin, L.cout_p, L.N, L.H, L.W);
     pr = prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
-    int dzmax_n = 0;  // per-wave maxima of |dz| that launch leaves (two-MFMA weight gradient)
+    int dzmax_n = 0;  // per-workgroup maxima of |dz| that launch leaves (two-MFMA weight gradient)
     MIMO_TRY(bn_bwd_apply_launch(src, this->st, L.z, L.dtz, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
                                  L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, (L.dg_split && !mixed && !thin_wg) ? 1 : 0,
                                  fwd_training ? nullptr : s_partial, &rows, st, (L.wg_np2 && !thin_wg) ? s_dzmax2[b] : nullptr,
