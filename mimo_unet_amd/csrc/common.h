@@ -54,19 +54,8 @@ __device__ __forceinline__ int xcd_virtual_index(int linear, int total) {
 // off == 1: Ho==Hi, X is reflect-padded (forward conv, components.py:23,26)
 // off == 2: Ho==Hi+2, X is zero outside the image (transposed conv producing the gradient on
 //           the reflect-PADDED domain; consumers fold the border back, see fold_* in elementwise.hip)
-// Scale of the fp16 (hi, lo) weight images of the split16 / 16-mixed forward: 2^8 (rounds 1-4: keeps ordinary weights out of
-// fp16's subnormals) while the layer's largest |w| is below 128; from there the power of two that puts max |w| into
-// [2^13, 2^14) — a layer with |w| >= 256 no longer overflows its hi part (round 5: the reference's fp32 Conv2d is finite for
-// any fp32 weight, components.py:23,26).  `wmax_bits` = float bits of max |w| (wabsmax_jobs_launch); inverse: the
-// reciprocal, applied in the convolution's epilogue.  Both are exact powers of two.
-__host__ __device__ __forceinline__ float w16_scale(unsigned wmax_bits, bool inverse) {
-  const int e = (int)((wmax_bits >> 23) & 0xffu) - 127;  // floor(log2 max |w|)
-  int k = e < 7 ? 8 : 13 - e;                            // scale = 2^k
-  k = k < -100 ? -100 : k;
-  union { unsigned u; float v; } c;
-  c.u = (unsigned)(127 + (inverse ? -k : k)) << 23;
-  return c.v;
-}
+// power-of-two scale of a layer's fp16 weight image from the float bits of its max |w| (tile_sched.h: host-testable)
+__host__ __device__ __forceinline__ float w16_scale(unsigned wmax_bits, bool inverse) { return sched::w16_scale(wmax_bits, inverse); }
 
 constexpr int kFinSlack = 32;  // zero floats behind ConvLaunch::in_scale / in_shift (a 32-channel chunk may start at cin_p - 8)
 struct ConvLaunch {
@@ -169,17 +158,9 @@ struct WgradLaunch {
   const float* in_scale = nullptr;
   const float* in_shift = nullptr;
 };
-// the power of two 2^(14 - floor(log2 max|dz|)) (inverse: its reciprocal) from the float bits of max |dz|: scaled values lie
-// below 2^15 (fp16's largest finite value is 65504); an all-zero tensor scales by 2^126
+// the power of two that scales dz in the two-MFMA weight gradient, from the float bits of max |dz| (tile_sched.h: host-testable)
 constexpr int kDzMaxSlots = 2048 * 2;  // workgroups of the largest launch that writes dz (<= 2048 x 2)
-__host__ __device__ __forceinline__ float wg_dz_scale(unsigned absmax_bits, bool inverse) {
-  int e = (int)((absmax_bits >> 23) & 0xffu);  // biased exponent
-  e = e < 16 ? 16 : e > 254 ? 254 : e;
-  const unsigned f = (unsigned)(inverse ? e - 14 : 268 - e);
-  union { unsigned u; float v; } c;
-  c.u = f << 23;
-  return c.v;
-}
+__host__ __device__ __forceinline__ float wg_dz_scale(unsigned absmax_bits, bool inverse) { return sched::wg_dz_scale(absmax_bits, inverse); }
 #if defined(__HIPCC__)
 // max of the n per-workgroup maxima, computed redundantly by every wave that calls it (n <= kDzMaxSlots floats, L2-resident:
 // n / 64 coalesced loads per lane and a butterfly) — no hot word that thousands of waves would queue on

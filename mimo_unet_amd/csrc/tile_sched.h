@@ -124,6 +124,33 @@ static inline int wg_pick_splits(int N, int H, int W, int cin_pad, int cout_pad,
   return best;
 }
 
+// ---- power-of-two scales of the fp16 operands (round 5) ---------------------------------------------------------------
+// Float bits in, a power of two out: pure integer work on the exponent field, exact by construction.
+MIMO_SCHED_HD static inline float pow2_bits(int k) {  // 2^k for -126 <= k <= 127
+  union { unsigned u; float v; } c;
+  c.u = (unsigned)(127 + k) << 23;
+  return c.v;
+}
+// Scale of the fp16 (hi, lo) weight images of the split16 / 16-mixed forward: 2^8 (rounds 1-4: keeps ordinary weights out of
+// fp16's subnormals) while the layer's largest |w| is below 128; from there the power of two that puts max |w| into
+// [2^13, 2^14) — a layer with |w| >= 256 no longer overflows its hi part (the reference's fp32 Conv2d is finite for any
+// fp32 weight, components.py:23,26).  `wmax_bits` = float bits of max |w|; inverse: the reciprocal, applied in the
+// convolution's epilogue.
+MIMO_SCHED_HD static inline float w16_scale(unsigned wmax_bits, bool inverse) {
+  const int e = (int)((wmax_bits >> 23) & 0xffu) - 127;  // floor(log2 max |w|)
+  int k = e < 7 ? 8 : 13 - e;                            // scale = 2^k
+  k = k < -100 ? -100 : k;
+  return pow2_bits(inverse ? -k : k);
+}
+// Scale of dz in the two-MFMA weight gradient: 2^(14 - floor(log2 max|dz|)), so that the largest scaled |dz| lies in
+// [2^14, 2^15) (fp16's largest finite value is 65504); inverse: its reciprocal.  An all-zero tensor scales by 2^125.
+MIMO_SCHED_HD static inline float wg_dz_scale(unsigned absmax_bits, bool inverse) {
+  int e = (int)((absmax_bits >> 23) & 0xffu);  // biased exponent
+  e = e < 16 ? 16 : e > 254 ? 254 : e;
+  const int k = 141 - e;  // 14 - (e - 127)
+  return pow2_bits(inverse ? -k : k);
+}
+
 // ---- wide convolution (conv_wide.hip): 512-pixel tiles, 16-channel K chunks, 32x32x16 MFMA ----------------------
 constexpr int kWideNPix = 512;    // output pixels per tile (4 consumer waves x 4 fragments of 32 pixels)
 constexpr int kWideMaxPix = 640;  // LDS rows of an input halo tile

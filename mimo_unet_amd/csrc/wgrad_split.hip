@@ -25,6 +25,11 @@
 
 #include "common.h"
 
+#ifndef MIMO_WGRAD_NP2_DEPTH
+// taps the activation fragments of the two-MFMA weight gradient are read ahead of their MFMAs (a tap is 2 * NI MFMAs = 128
+// matrix-pipe cycles at NI = 4, about the latency of a transposed LDS read)
+#define MIMO_WGRAD_NP2_DEPTH 1
+#endif
 #ifndef MIMO_WGRAD_PIN_PROLOGUE
 // 1: pin the prologue's LDS reads into a scheduling group of their own, which puts the consumers' fragment reads really
 // one tap ahead of their MFMAs in the ISA.  Measured SLOWER (round 4, profiles/r04/wgrad_read_pipeline.txt: +3.5 % per
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_split_ws_kernel(WgradLaunch a, i
       // r.  One MFMA per product (16-bit storage, bf16 mode): a tap is NI MFMAs = 16 * NI cycles of matrix-pipe time,
       // far below the ~130-cycle latency of a transposed LDS read -> two taps ahead (round 3: with one tap ahead that
       // path waited for LDS at every tap, 598 -> 789 TFLOP/s on the class).  Three MFMAs per product: one tap ahead.
-      constexpr int kDepth = NP >= 2 ? 1 : 2;
+      constexpr int kDepth = NP == 3 ? 1 : NP == 2 ? MIMO_WGRAD_NP2_DEPTH : 2;
       bf16x8 bh[2][NI], bl[NP >= 2 ? 2 : 1][NI], ah[kDepth + 1][MI], al[NP == 3 ? kDepth + 1 : 1][MI];
       // the fragment addresses of all TR x taps steps are loop-invariant; hoisted out of the tile loop they would take
       // ~45 registers (spills) — an opaque copy of the lane's row index per tile keeps them recomputed in place

@@ -6,6 +6,7 @@
 //   * wide_config / wide_grid_x: geometry invariants for every BASELINE layer at N in {1, 2, 4, 16, 32, 64}
 //   * weight-gradient channel tiles / split counts: >= 1, slabs within the plan's scratch formula
 //   * conv_cout_pad: covers the channels, multiple of the fragment width
+//   * w16_scale / wg_dz_scale (round 5): exact powers of two, reciprocal pairs, scaled maxima inside fp16's range
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -195,7 +196,42 @@ static void test_wide_offset_guard() {
   CHECK(wide_config(0, 1, 64, 64, 2048, 2048, 0).nf == 0, "data gradient, same bound");
 }
 
+// Power-of-two scales of the fp16 operands (w16_scale, wg_dz_scale): for every exponent and a sweep of mantissas — an exact
+// power of two, reciprocal pairs, the scaled maximum inside the band that fp16 represents, and the fixed 2^8 for ordinary weights.
+static float bits_to_float(unsigned u) {
+  union { unsigned u; float v; } c;
+  c.u = u;
+  return c.v;
+}
+static unsigned float_to_bits(float v) {
+  union { unsigned u; float v; } c;
+  c.v = v;
+  return c.u;
+}
+static void test_scales() {
+  for (unsigned e = 1; e <= 254; ++e)
+    for (unsigned m = 0; m < (1u << 23); m += 0x1ffffu) {
+      const unsigned bits = (e << 23) | m;
+      const float x = bits_to_float(bits);
+      const float ws = w16_scale(bits, false), wi = w16_scale(bits, true);
+      CHECK((float_to_bits(ws) & 0x7fffffu) == 0 && (float_to_bits(wi) & 0x7fffffu) == 0, "w16_scale(%g) not a power of two", x);
+      CHECK(ws * wi == 1.0f, "w16_scale(%g): %g * %g != 1", x, ws, wi);
+      if (x < 128.f) CHECK(ws == 256.f, "w16_scale(%g) = %g, expected 2^8", x, ws);
+      if (x >= 128.f && e <= 127 + 113) CHECK(x * ws >= 8192.f && x * ws < 16384.f, "w16_scale(%g): scaled max %g outside [2^13, 2^14)", x, x * ws);
+      CHECK(x * ws < 65504.f || e > 127 + 113, "w16_scale(%g): scaled max %g overflows fp16", x, x * ws);
+      const float ds = wg_dz_scale(bits, false), di = wg_dz_scale(bits, true);
+      CHECK((float_to_bits(ds) & 0x7fffffu) == 0 && ds * di == 1.0f, "wg_dz_scale(%g): %g, %g", x, ds, di);
+      if (e >= 16) CHECK(x * ds >= 16384.f && x * ds < 32768.f, "wg_dz_scale(%g): scaled max %g outside [2^14, 2^15)", x, x * ds);
+      if (e < 16) CHECK(x * ds < 32768.f, "wg_dz_scale(%g): scaled max %g", x, x * ds);
+    }
+  CHECK(wg_dz_scale(0u, false) > 0.f && wg_dz_scale(0u, true) > 0.f, "all-zero dz: finite positive scale");
+  CHECK(w16_scale(0u, false) == 256.f, "all-zero weights: 2^8");
+  // infinity / NaN maxima: a finite scale (the non-finite values themselves propagate)
+  CHECK(wg_dz_scale(0x7f800000u, false) > 0.f && wg_dz_scale(0x7fc00000u, true) > 0.f, "non-finite maximum: finite scale");
+}
+
 int main() {
+  test_scales();
   test_xcd();
   test_wide_offset_guard();
   test_tiles();
