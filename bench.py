@@ -312,7 +312,7 @@ def main():
         import itertools
         from mimo_unet_amd.data import DevicePrefetcher
         host = {k: (v.cpu().pin_memory() if args.host_batches == "pinned" else v.cpu()) for k, v in resident.items()}
-        pf = DevicePrefetcher(itertools.repeat(host), device=torch.device("cuda", dev), depth=2)
+        pf = DevicePrefetcher(itertools.repeat(host), device=torch.device("cuda", dev), depth=int(os.environ.get("MIMO_PREFETCH_DEPTH", "2")))
         return pf, iter(pf)
 
     if args.host_batches:

@@ -1136,9 +1136,7 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
     // 128-pixel tiles / two workgroups per CU: forward only (measured per layer on one box: forward 30->30 at
     // 256x256 169 -> 147 us, 45->30 282 -> 253 us; the data gradient of the same shapes 132 -> 145 us)
     static const bool mf2_on = !(getenv("MIMO_CONV_WS_MF2") && atoi(getenv("MIMO_CONV_WS_MF2")) == 0);
-    // ... and the split16 data gradient of images of at most MIMO_CONV_WS_MF2_DGRAD_MAXPIX padded pixels (experiment, default off)
-    static const int mf2_dgrad_maxpix = getenv("MIMO_CONV_WS_MF2_DGRAD_MAXPIX") ? atoi(getenv("MIMO_CONV_WS_MF2_DGRAD_MAXPIX")) : 0;
-    const bool mf2 = mf2_on && (MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6 || (MODE == 0 && a.Ho * a.Wo <= mf2_dgrad_maxpix));
+    const bool mf2 = mf2_on && (MODE == 1 || MODE == 2 || MODE == 4 || MODE == 6);
     switch (nf) {
       case 4: return launch_ws<4, MODE, 4>(a, rows, stream);
       case 3: return launch_ws<3, MODE, 4>(a, rows, stream);
