@@ -24,11 +24,16 @@ tensors resident in HBM, keeping ``depth`` batches in flight:
   ``Tensor.copy_`` between host tensors woke torch's whole intra-op thread pool per call);
 * **device ring** — ``depth + 1`` sets of device tensors, allocated once per batch
   shape; no allocator traffic per step;
-* **event hand-off** — the consumer's stream waits on the slot's "uploaded" event, and
-  the copy stream waits on the slot's "consumed" event (recorded when the consumer asks
-  for the next batch, i.e. after everything that reads the slot has been enqueued)
-  before the slot is overwritten.  The consuming thread only ever waits for the worker
-  (host side, counted in ``starved``), never for the GPU.
+* **event hand-off, resolved on the worker** — a slot is overwritten only after its
+  "consumed" event (recorded when the consumer asks for the next batch, i.e. after
+  everything that reads the slot has been enqueued) has completed, and is handed over
+  only after its "uploaded" event has: the WORKER waits for both on the host, so neither
+  GPU queue ever holds a wait on the other.  Measured (profiles/r05/data_path.txt §4):
+  with the same two dependencies expressed as stream waits (``MIMO_PREFETCH_HANDOFF=gpu``)
+  a pinned feed costs 0.25-0.3 ms per step at every batch size — 4.85 against 4.58 ms at
+  4 images per GPU — although the copies themselves are the same 27 us SDMA transfers.
+  The consuming thread only ever waits for the worker (counted in ``starved``), never
+  for the GPU directly; through the worker it is held to ``depth`` steps ahead of the GPU.
 
 The layout change NCHW -> NHWC (and the per-subnetwork gather) is not done here: the
 engine's first kernel (`pack_input_kernel`) reads the NCHW batch as uploaded.
@@ -37,6 +42,7 @@ A yielded batch stays valid until the next one is drawn — the contract of a tr
 that uses each batch for one step."""
 from __future__ import annotations
 
+import os
 import queue
 import threading
 from typing import Any, Dict, Iterable, Iterator, Optional
@@ -73,6 +79,10 @@ class DevicePrefetcher:
             raise ValueError("depth must be >= 1")
         self.batches, self.depth = batches, int(depth)
         self.copy_stream = torch.cuda.Stream(self.device)
+        # "host": the worker waits for the slot events itself; "gpu": stream waits (kept for the A/B, see the module text)
+        self.handoff = os.environ.get("MIMO_PREFETCH_HANDOFF", "host")
+        if self.handoff not in ("host", "gpu"):
+            raise ValueError("MIMO_PREFETCH_HANDOFF must be 'host' or 'gpu'")
         self.starved = 0           # times the consumer found no uploaded batch ready and waited for the worker
         self.pageable_uploads = 0  # tensors that came from pageable memory (synchronous copies, on the worker)
 
@@ -89,7 +99,11 @@ class DevicePrefetcher:
                 slot.dev = {k: torch.empty(shape, dtype=dt, device=self.device) for k, shape, dt in spec}
                 slot.spec = spec
             if slot.consumed is not None:
-                self.copy_stream.wait_event(slot.consumed)  # the step that read this slot's device tensors is done
+                # the step that read this slot's device tensors is done
+                if self.handoff == "host":
+                    slot.consumed.synchronize()
+                else:
+                    self.copy_stream.wait_event(slot.consumed)
             for k, v in batch.items():
                 if not torch.is_tensor(v):
                     out[k] = v
@@ -101,6 +115,8 @@ class DevicePrefetcher:
             slot.keep = batch
             slot.uploaded = torch.cuda.Event()
             slot.uploaded.record(self.copy_stream)
+            if self.handoff == "host":
+                slot.uploaded.synchronize()
         return out
 
     def _produce(self, it: Iterator[Dict[str, Any]], free_q: "queue.Queue", ready_q: "queue.Queue") -> None:
@@ -142,7 +158,8 @@ class DevicePrefetcher:
                 if isinstance(item, BaseException):
                     raise item
                 slot, dev_batch = item
-                torch.cuda.current_stream(self.device).wait_event(slot.uploaded)
+                if self.handoff != "host":  # ("host": the worker handed the slot over after the upload had completed)
+                    torch.cuda.current_stream(self.device).wait_event(slot.uploaded)
                 previous = slot
                 yield dev_batch
         finally:
