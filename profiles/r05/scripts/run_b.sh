@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r05_b
 mkdir -p $O
 cd "$R"
-python scripts/r05/data_path_probe.py > $O/data_path_probe.txt 2>&1
+python profiles/r05/scripts/data_path_probe.py > $O/data_path_probe.txt 2>&1
 cat $O/data_path_probe.txt
 MIMO_PARITY_LOG=$O/parity_errors.txt timeout 1800 python -m pytest tests -q -m gpu > $O/pytest.txt 2>&1
 tail -25 $O/pytest.txt

@@ -8,12 +8,12 @@ mkdir -p $O
 cd "$R"
 V=$R/build/variants/libmimo_nodefer.so
 for a in "4 256" "32 256" "3 100" "2 64"; do
-  python scripts/r05/step_hash.py $a >> $O/hash_defer.txt 2>&1
-  MIMO_HIP_LIB=$V python scripts/r05/step_hash.py $a >> $O/hash_nodefer.txt 2>&1
+  python profiles/r05/scripts/step_hash.py $a >> $O/hash_defer.txt 2>&1
+  MIMO_HIP_LIB=$V python profiles/r05/scripts/step_hash.py $a >> $O/hash_nodefer.txt 2>&1
 done
 diff $O/hash_defer.txt $O/hash_nodefer.txt && echo "BIT-IDENTICAL" | tee $O/bitcmp.txt
 cat $O/hash_defer.txt
-python scripts/r05/data_path_probe.py > $O/data_path_probe.txt 2>&1; tail -3 $O/data_path_probe.txt
+python profiles/r05/scripts/data_path_probe.py > $O/data_path_probe.txt 2>&1; tail -3 $O/data_path_probe.txt
 MIMO_PARITY_LOG=$O/parity_errors.txt timeout 1500 python -m pytest tests/test_ops_gpu.py tests/test_network_gpu.py tests/test_data_gpu.py tests/test_configs_gpu.py -q -m gpu -x > $O/pytest.txt 2>&1
 tail -5 $O/pytest.txt
 export MIMO_LAYER_BENCH_ONLY=0,1,2,13,14,15 MIMO_LAYER_BENCH_WGRAD=0 REPS=6

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r05_d
 mkdir -p $O
 cd "$R"
-MIMO_AB_LIB=$R/build/variants/libmimo_nodefer.so python scripts/r05/op_bitcmp.py > $O/op_bitcmp.txt 2>&1
+MIMO_AB_LIB=$R/build/variants/libmimo_nodefer.so python profiles/r05/scripts/op_bitcmp.py > $O/op_bitcmp.txt 2>&1
 cat $O/op_bitcmp.txt
 timeout 600 python -m pytest tests/test_data_gpu.py tests/test_network_gpu.py -q -m gpu -k "data or caller_masks" > $O/pytest.txt 2>&1
 tail -5 $O/pytest.txt

@@ -8,7 +8,7 @@ mkdir -p $O
 cd "$R"
 MIMO_PARITY_LOG=$O/parity_errors.txt timeout 2000 python -m pytest tests -q -m gpu > $O/pytest.txt 2>&1
 tail -15 $O/pytest.txt
-MIMO_AB_LIB=$R/build/variants/libmimo_nodefer.so python scripts/r05/op_bitcmp.py > $O/op_bitcmp.txt 2>&1
+MIMO_AB_LIB=$R/build/variants/libmimo_nodefer.so python profiles/r05/scripts/op_bitcmp.py > $O/op_bitcmp.txt 2>&1
 cat $O/op_bitcmp.txt
 for i in 1 2 3; do
   for v in 3 2; do

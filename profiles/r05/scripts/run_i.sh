@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r05_i
 mkdir -p $O
 cd "$R"
-python scripts/r05/debug_status.py 2>&1 | tail -8 | tee $O/debug_status.txt
+python profiles/r05/scripts/debug_status.py 2>&1 | tail -8 | tee $O/debug_status.txt
 timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_network_gpu.py -q -m gpu -x -k "upsample or golden or odd or bit_identical or fgsm" > $O/pytest.txt 2>&1
 tail -5 $O/pytest.txt
 for i in 1 2 3; do
