@@ -208,6 +208,20 @@ __device__ __forceinline__ void pix_next(PixIter& it, int H, int W) {
   }
 }
 
+__device__ __forceinline__ void pix_prev(PixIter& it, int H, int W) {
+  it.x -= it.dx;
+  it.y -= it.dy;
+  it.n -= it.dn;
+  if (it.x < 0) {
+    it.x += W;
+    --it.y;
+  }
+  if (it.y < 0) {
+    it.y += H;
+    --it.n;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // two-level column reduction
 // ---------------------------------------------------------------------------------------
@@ -1608,6 +1622,9 @@ int split_pairs_launch(const float* src, float* dst, int64_t P, int Cp, hipStrea
 #ifndef MIMO_APPLY_MINWAVES
 #define MIMO_APPLY_MINWAVES 7
 #endif
+#ifndef MIMO_APPLY_REVERSE
+#define MIMO_APPLY_REVERSE 1  // 0: front to back (A/B builds)
+#endif
 #ifndef MIMO_APPLY_ABSMAX
 #define MIMO_APPLY_ABSMAX 1  // 0: A/B build without the max |dz| tracking (the two-MFMA weight gradient then reads garbage)
 #endif
@@ -1655,12 +1672,26 @@ __global__ __launch_bounds__(256, (SRC == GS_PLAIN || SRC == GS_FOLD) ? MIMO_APP
       }
     } else {
       const int P = N * H * W;
+#if MIMO_APPLY_REVERSE
+      // back to front: the statistics pass in front of this one read the same two tensors front to back, so their LAST
+      // part is what the last-level cache still holds
+      if (t.p < P) {
+        const int p_last = t.p + (P - 1 - t.p) / t.pstep * t.pstep;
+        PixIter it = pix_iter(p_last, t.pstep, H, W);
+        for (int p = p_last; p >= 0; p -= t.pstep, pix_prev(it, H, W)) {
+          const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
+          float d0, d1;
+          emit(p, relu_grad4<SRC, TZ, TA>(src, hl, mask, C, p, it, t.q, H, W, v, sc, sh, &d0, &d1), v);
+        }
+      }
+#else
       PixIter it = pix_iter(t.p, t.pstep, H, W);
       for (int p = t.p; p < P; p += t.pstep, pix_next(it, H, W)) {
         const float4 v = ld4(z + (size_t)p * ldz + 4 * t.q);
         float d0, d1;
         emit(p, relu_grad4<SRC, TZ, TA>(src, hl, mask, C, p, it, t.q, H, W, v, sc, sh, &d0, &d1), v);
       }
+#endif
     }
   }
   if (MIMO_APPLY_ABSMAX && absmax) block_absmax_store(absmax, amax);

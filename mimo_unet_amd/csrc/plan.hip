@@ -1298,13 +1298,17 @@ struct mimo_plan {
     else
       MIMO_TRY(wgrad_launch(wg, ws));
     prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), ws);
-    if (async) {
-      MIMO_HIP_CHECK(hipEventRecord(ev_wg[b], wg_stream));
-      wg_pending[b] = true;
-    }
     if (!thin_wg)  // (the plain-FMA kernel's launch reduces its own partials)
       MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
                                    grads + L.off_w, ws, wg.dz_absmax, wg.dz_absmax_n));
+    if (async) {
+      // dz buffer b AND its max |dz| slots are free again — recorded behind the REDUCTION: it reads the slots too (to take the
+      // two-MFMA kernel's scale out again), and the BatchNorm backward of the layer after next overwrites them.  (Until the
+      // end of round 5 the event sat in front of the reduction: a race that showed as a weight gradient off by > 1e-4 of
+      // its scale in one small-geometry test when that test ran alone.)
+      MIMO_HIP_CHECK(hipEventRecord(ev_wg[b], wg_stream));
+      wg_pending[b] = true;
+    }
     return MIMO_OK;
   }
 

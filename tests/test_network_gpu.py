@@ -784,6 +784,46 @@ def test_side_stream_weight_gradients_match(name, monkeypatch):
     assert all(torch.equal(grads[0], g) for g in grads[1:])
 
 
+def test_side_stream_weight_gradients_match_on_a_small_odd_geometry(monkeypatch):
+    """The same on the sequence where a race showed at the end of round 5 (S = 3, fbc = 10, 100 x 100, batch 3, masked loss; two
+    training iterations and an eval-mode backward, the head's gradient source fused): the side stream's weight-gradient
+    REDUCTION read the max |dz| slots of a dz buffer whose release event had been recorded in front of it, while the main
+    stream was already through the BatchNorm backward of the layer after next.  Three repetitions on the side stream, every
+    gradient bit-identical to the same sequence with everything on one stream."""
+    cfg = O.NetConfig(2, 2, 3, 10, encoder_dropout_rate=0.2)
+    st = O.init_state(cfg, 91)
+    g = torch.Generator().manual_seed(92)
+    for k in st:
+        if (".double_conv.1." in k or ".double_conv.4." in k) and k.endswith("weight"):
+            st[k] = torch.randn(st[k].shape, generator=g)
+    image, label = torch.rand(3, 2, 100, 100, generator=g).cuda(), torch.rand(3, 1, 100, 100, generator=g).cuda()
+    mask = (torch.rand(3, 1, 100, 100, generator=g) > 0.3).float().cuda()
+    perms = O.draw_perms(3, 3, generator=g).cuda()
+    monkeypatch.setenv("MIMO_FUSE_BWD_SRC", "3")
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MIMO_WGRAD_STREAM", mode)
+        grads = []
+        for rep in range(3):
+            torch.manual_seed(93)
+            model = build_model(cfg, st, dropout=(0.2, 0.0, 0.0))
+            model.train()
+            for _ in range(2):
+                model.zero_grad()
+                model.training_step_with_perms(image, label, mask, perms)["loss"].backward()
+                grads.append(model.model.flat_gradients().clone())
+            model.eval()
+            x5 = torch.stack([image[perms[s]] for s in range(3)], 1).requires_grad_(True)
+            p1, p2 = model(x5)
+            model.zero_grad()
+            (p1.mean() + p2.mean()).backward()
+            grads.append(model.model.flat_gradients().clone())
+        torch.cuda.synchronize()
+        runs[mode] = grads
+    for i, (a, b) in enumerate(zip(runs["0"], runs["1"])):
+        assert torch.equal(a, b), f"gradient set {i}: max difference {float((a - b).abs().max()):.3e}"
+
+
 def test_inference_path_matches_eval_forward_and_tracks_parameter_changes():
     """Eval mode under torch.no_grad() takes the inference path (BatchNorm + ReLU + Dropout2d multipliers
     in the convolution epilogue, packed weights cached on the parameter version): bit-identical to the
