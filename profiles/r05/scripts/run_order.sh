@@ -1,0 +1,21 @@
+#!/bin/bash
+# order dependence of the GPU suite: every test file alone in a process, then all tests in two shuffled orders
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r05_order
+mkdir -p $O
+cd $R
+for f in tests/test_*gpu*.py; do
+  echo "$f: $(python -m pytest $f -m gpu -q 2>&1 | tail -1)" >> $O/per_file.txt
+done
+python -m pytest tests -m gpu --collect-only -q 2>/dev/null | grep "::" > $O/ids.txt
+for seed in 1 2; do
+  python3 - $O/ids.txt $seed > $O/ids_$seed.txt <<'P'
+import random, sys
+ids = [l.strip() for l in open(sys.argv[1]) if l.strip()]
+random.Random(int(sys.argv[2])).shuffle(ids)
+print("\n".join(ids))
+P
+  python -m pytest $(cat $O/ids_$seed.txt | tr '\n' ' ') -q -p no:cacheprovider 2>&1 | tail -6 > $O/shuffled_$seed.txt
+done
+cat $O/per_file.txt; tail -3 $O/shuffled_1.txt $O/shuffled_2.txt

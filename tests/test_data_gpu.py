@@ -153,16 +153,20 @@ def test_host_fed_loop_runs_ahead_like_the_resident_loop():
 
     host = _host_batches(2, 16, 2, 256, 256, pinned=False)
     resident = [{k: v.cuda() for k, v in b.items()} for b in host]
-    _, t_res = run(itertools.cycle(resident))
+    _, t_res0 = run(itertools.cycle(resident))
     pinned = [{k: v.pin_memory() for k, v in b.items()} for b in host]
     h_deep, t_deep = run(DevicePrefetcher(itertools.cycle(pinned), device="cuda", depth=8))
     h_pin, t_pin = run(DevicePrefetcher(itertools.cycle(pinned), device="cuda", depth=2))
     h_page, t_page = run(DevicePrefetcher(itertools.cycle(host), device="cuda", depth=2))
-    report(f"cfg3 batch 16, 10 steps: resident {t_res * 1e3:.1f} ms; pinned host batches, depth 8: {t_deep * 1e3:.1f} ms (host enqueued "
-           f"in {h_deep * 1e3:.1f} ms); depth 2: pinned {t_pin * 1e3:.1f} ms (host {h_pin * 1e3:.1f} ms), pageable {t_page * 1e3:.1f} ms "
-           f"(host {h_page * 1e3:.1f} ms) - host times at depth 2 include waiting for data")
+    _, t_res1 = run(itertools.cycle(resident))
+    # (the reference is measured in front of and behind the fed loops: 130 ms loops see the clock state the tests before them
+    # left, and this test failed once in a shuffled run of the suite with a single reference in front)
+    t_res = max(t_res0, t_res1)
+    report(f"cfg3 batch 16, 10 steps: resident {t_res0 * 1e3:.1f} / {t_res1 * 1e3:.1f} ms (before / after); pinned host batches, depth 8: "
+           f"{t_deep * 1e3:.1f} ms (host enqueued in {h_deep * 1e3:.1f} ms); depth 2: pinned {t_pin * 1e3:.1f} ms (host {h_pin * 1e3:.1f} ms), "
+           f"pageable {t_page * 1e3:.1f} ms (host {h_page * 1e3:.1f} ms) - host times at depth 2 include waiting for data")
     assert h_deep < 0.5 * t_deep, (h_deep, t_deep)
-    assert max(t_deep, t_pin) < 1.05 * t_res, (t_res, t_deep, t_pin)
+    assert max(t_deep, t_pin) < 1.05 * t_res, (t_res0, t_res1, t_deep, t_pin)
     # (pageable batches - not what the reference's loaders yield - go through the driver's staged copy, whose speed is the
     # host's: 1.01 x and 1.08 x the resident loop on two boxes of the same pool)
-    assert t_page < 1.15 * t_res, (t_res, t_page)
+    assert t_page < 1.15 * t_res, (t_res0, t_res1, t_page)
