@@ -28,7 +28,7 @@ if [ -d $G/r05_b4 ]; then
   cp $G/r05_b4/bench.json $P/b4/bench_cfg3_b4.json
   cp $G/r05_b4/bench_under_rocprof.json $P/b4/bench_cfg3_b4_under_rocprof.json
   cp $G/r05_b4/b4_np_ab.txt $P/b4/wgrad_np_ab.txt
-  for m in pinned pageable; do for b in b32 b4; do cp $G/r05_q/bench_${b}_host_$m.json $P/b4/bench_${b}_host_$m.json; done; done  # (run_q.sh: after the hand-off change)
+  for m in pinned pageable; do for b in b32 b4; do cp $G/r05_b4/bench_${b}_host_$m.json $P/b4/bench_${b}_host_$m.json; done; done
   cp $G/r05_b4/convergence.txt $P/convergence_final.txt
 fi
 if [ -f $G/r05_h/b4_step_serial.txt ]; then cp $G/r05_h/b4_step_serial.txt $P/b4/step_serial_timeline.txt; fi
