@@ -71,6 +71,44 @@ def test_prefetcher_passes_non_tensors_through_and_rejects_cpu():
     assert out["meta"] == "patch-17" and out["image"].is_cuda and float(out["image"].sum()) == 32.0
 
 
+def test_prefetcher_surfaces_loader_errors_survives_an_early_stop_and_can_be_iterated_again():
+    """What a training script does to a loader besides iterating it to the end: an exception raised by the wrapped iterable
+    (a corrupt sample) must come out of the consuming loop, not die in the worker thread; a loop that stops early
+    (`limit_train_batches`, a `break`) must not leave the next epoch hanging; and a second `iter()` — the next epoch —
+    yields the same batches again (every epoch gets its own worker and slots)."""
+    from mimo_unet_amd.data import DevicePrefetcher
+    host = _host_batches(5, 2, 2, 16, 16, pinned=True)
+
+    class Loader:
+        def __init__(self, fail_at=None):
+            self.fail_at = fail_at
+
+        def __len__(self):
+            return len(host)
+
+        def __iter__(self):
+            for i, b in enumerate(host):
+                if i == self.fail_at:
+                    raise RuntimeError("corrupt sample 3")
+                yield b
+
+    pf = DevicePrefetcher(Loader(fail_at=3), device="cuda", depth=2)
+    seen = []
+    with pytest.raises(RuntimeError, match="corrupt sample 3"):
+        for b in pf:
+            seen.append(b["image"].clone())
+    # everything in front of the failure was delivered, in order
+    assert len(seen) == 3 and all(torch.equal(g.cpu(), h["image"]) for g, h in zip(seen, host))
+
+    pf = DevicePrefetcher(Loader(), device="cuda", depth=2)
+    for i, b in enumerate(pf):
+        if i == 1:
+            break  # early stop with uploads in flight
+    for epoch in range(2):  # ... and two full epochs afterwards
+        got = [b["label"].clone() for b in pf]
+        assert len(got) == 5 and all(torch.equal(g.cpu(), h["label"]) for g, h in zip(got, host))
+
+
 def _sleep_cycles_for(ms):
     """cycles argument of torch.cuda._sleep for about `ms` of device time (calibrated on this box)"""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
