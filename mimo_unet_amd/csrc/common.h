@@ -178,7 +178,8 @@ int wgrad_split_has_np2(int cin_p, int cout_p);
 int wgrad_split_fuses_input(int cin_p, int cout_p, int store, int np);
 // split-bf16 variant (wgrad_split.hip): cin_pad / cout_pad must be multiples of its (CI, CO) tile
 void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO);
-int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO, int store = 0);  // store: WgradLaunch::store
+// store: WgradLaunch::store; cus: CUs the launch is sized for (sched::wg_side_cus)
+int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO, int store = 0, int cus = 256);
 int wgrad_split_launch(const WgradLaunch& a, hipStream_t stream);
 int wgrad_pick_splits(int N, int H, int W, int cin_pad, int cout_pad);
 // extra floats the reduction needs behind the splits*9*cin_pad*cout_pad partial slabs

@@ -190,6 +190,7 @@ struct mimo_plan {
   // (Measured and removed in round 3: per-layer dz buffers without back-pressure, 3-4 ping-pong buffers, releasing a
   // weight gradient only after its layer's data gradient — none faster)
   bool wg_async = false;
+  int wg_cus = 256;  // CUs the weight-gradient launches are sized for (sched::wg_side_cus; MIMO_WGRAD_CUS overrides)
   // BatchNorm backward forms the gradient arriving at a pooled tensor / at the head's input itself (GS_POOL / GS_HEAD):
   // fp32 storage, MIMO_FUSE_BWD_SRC=0 switches it off (read per plan)
   bool fuse_bwd_src = false;
@@ -397,7 +398,7 @@ struct mimo_plan {
       L.wg_cout_pad = round_up(L.cout_p, CO);
       // operand storage of this layer's weight gradient (= WgradLaunch::store in convbn_backward: fwd_split below)
       const int wg_store = !mixed ? 0 : (L.cin_p >= 8 ? (f16 ? 2 : 1) : (f16 ? 4 : 3));
-      L.wg_splits = wgrad_split_pick_splits(n, h, w, L.wg_cin_pad, L.wg_cout_pad, CI, CO, wg_store);
+      L.wg_splits = wgrad_split_pick_splits(n, h, w, L.wg_cin_pad, L.wg_cout_pad, CI, CO, wg_store, wg_cus);
     } else {
       L.wg_cin_pad = round_up(L.cin_p, 32);
       L.wg_cout_pad = round_up(L.cout_p, 32);
@@ -598,6 +599,13 @@ struct mimo_plan {
     Ci = cfg.in_channels;
     Co = cfg.out_channels;
     Ci_p = round_up(Ci, 4);
+    {
+      // (a property of the plan, not of the stream mode: MIMO_WGRAD_STREAM=0 and the profiler's serialised pass run the same
+      // launches, so the two modes stay bit-identical)
+      const char* e = getenv("MIMO_WGRAD_CUS");
+      const int v = e ? atoi(e) : 0;
+      wg_cus = (v >= 8 && v <= 256) ? v : sched::wg_side_cus((long)N * H * W);
+    }
     if (S < 1 || f < 1 || N < 1 || Ci < 1 || Co < 2 || (Co & 1) || Co > kMaxHeadOut || f > 256) {
       set_error("unsupported configuration S=%d f=%d N=%d Ci=%d Co=%d", S, f, N, Ci, Co);
       return MIMO_ERR_INVALID;

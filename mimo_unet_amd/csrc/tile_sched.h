@@ -98,7 +98,7 @@ static inline int wg_ws_tr(int CI, bool s16 = false) { return (CI == 32 || s16) 
 static inline int wg_num_tiles(int N, int H, int W, int tr) { return N * cdiv(H, tr) * cdiv(W, kWgTC); }
 // pixel splits (slabs) of a layer's weight gradient: >= 1, <= min(tiles, 1024)
 static inline int wg_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO, bool ws_enabled, int mode,
-                                 bool s16 = false) {
+                                 bool s16 = false, int cus = 256) {
   const int wtiles = (cin_pad / CI) * (cout_pad / CO);
   const bool ws = wg_use_ws(CI, CO, ws_enabled);
   const int tiles = wg_num_tiles(N, H, W, ws ? wg_ws_tr(CI, s16) : 4);
@@ -112,7 +112,7 @@ static inline int wg_pick_splits(int N, int H, int W, int cin_pad, int cout_pad,
   // wave-specialised kernel: one workgroup per CU (128 KB of LDS), all workgroups of a launch do the same work, so
   // time ~ rounds x (pixel tiles per workgroup + fixed cost); the fixed cost (147 KB slab written per workgroup and
   // re-read by the reduction, pipeline fill) is worth about `kFixed` pixel tiles.
-  const int kCUs = 256;
+  const int kCUs = cus;  // CUs the launch may fill (256 = the chip)
   const int kFixed = 16 / wg_ws_tr(CI, s16);
   int best = 1;
   long bestCost = -1;
@@ -123,6 +123,16 @@ static inline int wg_pick_splits(int N, int H, int W, int cin_pad, int cout_pad,
   }
   return best;
 }
+
+// CUs the weight-gradient launches of a plan are sized for (round 5).  They run on a side stream beside the main stream's
+// kernels; both are persistent grids of one workgroup per CU that cannot share a CU (128-140 KB of LDS each), so a
+// weight-gradient launch that fills the chip makes the main stream's next kernel wait for whole workgroups.  At 32 images
+// that costs nothing (every launch is many rounds long); at a few images per GPU — the per-GPU batches of a strong-scaling
+// run — the main stream's kernels are 64-256 workgroups of one or two tiles, and leaving them part of the chip is worth
+// 5 % of the step at 4 images (4.66 -> 4.40 ms with 128 CUs; 160: 4.43, 112: 4.50, 96: 4.54, 64: 4.93), 2 % at 8 and 16
+// (192 CUs: 7.52 -> 7.36, 13.0 -> 12.8 ms; 128: 7.42, 12.85), nothing at 32 (23.90 vs 23.92) — profiles/r05/exp/wgrad_cu_share.txt.
+// pixels = images x height x width of the plan's input.
+static inline int wg_side_cus(long pixels) { return pixels <= 6L * 65536 ? 128 : pixels <= 24L * 65536 ? 192 : 256; }
 
 // ---- power-of-two scales of the fp16 operands (round 5) ---------------------------------------------------------------
 // Float bits in, a power of two out: pure integer work on the exponent field, exact by construction.

@@ -694,9 +694,10 @@ static bool wgrad_ws_enabled() {
 }
 void wgrad_split_tiles(int cin_p, int cout_p, int* CI, int* CO) { sched::wg_tiles(cin_p, cout_p, wgrad_ws_enabled(), CI, CO); }
 static bool wgrad_use_ws(int CI, int CO) { return sched::wg_use_ws(CI, CO, wgrad_ws_enabled()); }
-int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO, int store) {
+int wgrad_split_pick_splits(int N, int H, int W, int cin_pad, int cout_pad, int CI, int CO, int store, int cus) {
   static const int mode = [] { const char* e = getenv("MIMO_WGRAD_SPLIT_MODE"); return e ? atoi(e) : 1; }();
-  return sched::wg_pick_splits(N, H, W, cin_pad, cout_pad, CI, CO, wgrad_ws_enabled(), mode, wgrad_s16(store));
+  return sched::wg_pick_splits(N, H, W, cin_pad, cout_pad, CI, CO, wgrad_ws_enabled(), mode, wgrad_s16(store),
+                               cus >= 8 && cus <= 256 ? cus : 256);
 }
 
 // 1 when this geometry runs on the kernel that has the two-MFMA (fp16) instances: WgradLaunch::np = 2

@@ -134,7 +134,8 @@ static void test_layers() {
           wg_tiles(cin_p, cout_p, ws != 0, &CI, &CO);
           CHECK((CI == 32 || CI == 48 || CI == 64) && (CO == 32 || CO == 48 || CO == 64), "wg tiles %d %d", CI, CO);
           const int cin_pad = rup(cin_p, CI), cout_pad = rup(cout_p, CO);
-          const int s = wg_pick_splits(N, L.h, L.h, cin_pad, cout_pad, CI, CO, ws != 0, mode & 1, s16);
+          for (const int cus : {256, 192, 128}) {  // launches sized for the whole chip or for a share of it (wg_side_cus)
+          const int s = wg_pick_splits(N, L.h, L.h, cin_pad, cout_pad, CI, CO, ws != 0, mode & 1, s16, cus);
           const int tiles = wg_num_tiles(N, L.h, L.h, wg_use_ws(CI, CO, ws != 0) ? wg_ws_tr(CI, s16) : 4);
           CHECK(s >= 1 && s <= 1024 && s <= tiles, "wg splits %d (tiles %d) for %d->%d @%d N %d", s, tiles, L.cin, L.cout, L.h, N);
           // slabs + group-sum levels fit the plan's scratch formula (plan.hip cap_slab: splits + splits / 8 + 2 slabs)
@@ -144,6 +145,7 @@ static void test_layers() {
             extra += n;
           }
           CHECK(extra <= s / 8 + 2, "wg reduce levels %d > %d for %d splits", extra, s / 8 + 2, s);
+          }
         }
     }
 }
@@ -230,7 +232,21 @@ static void test_scales() {
   CHECK(wg_dz_scale(0x7f800000u, false) > 0.f && wg_dz_scale(0x7fc00000u, true) > 0.f, "non-finite maximum: finite scale");
 }
 
+static void test_side_cus() {
+  // the per-GPU batches of cfg3 under 8-, 4-, 2- and 1-way strong scaling (the measurements the rule stands on)
+  CHECK(wg_side_cus(4L * 256 * 256) == 128 && wg_side_cus(8L * 256 * 256) == 192 && wg_side_cus(16L * 256 * 256) == 192 &&
+            wg_side_cus(32L * 256 * 256) == 256,
+        "wg_side_cus at 4 / 8 / 16 / 32 images of 256 x 256");
+  long prev = 0;
+  for (long px = 1; px < (1L << 34); px = px * 3 / 2 + 1) {  // monotone, 8 <= cus <= 256
+    const int c = wg_side_cus(px);
+    CHECK(c >= 8 && c <= 256 && c >= prev, "wg_side_cus(%ld) = %d", px, c);
+    prev = c;
+  }
+}
+
 int main() {
+  test_side_cus();
   test_scales();
   test_xcd();
   test_wide_offset_guard();

@@ -22,7 +22,7 @@ def test_kernels_use_the_tested_header():
     """No private copy of a scheduler is left in the .hip sources."""
     csrc = os.path.join(ROOT, "mimo_unet_amd", "csrc")
     for fn, needles in (("conv_bf16x3.hip", ["using sched::pick_tile_n"]), ("conv3x3.hip", ["sched::pick_tile_n", "sched::conv_cout_pad"]),
-                        ("wgrad_split.hip", ["sched::wg_tiles", "sched::wg_pick_splits"]), ("common.h", ["sched::xcd_virtual_index", "sched::w16_scale", "sched::wg_dz_scale"]),
+                        ("wgrad_split.hip", ["sched::wg_tiles", "sched::wg_pick_splits"]), ("plan.hip", ["sched::wg_side_cus"]), ("common.h", ["sched::xcd_virtual_index", "sched::w16_scale", "sched::wg_dz_scale"]),
                         ("conv_wide.hip", ["sched::wide_config", "sched::wide_grid_x"])):
         text = open(os.path.join(csrc, fn)).read()
         for n in needles:
