@@ -196,7 +196,10 @@ struct mimo_plan {
   bool fuse_bwd_src = false;
   bool fuse_bwd_pool = false, fuse_bwd_head = false;  // (MIMO_FUSE_BWD_SRC=2: pooled tensors only, 3: head only — A/B)
   hipStream_t wg_stream = nullptr;
-  static constexpr int kDzBufs = 2;
+#ifndef MIMO_DZ_BUFS
+#define MIMO_DZ_BUFS 2  // dz buffers (with their max |dz| slots) the side stream's weight gradients may lag behind
+#endif
+  static constexpr int kDzBufs = MIMO_DZ_BUFS;
   static constexpr int wg_bufs = kDzBufs;
   hipEvent_t ev_dz[kDzBufs] = {}, ev_wg[kDzBufs] = {}, ev_join = nullptr;
   bool wg_pending[kDzBufs] = {};
