@@ -607,7 +607,7 @@ struct mimo_plan {
       // launches, so the two modes stay bit-identical)
       const char* e = getenv("MIMO_WGRAD_CUS");
       const int v = e ? atoi(e) : 0;
-      wg_cus = (v >= 8 && v <= 256) ? v : sched::wg_side_cus((long)N * H * W);
+      wg_cus = (v >= 8 && v <= 256) ? v : sched::wg_side_cus((long)N * H * W, S * f);
     }
     if (S < 1 || f < 1 || N < 1 || Ci < 1 || Co < 2 || (Co & 1) || Co > kMaxHeadOut || f > 256) {
       set_error("unsupported configuration S=%d f=%d N=%d Ci=%d Co=%d", S, f, N, Ci, Co);

@@ -131,8 +131,13 @@ static inline int wg_pick_splits(int N, int H, int W, int cin_pad, int cout_pad,
 // run — the main stream's kernels are 64-256 workgroups of one or two tiles, and leaving them part of the chip is worth
 // 5 % of the step at 4 images (4.66 -> 4.40 ms with 128 CUs; 160: 4.43, 112: 4.50, 96: 4.54, 64: 4.93), 2 % at 8 and 16
 // (192 CUs: 7.52 -> 7.36, 13.0 -> 12.8 ms; 128: 7.42, 12.85), nothing at 32 (23.90 vs 23.92) — profiles/r05/exp/wgrad_cu_share.txt.
-// pixels = images x height x width of the plan's input.
-static inline int wg_side_cus(long pixels) { return pixels <= 6L * 65536 ? 128 : pixels <= 24L * 65536 ? 192 : 256; }
+// The size of a plan's launches grows with the pixels of its input AND with the width of the network, so the rule is on
+// work = images x height x width x (subnetworks x filter_base_count), in units of cfg3's (S x fbc = 60) images of 256 x 256:
+// cfg4 (S = 4: twice the width) at 16 images behaves like cfg3 at 32 — 0.5 % slower with 192 CUs, 3 % slower with 128.
+static inline int wg_side_cus(long pixels, int width) {
+  const long work = pixels * (long)width, unit = 65536L * 60;
+  return work <= 6 * unit ? 128 : work <= 24 * unit ? 192 : 256;
+}
 
 // ---- power-of-two scales of the fp16 operands (round 5) ---------------------------------------------------------------
 // Float bits in, a power of two out: pure integer work on the exponent field, exact by construction.

@@ -233,15 +233,18 @@ static void test_scales() {
 }
 
 static void test_side_cus() {
-  // the per-GPU batches of cfg3 under 8-, 4-, 2- and 1-way strong scaling (the measurements the rule stands on)
-  CHECK(wg_side_cus(4L * 256 * 256) == 128 && wg_side_cus(8L * 256 * 256) == 192 && wg_side_cus(16L * 256 * 256) == 192 &&
-            wg_side_cus(32L * 256 * 256) == 256,
-        "wg_side_cus at 4 / 8 / 16 / 32 images of 256 x 256");
-  long prev = 0;
-  for (long px = 1; px < (1L << 34); px = px * 3 / 2 + 1) {  // monotone, 8 <= cus <= 256
-    const int c = wg_side_cus(px);
-    CHECK(c >= 8 && c <= 256 && c >= prev, "wg_side_cus(%ld) = %d", px, c);
-    prev = c;
+  // the per-GPU batches of cfg3 (S x fbc = 60) under 8-, 4-, 2- and 1-way strong scaling, cfg4 (S = 4: 120) at its 16 images per
+  // GPU and cfg2 (2 x 21) at its 64: the measurements the rule stands on (profiles/r05/exp/wgrad_cu_share.txt)
+  CHECK(wg_side_cus(4L * 256 * 256, 60) == 128 && wg_side_cus(8L * 256 * 256, 60) == 192 && wg_side_cus(16L * 256 * 256, 60) == 192 &&
+            wg_side_cus(32L * 256 * 256, 60) == 256 && wg_side_cus(16L * 256 * 256, 120) == 256 && wg_side_cus(64L * 256 * 256, 42) == 256,
+        "wg_side_cus on the measured configurations");
+  for (const int width : {8, 42, 60, 120, 512}) {
+    int prev = 0;
+    for (long px = 1; px < (1L << 34); px = px * 3 / 2 + 1) {  // monotone, 8 <= cus <= 256
+      const int c = wg_side_cus(px, width);
+      CHECK(c >= 8 && c <= 256 && c >= prev, "wg_side_cus(%ld, %d) = %d", px, width, c);
+      prev = c;
+    }
   }
 }
 
