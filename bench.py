@@ -11,8 +11,9 @@ One "step" = what Lightning runs per batch for the reference's `MimoUnetModel`
 (mimo/models/mimo_unet.py:115-144 + backward + Adam): draw the S batch permutations,
 forward (gather fused into the first kernel), Laplace NLL, loss-buffer weighting, backward,
 [gradient all-reduce over RCCL when N>1], fused Adam.  Synthetic inputs resident in HBM: image ~ U[0,1),
-label = `learnable_label(image)` (a smoothed channel mix + uniform noise; SURVEY 8d's U[0,1) labels make the
-NLL's scale head collapse on single pixels after ~100 steps in every arithmetic), the same batch every
+label ~ U[0,1) (`--labels learnable`: a smoothed channel mix of the image + uniform noise — the U[0,1)
+labels make the NLL's scale head collapse on single pixels after ~100 steps of the same batch in every arithmetic, DESIGN 4,
+which a default run never reaches), the same batch every
 step, PyTorch default random init, fp32 storage (MIMO_PRECISION=bf16-mixed | 16-mixed select the 16-bit storage modes — reduced precision, never the
 headline metric).
 
@@ -220,8 +221,11 @@ def main():
     # strong (default) = the config's batch is the GLOBAL batch (cfg3 = 32 global, 4 per GPU at 8 GPUs);
     # weak = the config's batch per GPU (Lightning-DDP's batch_size semantics).  At one GPU the two are the same run.
     ap.add_argument("--scaling", default=os.environ.get("MIMO_BENCH_SCALING", "strong"), choices=["weak", "strong"])
-    ap.add_argument("--labels", default="learnable", choices=["learnable", "uniform"],
-                    help="learnable: label = learnable_label(image); uniform: SURVEY 8d's label ~ U[0,1)")
+    ap.add_argument("--labels", default="uniform", choices=["uniform", "learnable"],
+                    help="uniform (default): SURVEY 8d's label ~ U[0,1); learnable: label = learnable_label(image)")
+    ap.add_argument("--one-regime", action="store_true", help="N > 1: skip the second timed pass in the other scaling regime")
+    ap.add_argument("--no-strict", action="store_true",
+                    help="skip the second timed pass under MIMO_WGRAD_NP=3 (value_strict: the three-MFMA weight gradient)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the instrumented second pass (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # the data path: every step's batch starts in HOST memory and reaches HBM through
@@ -239,8 +243,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus and (world > 1 or "RANK" in os.environ):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the run that was asked for")
     if args.scaling == "strong" and c["batch"] % world:
         raise SystemExit(f"strong scaling: global batch {c['batch']} does not split over {world} ranks")
     B = c["batch"] // world if args.scaling == "strong" else c["batch"]  # per-GPU batch
@@ -266,6 +270,8 @@ def main():
             dist.init_process_group(backend)
         if dist.get_backend() != backend:
             raise SystemExit(f"process group runs on {dist.get_backend()!r}, {backend!r} was requested")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the {backend} process group has {dist.get_world_size()} rank(s)")
         # one GPU per rank under RCCL (ranks may share a device only in the gloo functional check)
         devs = [None] * dist.get_world_size()
         # identity of the physical device: host + PCI address (+ uuid where torch exposes it) — not the device index,
@@ -278,15 +284,33 @@ def main():
         if backend == "nccl" and len(set(devs)) != len(devs):
             raise SystemExit(f"RCCL ranks share a GPU: {devs}")
 
-    torch.manual_seed(1)
-    model = make_model(c).cuda()
-    model.train()
-    if dist is not None:
-        # DDP semantics: every rank starts from rank 0's parameters and buffers (not from a shared seed)
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, 0)
-    opt = model.configure_optimizers()["optimizer"]
-    opt.reduce_scale = 1.0 / world
+    from mimo_unet_amd.ddp import FlatGradientAllReducer
+    precision = os.environ.get("MIMO_PRECISION", "split16")
+
+    class Run:
+        """model + optimiser (+ reducer, + loss scaler) of one timed pass; the plans read the environment when they are
+        created (first step), so a second Run under MIMO_WGRAD_NP=3 gives the strict-arithmetic figure in the same process"""
+
+        def __init__(self):
+            torch.manual_seed(1)
+            self.model = make_model(c).cuda()
+            self.model.train()
+            if dist is not None:
+                # DDP semantics: every rank starts from rank 0's parameters and buffers (not from a shared seed)
+                for t in list(self.model.parameters()) + list(self.model.buffers()):
+                    dist.broadcast(t.data, 0)
+            self.opt = self.model.configure_optimizers()["optimizer"]
+            self.opt.reduce_scale = 1.0 / world
+            self.reducer = FlatGradientAllReducer() if dist is not None else None
+            if self.reducer is not None:
+                self.reducer.always = force_dist  # one-rank functional check: still issue the RCCL all-reduces
+                self.reducer.attach(self.model.model)  # all-reduces start from inside the backward, as gradient ranges become final
+            # "16-mixed" = the reference's production precision: fp16 storage / operands under torch's GradScaler (FlatAdam
+            # unscales, checks for inf / nan and skips on the device)
+            self.scaler = torch.amp.GradScaler("cuda") if precision == "16-mixed" else None
+
+    run = Run()
+    model, opt = run.model, run.opt
     def make_label(image, g):
         if args.labels == "uniform":
             return torch.rand(image.shape[0], 1, c["H"], c["W"], device="cuda", generator=g)
@@ -318,51 +342,38 @@ def main():
     if args.host_batches:
         prefetcher, feed = host_feed(batch)
 
-    from mimo_unet_amd.ddp import FlatGradientAllReducer
-    reducer = FlatGradientAllReducer() if dist is not None else None
-    if reducer is not None:
-        reducer.always = force_dist  # one-rank functional check: still issue the RCCL all-reduces
-        reducer.attach(model.model)  # all-reduces start from inside the backward, as gradient ranges become final
-
     adam_events = []
-    precision = os.environ.get("MIMO_PRECISION", "split16")
-    # "16-mixed" = the reference's production precision: fp16 storage / operands under torch's GradScaler (FlatAdam
-    # unscales, checks for inf / nan and skips on the device)
-    scaler = torch.amp.GradScaler("cuda") if precision == "16-mixed" else None
 
-    def optimizer_step():
-        if scaler is not None:
-            scaler.step(opt)
-            scaler.update()
-        else:
-            opt.step()
-
-    def step(i, time_adam=False):
-        opt.zero_grad()
-        out = model.training_step(batch if feed is None else next(feed), i)
-        (scaler.scale(out["loss"]) if scaler is not None else out["loss"]).backward()
-        if reducer is not None:
-            reducer.finish()  # bucketed sums over RCCL were started from inside backward; FlatAdam scales by 1/world
+    def step(i, time_adam=False, r=None):
+        r = r or run
+        r.opt.zero_grad()
+        out = r.model.training_step(batch if feed is None else next(feed), i)
+        (r.scaler.scale(out["loss"]) if r.scaler is not None else out["loss"]).backward()
+        if r.reducer is not None:
+            r.reducer.finish()  # bucketed sums over RCCL were started from inside backward; FlatAdam scales by 1/world
         if time_adam:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            optimizer_step()
+        if r.scaler is not None:
+            r.scaler.step(r.opt)
+            r.scaler.update()
+        else:
+            r.opt.step()
+        if time_adam:
             e1.record()
             adam_events.append((e0, e1))
-        else:
-            optimizer_step()
         return out["loss"]
 
-    def timed_pass():
+    def timed_pass(r=None):
         """--warmup untimed steps, then EXACTLY --steps steps between barrier + synchronize; max over ranks"""
         for i in range(args.warmup):
-            step(i)
+            step(i, r=r)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            loss = step(i)
+            loss = step(i, r=r)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -375,6 +386,7 @@ def main():
 
     # ---- timed region (the regime of --scaling): no instrumentation ----
     elapsed, final_loss = timed_pass()
+    collectives = list(run.reducer.last_issued) if run.reducer is not None else []
     # host time to ENQUEUE one step on an idle GPU (outside the timed region): the launch path's share of a step
     # (a diagnostic like the second pass below: --profile-steps 0 skips both, so that traces hold exactly warmup + steps)
     host_ms = []
@@ -395,11 +407,25 @@ def main():
         torch.cuda.synchronize()
         prof, tiers, kind_tiers = plan.profile_read(), plan.profile_read_tiers(), plan.profile_read_kind_tiers()
         plan.profile(False)
+    # ---- the same timed pass under the STRICT arithmetic: three bf16-pair MFMAs per product in the weight gradient
+    # (MIMO_WGRAD_NP=3, rounds 1-4; ~1e-5 per product like the forward and the data gradient) instead of the default's two
+    # fp16 MFMAs with the activation as one fp16 value — a second model and plan in this process, same protocol ----
+    strict = None
+    if precision == "split16" and os.environ.get("MIMO_WGRAD_NP") is None and not args.no_strict:
+        os.environ["MIMO_WGRAD_NP"] = "3"  # read when the plan is created (the run's first step)
+        try:
+            r3 = Run()
+            strict_elapsed, _ = timed_pass(r3)
+        finally:
+            del os.environ["MIMO_WGRAD_NP"]
+        strict = (world * B * args.steps / strict_elapsed, strict_elapsed / args.steps * 1e3)
+        del r3
+        torch.cuda.empty_cache()
     # ---- N > 1: the OTHER regime too, from a second timed pass (SURVEY 8d/e contract cfg3 as 32 GLOBAL = strong;
     # Lightning DDP semantics = the batch per device = weak), so that one line carries both, labelled ----
     other = "strong" if args.scaling == "weak" else "weak"
     other_elapsed = None
-    if world > 1 and not (other == "strong" and c["batch"] % world):
+    if world > 1 and not args.one_regime and not (other == "strong" and c["batch"] % world):
         batch = make_batch(other)
         if args.host_batches:
             prefetcher, feed = host_feed(batch)
@@ -433,6 +459,10 @@ def main():
         "metric": "train images/sec at 256x256, S=2, fbc=30" if args.config == "cfg3" else f"train images/sec ({args.config})",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        # the same timed pass with the weight gradient on three bf16-pair MFMAs per product (fp32-class like the rest of the
+        # step; MIMO_WGRAD_NP=3) — the fence around the default's two-MFMA weight gradient
+        "value_strict": None if strict is None else round(strict[0], 2),
+        "ms_per_step_strict": None if strict is None else round(strict[1], 3),
         "dtype": {"fp32": "f32", "split16": "f32 (split into 16-bit hi/lo pairs on the MFMA; weight gradient: activation as one fp16 value)",
                   "bf16": "bf16 MFMA operands, f32 accumulate/storage (reduced precision)",
                   "bf16-mixed": "bf16 storage + MFMA operands, f32 accumulate / master weights / statistics (reduced precision)",
@@ -447,6 +477,11 @@ def main():
                    "world_size": world, "backend": None if dist is None else backend,
                    # ranks that really ran RCCL (None under the gloo functional check and at one rank)
                    "rccl_ranks": dist.get_world_size() if dist is not None and backend == "nccl" else None,
+                   # the gradient exchange of one step of the timed regime: (begin, end) float ranges of the flat buffer,
+                   # in the order the backward issued them
+                   "ddp_algorithm": None if run.reducer is None else run.reducer.algorithm,
+                   "collectives_per_step": None if run.reducer is None else len(collectives),
+                   "collective_mbytes": None if run.reducer is None else [round(4e-6 * (e - b), 2) for b, e in collectives],
                    "rank_devices": None if dist is None else devs,
                    # both data-parallel regimes, each from its own timed pass of --steps steps (value = the --scaling one)
                    "weak_images_per_s": round(regime["weak"][0], 2) if "weak" in regime else None,

@@ -204,11 +204,13 @@ struct PackJob {
   int kind, cout, cin, rows_pad, cols, transposed, total, bias_n;
   int pair;  // kind 1 / 2: tap-paired image of the last chunk (conv3x3_pair_tail)
   int map_rows;  // kind 3 / 4: entries of row_map (rows_pad may exceed it)
-  unsigned* wmax;  // fp16 kinds (1, 3, 5): max |w| of the layer, float bits, monotone (wabsmax_jobs_launch); image scale = w16_scale
+  unsigned* wmax;  // fp16 kinds (1, 3, 5): max |w| of the layer at this pack, float bits (wabsmax_jobs_launch); image scale = w16_scale
 };
 int pack_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream);
-// max |w| of every job with a wmax word (run in front of pack_jobs_launch; the words only ever grow)
-int wabsmax_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream);
+// max |w| of every job with a wmax word (run in front of pack_jobs_launch, on words the caller has zeroed: the maximum of
+// THIS pack).  status != nullptr: bit 0 (kStatusFwdStats) is OR-ed in when a maximum is not finite
+int wabsmax_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream,
+                        int* status = nullptr);
 
 // weight packing: torch OIHW -> [9][rows_pad][cols] (see conv3x3.hip)
 int pack_weights_launch(const float* w, float* dst, int cout, int cin, int rows_pad, int cols,

@@ -1324,7 +1324,7 @@ __global__ void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* 
 
 // max |w| of each job's weight tensor into its wmax word (jobs without one: nothing).  A workgroup whose maximum stays below
 // 64 issues no atomic (the scale only changes from 128 up, w16_scale): for ordinary weights this is one read of the parameters.
-__global__ void wabsmax_jobs_kernel(const PackJob* __restrict__ jobs, const float* __restrict__ params) {
+__global__ void wabsmax_jobs_kernel(const PackJob* __restrict__ jobs, const float* __restrict__ params, int* __restrict__ status) {
   const PackJob j = jobs[blockIdx.y];
   if (!j.wmax) return;
   const float4* w4 = reinterpret_cast<const float4*>(params + j.w_off);  // (tensor offsets are multiples of 4 floats)
@@ -1342,14 +1342,16 @@ __global__ void wabsmax_jobs_kernel(const PackJob* __restrict__ jobs, const floa
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    // (fmaxf drops a NaN operand: an infinite or NaN weight shows as a maximum that is not an ordinary number)
+    if (status && !(m <= 3.0e38f)) atomicOr(status, 1);
     if (m >= 64.f) atomicMax(j.wmax, __float_as_uint(m));  // (non-negative floats order like their bit patterns)
   }
 }
 
-int wabsmax_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream) {
+int wabsmax_jobs_launch(const PackJob* jobs_dev, int njobs, int max_total, const float* params, hipStream_t stream, int* status) {
   if (njobs <= 0) return MIMO_OK;
   const int gx = max(1, min(ceil_div(max_total / 9, 256 * 8), 128));
-  hipLaunchKernelGGL(wabsmax_jobs_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev, params);
+  hipLaunchKernelGGL(wabsmax_jobs_kernel, dim3(gx, njobs), dim3(256), 0, stream, jobs_dev, params, status);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

@@ -107,6 +107,9 @@ struct Dropout2dSite {
 int dropout2d_masks_launch(const Dropout2dSite* sites_dev, int nsites, int max_count, uint64_t active, uint64_t seed,
                            uint64_t offset, hipStream_t st);
 
+// test hook: one idle wave for `us` microseconds on `st` (MIMO_DEBUG_WGRAD_DELAY_US)
+int debug_delay_launch(int us, hipStream_t st);
+
 // ---- BatchNorm + ReLU backward ------------------------------------------------------------
 // dy = (gradient arriving at the activation) * mask * [z*scale+shift > 0] is evaluated on the fly by both passes (never
 // stored).  Where that gradient comes from:

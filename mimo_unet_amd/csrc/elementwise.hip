@@ -1013,6 +1013,26 @@ __device__ __forceinline__ float4 philox_keep4(unsigned int i0, unsigned int i1,
                      (r.z >> 8) * k >= p ? inv_keep : 0.f, (r.w >> 8) * k >= p ? inv_keep : 0.f);
 }
 
+// One wave that does nothing for `us` microseconds (s_memrealtime: the constant 100 MHz counter).  Test hook only
+// (MIMO_DEBUG_WGRAD_DELAY_US, plan.hip): delays the side stream in front of every weight gradient so that the stream
+// protocol's hazards — a buffer released before its last reader has run — show as wrong bits instead of staying hidden
+// behind favourable timing.
+__global__ void debug_delay_kernel(int us, int* __restrict__ sink) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t ticks = (uint64_t)us * 100u;
+  int n = 0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    ++n;
+  }
+  if (sink && n < 0) *sink = n;  // never taken: keeps the loop
+}
+int debug_delay_launch(int us, hipStream_t st) {
+  hipLaunchKernelGGL(debug_delay_kernel, dim3(1), dim3(64), 0, st, us, (int*)nullptr);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
 // Dropout2d multipliers [N][C] of every active site in one launch (blockIdx.y = site, bit `site` of `active`)
 __global__ void dropout2d_masks_kernel(const Dropout2dSite* __restrict__ sites, uint64_t active, uint64_t seed, uint64_t offset) {
   const int site = blockIdx.y;

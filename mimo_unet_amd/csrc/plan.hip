@@ -88,7 +88,7 @@ struct ConvBN {
   float *wf = nullptr, *wd = nullptr, *bias_p = nullptr;
   void *wf16 = nullptr, *wd16 = nullptr;  // split-bf16 packed weights (MIMO_PREC_SPLIT16)
   bool fwd_split = false, dg_split = false, wg_split = false;
-  unsigned* wmax = nullptr;  // fp16 forward weight image: max |w| of the layer, float bits (w16_scale: the image's power-of-two scale)
+  unsigned* wmax = nullptr;  // fp16 forward weight image: max |w| of the layer AT ITS LAST PACK, float bits (w16_scale: the image's power-of-two scale)
   bool wg_np2 = false;  // the weight gradient runs two fp16 MFMAs per product (wgrad_split.hip NP == 2)
   bool thin = false;  // image convolution (<= 4 input channels) on the plain-FMA kernels of conv_thin.hip
   int fwd_wide = 0, dg_wide = 0;  // != 0: the launch runs on conv_wide.hip, value = packed weight rows (conv3x3_wide_rows)
@@ -191,6 +191,9 @@ struct mimo_plan {
   // weight gradient only after its layer's data gradient — none faster)
   bool wg_async = false;
   int wg_cus = 256;  // CUs the weight-gradient launches are sized for (sched::wg_side_cus; MIMO_WGRAD_CUS overrides)
+  // test hook (MIMO_DEBUG_WGRAD_DELAY_US, read per plan): an idle kernel of that many microseconds in front of every weight
+  // gradient, on the stream it runs on — the consumer of dz and its max |dz| slots arrives late (tests/test_streams_gpu.py)
+  int wg_delay_us = 0;
   // BatchNorm backward forms the gradient arriving at a pooled tensor / at the head's input itself (GS_POOL / GS_HEAD):
   // fp32 storage, MIMO_FUSE_BWD_SRC=0 switches it off (read per plan)
   bool fuse_bwd_src = false;
@@ -288,9 +291,44 @@ struct mimo_plan {
   hipStream_t cap_stream = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   uint64_t graph_key = 0;
+  // hipGraph replay of the TRAINING step (round 6, MIMO_TRAIN_GRAPH; mimo_unet.py:115-144 at its per-GPU shard is ~290
+  // launches of which ~200 run < 20 us): the training forward is one graph, the backward one graph (mimo_backward) or one
+  // per stage (mimo_backward_stage: the data-parallel caller starts a stage's all-reduce between two graphs).  Captured
+  // kernels only see plan-owned memory: x / perm / Dropout2d multipliers are staged in front of the forward graph, label /
+  // mask / perm by mimo_loss_forward, dloss in front of the first backward graph, the logits leave through g_out.  A call
+  // shape (key) is captured the SECOND time it is seen — one-off shapes stay eager, and every kernel has run eagerly once
+  // before it is captured.  The side stream's weight gradients are a fork / join inside each backward graph.
+  bool train_graph = false;
+  hipGraphExec_t tg_fwd = nullptr;
+  uint64_t tg_fwd_key = 0, tg_fwd_seen = 0;
+  static constexpr int kBwdGraphs = 9;  // [0, 8): the single stages; [8]: the whole backward
+  hipGraphExec_t tg_bwd[kBwdGraphs] = {};
+  uint64_t tg_bwd_key = 0, tg_bwd_seen = 0;
+  bool tg_bwd_live = false;    // the backward in progress replays graphs (decided at its stage 0)
+  // captures this plan may still make: a caller that keeps alternating call shapes on one plan would otherwise re-capture
+  // (milliseconds of host time) every other step
+  static constexpr int kMaxTrainCaptures = 24;
+  int tg_captures = 0;
+  bool fwd_graphed = false;    // the last forward was a training-graph replay: logits in g_out, masks staged
+  bool loss_staged = false;    // ... and mimo_loss_forward staged label / mask / perm
+  int64_t last_x_rows = 0;     // rows of the last forward's x (= rows of the label / mask tensors of that batch)
+  const int64_t* last_perm_arg = nullptr;  // the caller's perm tensor of the last graphed forward (staged in g_perm)
+  float *g_label = nullptr, *g_lmask = nullptr, *g_dloss = nullptr;
+  int64_t* g_lperm = nullptr;
+  void drop_train_graphs() {
+    if (tg_fwd) (void)hipGraphExecDestroy(tg_fwd);
+    tg_fwd = nullptr;
+    tg_fwd_key = tg_fwd_seen = 0;
+    for (auto& e : tg_bwd) {
+      if (e) (void)hipGraphExecDestroy(e);
+      e = nullptr;
+    }
+    tg_bwd_key = tg_bwd_seen = 0;
+  }
   void drop_graphs() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     graph_exec = nullptr;
+    drop_train_graphs();
   }
   float *g_x = nullptr, *g_out = nullptr;
   int64_t* g_perm = nullptr;
@@ -309,6 +347,11 @@ struct mimo_plan {
 
   bool capturing = false;
 
+  // max |w| words of the fp16 forward weight images (ConvBN::wmax), one array: zeroed and re-taken by every pack, so that a
+  // transient huge weight (a diverged step followed by load_state_dict) does not leave a layer's image at a tiny scale
+  static constexpr int kMaxWmaxWords = 128;
+  unsigned* wmax_pool = nullptr;
+  int wmax_used = 0;
   // weight repack job tables (device): [0, n_fwd_jobs) forward packs (+ bias copies), then the data-gradient packs
   PackJob* pack_jobs = nullptr;
   int n_fwd_jobs = 0, n_all_jobs = 0, pack_max_total = 0;
@@ -429,12 +472,24 @@ struct mimo_plan {
       if (L.thin && train_bufs) cap_slab = std::max(cap_slab, wgrad_thin_scratch(Cin, L.cout_p));
     }
     if (L.wg_split && !L.dg_split) any_mixed_dz = true;
-    L.wg_np2 = cfg.precision == MIMO_PREC_SPLIT16 && L.wg_split && train_bufs && wgrad_split_has_np2(L.cin_p, L.cout_p);
+    // two fp16 MFMAs per product: not for the image convolution (raw inputs need not fit fp16: its forward runs on the fp32
+    // kernels), and only while the launch that writes dz has a max |dz| slot for each of its workgroups
+    // (<= 2048 x ceil(Cp / 1024); wider layers keep the three-MFMA arithmetic)
+    L.wg_np2 = cfg.precision == MIMO_PREC_SPLIT16 && L.wg_split && train_bufs && L.fwd_split && wgrad_split_has_np2(L.cin_p, L.cout_p) &&
+               2048 * ceil_div(L.cout_p / 4, 256) <= kDzMaxSlots;
     if (cfg.precision == MIMO_PREC_SPLIT16 || mixed) {  // decomposition per layer and direction (sched::wide_config)
       if (L.fwd_split) L.fwd_wide = conv3x3_wide_rows(fwd_mode(), n, L.cin_p, L.cout_p, h, w);
       if (L.dg_split) L.dg_wide = conv3x3_wide_rows(dgrad_mode(), n, L.cout_p, L.cin_p, h + 2, w + 2);
     }
-    if (L.fwd_split && (cfg.precision == MIMO_PREC_SPLIT16 || cfg.precision == MIMO_PREC_FP16_MIXED)) MIMO_TRY(dalloc(&L.wmax, 1));
+    if (L.fwd_split && (cfg.precision == MIMO_PREC_SPLIT16 || cfg.precision == MIMO_PREC_FP16_MIXED)) {
+      // one array for all layers' words: every pack zeroes it in one memset and takes the maxima afresh (pack_all)
+      if (!wmax_pool) MIMO_TRY(dalloc(&wmax_pool, kMaxWmaxWords));
+      if (wmax_used >= kMaxWmaxWords) {
+        set_error("too many convolution layers (%d) for the fp16 weight-scale words", wmax_used + 1);
+        return MIMO_ERR_INVALID;
+      }
+      L.wmax = wmax_pool + wmax_used++;
+    }
     if (L.fwd_split) {
       uint16_t* q = nullptr;
       MIMO_TRY(dalloc(&q, L.fwd_wide ? conv3x3_wide_weight_elems(L.cin_p, L.fwd_wide)
@@ -608,6 +663,8 @@ struct mimo_plan {
       const char* e = getenv("MIMO_WGRAD_CUS");
       const int v = e ? atoi(e) : 0;
       wg_cus = (v >= 8 && v <= 256) ? v : sched::wg_side_cus((long)N * H * W, S * f);
+      const char* d = getenv("MIMO_DEBUG_WGRAD_DELAY_US");
+      wg_delay_us = d ? std::max(0, std::min(atoi(d), 5000)) : 0;
     }
     if (S < 1 || f < 1 || N < 1 || Ci < 1 || Co < 2 || (Co & 1) || Co > kMaxHeadOut || f > 256) {
       set_error("unsupported configuration S=%d f=%d N=%d Ci=%d Co=%d", S, f, N, Ci, Co);
@@ -839,6 +896,17 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&g_x, (size_t)N * S * Ci * H * W));
     MIMO_TRY(dalloc(&g_out, (size_t)N * S * Co * H * W));
     MIMO_TRY(dalloc(&g_perm, (size_t)S * N));
+    {
+      // training-step graphs: on by default (MIMO_TRAIN_GRAPH=0: every training launch goes out eagerly)
+      const char* te = getenv("MIMO_TRAIN_GRAPH");
+      train_graph = graph_enabled && !cfg.inference_only && !(te && atoi(te) == 0);
+      if (train_graph) {
+        MIMO_TRY(dalloc(&g_label, (size_t)N * (Co / 2) * H * W));
+        MIMO_TRY(dalloc(&g_lmask, (size_t)N * H * W));
+        MIMO_TRY(dalloc(&g_lperm, (size_t)S * N));
+        MIMO_TRY(dalloc(&g_dloss, (size_t)S));
+      }
+    }
     g_masks.resize(dcs.size());
     g_mask_ptrs.assign(dcs.size(), nullptr);
     for (size_t i = 0; i < dcs.size(); ++i) MIMO_TRY(dalloc(&g_masks[i], (size_t)N * dcs[i]->c2.Cout));
@@ -866,8 +934,10 @@ struct mimo_plan {
   // one launch over the job table
   int pack_all(bool with_dgrad, hipStream_t st) {
     // (fp16 forward images: the layers' max |w| first — the scale of an image follows it from |w| >= 128 up, w16_scale)
-    if (cfg.precision == MIMO_PREC_SPLIT16 || cfg.precision == MIMO_PREC_FP16_MIXED)
-      MIMO_TRY(wabsmax_jobs_launch(pack_jobs, n_fwd_jobs, pack_max_total, params, st));
+    if ((cfg.precision == MIMO_PREC_SPLIT16 || cfg.precision == MIMO_PREC_FP16_MIXED) && wmax_used > 0) {
+      MIMO_HIP_CHECK(hipMemsetAsync(wmax_pool, 0, (size_t)wmax_used * sizeof(unsigned), st));
+      MIMO_TRY(wabsmax_jobs_launch(pack_jobs, n_fwd_jobs, pack_max_total, params, st, d_status));
+    }
     return pack_jobs_launch(pack_jobs, with_dgrad ? n_all_jobs : n_fwd_jobs, pack_max_total, params, st);
   }
 
@@ -964,9 +1034,14 @@ struct mimo_plan {
     dc->out.z_shift = dc->c2.shift;
   }
 
+  // the readers of this block's output go through z in this call (Act::z_live); dc->mask must be this call's
+  bool z_live_rule(const DoubleConv* dc, bool training, bool elem_mask_on_output) const {
+    return dc->c2.act_elided && dc->out.z && training && !fwd_no_grad && !dc->mask && !elem_mask_on_output;
+  }
+
   int dc_forward(DoubleConv* dc, bool training, hipStream_t st, bool elem_mask_on_output = false) {
     const int h = dc->c1.H, w = dc->c1.W;
-    dc->out.z_live = dc->c2.act_elided && dc->out.z && training && !fwd_no_grad && !dc->mask && !elem_mask_on_output;
+    dc->out.z_live = z_live_rule(dc, training, elem_mask_on_output);
     const int blk = prof_begin(kProfTierBase + 2 * tier_of(h), st);
     if (dc->kind == IN_POOL) {
       Act* s = dc->src0;
@@ -1004,6 +1079,7 @@ struct mimo_plan {
     }
     // ---- in-engine dropout: draw the Dropout2d multipliers of the flagged sites, note the element-wise ones ----
     mimo_forward_args a2 = *args;
+    const int64_t* const orig_perm = args->perm;
     {
       const int ndc = (int)dcs.size();
       uint64_t active = 0;
@@ -1042,15 +1118,27 @@ struct mimo_plan {
     const bool x5 = args->stride_s == img && args->stride_n == (int64_t)S * img;
     const bool x4 = args->stride_s == 0 && args->stride_n == img;
     const int64_t rows = args->x_rows > 0 ? args->x_rows : N;
-    if (!graph_enabled || training_call || prof_on || !(x5 || x4) || args->elem_masks || need_derive || rows > N) {
+    last_x_rows = rows;
+    last_perm_arg = nullptr;
+    fwd_graphed = loss_staged = false;
+    // eval mode replays a graph while the packed weights stand (need_derive: the repack is not part of that graph); a
+    // training forward always repacks — inside its graph
+    const bool graphable = graph_enabled && !prof_on && (x5 || x4) && !args->elem_masks && rows <= N &&
+                           (training_call ? (train_graph && tg_captures < kMaxTrainCaptures) : !need_derive);
+    uint64_t key = 1 | (x5 ? 2 : 0) | (args->perm ? 4 : 0) | (fwd_no_grad ? 8 : 0) | (training_call ? 16 : 0);
+    for (size_t i = 0; i < dcs.size(); ++i)
+      if (args->drop_masks && args->drop_masks[i]) key |= 1ull << (8 + i);
+    bool eager = !graphable;
+    if (graphable && training_call && !(tg_fwd && key == tg_fwd_key) && key != tg_fwd_seen) {
+      tg_fwd_seen = key;  // first sighting of this call shape: eager (captured when it comes again)
+      eager = true;
+    }
+    if (eager) {
       const int rc = forward_impl(args, st);
       derived_version = rc == MIMO_OK ? version_after : -1;
       return rc;
     }
     // ---- stage the caller's tensors, (re)capture if the call shape changed, replay ----
-    uint64_t key = 1 | (x5 ? 2 : 0) | (args->perm ? 4 : 0) | (fwd_no_grad ? 8 : 0) | (training_call ? 16 : 0);
-    for (size_t i = 0; i < dcs.size(); ++i)
-      if (args->drop_masks && args->drop_masks[i]) key |= 1ull << (8 + i);
     MIMO_HIP_CHECK(hipMemcpyAsync(g_x, args->x, (size_t)rows * (x5 ? S : 1) * img * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (args->perm)
       MIMO_HIP_CHECK(hipMemcpyAsync(g_perm, args->perm, (size_t)S * N * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
@@ -1061,8 +1149,8 @@ struct mimo_plan {
         MIMO_HIP_CHECK(hipMemcpyAsync(g_masks[i], args->drop_masks[i], (size_t)N * dcs[i]->c2.Cout * sizeof(float),
                                       hipMemcpyDeviceToDevice, st));
     }
-    hipGraphExec_t* exec = &graph_exec;
-    uint64_t* ekey = &graph_key;
+    hipGraphExec_t* exec = training_call ? &tg_fwd : &graph_exec;
+    uint64_t* ekey = training_call ? &tg_fwd_key : &graph_key;
     if (!*exec || key != *ekey) {
       if (*exec) {
         (void)hipGraphExecDestroy(*exec);
@@ -1075,15 +1163,29 @@ struct mimo_plan {
       ga.out = g_out;
       MIMO_TRY(capture([&](hipStream_t cs) { return forward_impl(&ga, cs); }, exec));
       *ekey = key;
+      if (training_call) ++tg_captures;
     }
     elem_masks.clear();
     MIMO_HIP_CHECK(hipGraphLaunch(*exec, st));
     MIMO_HIP_CHECK(hipMemcpyAsync(args->out, g_out, (size_t)N * S * Co * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
-    for (size_t i = 0; i < dcs.size(); ++i) {
-      dcs[i]->mask = args->drop_masks ? args->drop_masks[i] : nullptr;
-      dcs[i]->out.z_live = false;  // (only eval-mode forwards replay a graph: every activated tensor was written)
+    if (training_call) {
+      // the per-call state forward_impl / dc_forward leave behind for the loss and the backward, on the STAGED tensors (a
+      // backward graph must not see the caller's pointers): masks, which activated tensors were elided, the logits
+      elem_masks.assign(1 + S, nullptr);
+      for (size_t i = 0; i < dcs.size(); ++i) {
+        dcs[i]->mask = g_mask_ptrs[i];
+        dcs[i]->out.z_live = z_live_rule(dcs[i].get(), true, false);
+      }
+      out = g_out;
+      fwd_graphed = true;
+      last_perm_arg = orig_perm;
+    } else {
+      for (size_t i = 0; i < dcs.size(); ++i) {
+        dcs[i]->mask = args->drop_masks ? args->drop_masks[i] : nullptr;
+        dcs[i]->out.z_live = false;  // (an eval-mode forward writes every activated tensor)
+      }
+      out = args->out;
     }
-    out = args->out;
     fwd_done = true;
     fwd_training = training_call;
     had_perm = args->perm != nullptr;
@@ -1181,6 +1283,24 @@ struct mimo_plan {
     if (!label_ || !loss_out) {
       set_error("mimo_loss_forward: null argument");
       return MIMO_ERR_INVALID;
+    }
+    loss_staged = false;
+    if (fwd_graphed && train_graph && last_x_rows >= 1 && last_x_rows <= N) {
+      // a backward graph reads label / mask / perm: plan-owned copies (the batch's tensors have last_x_rows rows)
+      const size_t hw = (size_t)H * W;
+      MIMO_HIP_CHECK(hipMemcpyAsync(g_label, label_, (size_t)last_x_rows * (Co / 2) * hw * sizeof(float), hipMemcpyDeviceToDevice, st));
+      label_ = g_label;
+      if (mask_) {
+        MIMO_HIP_CHECK(hipMemcpyAsync(g_lmask, mask_, (size_t)last_x_rows * hw * sizeof(float), hipMemcpyDeviceToDevice, st));
+        mask_ = g_lmask;
+      }
+      if (perm_ && perm_ == last_perm_arg) {
+        perm_ = g_perm;  // the forward staged this very tensor
+      } else if (perm_) {
+        MIMO_HIP_CHECK(hipMemcpyAsync(g_lperm, perm_, (size_t)S * N * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+        perm_ = g_lperm;
+      }
+      loss_staged = true;
     }
     int blocks = 0;
     MIMO_TRY(loss_fwd_launch(out, label_, mask_, perm_, N, S, Co, H * W, cfg.loss_kind, cfg.eps_min, cfg.eps_max,
@@ -1301,6 +1421,7 @@ struct mimo_plan {
     }
     // 16-bit storage: activations and dz plain NHWC 16-bit; the image convolution's input stays fp32
     wg.store = !mixed ? 0 : (L.fwd_split ? (f16 ? 2 : 1) : (f16 ? 4 : 3));
+    if (wg_delay_us > 0) MIMO_TRY(debug_delay_launch(wg_delay_us, ws));  // test hook: a late consumer
     pr = prof_begin(MIMO_PROF_CONV_WGRAD, ws);
     if (thin_wg)
       MIMO_TRY(wgrad_thin_launch(L.in, L.ld_in, dz, L.cout_p, L.N, L.H, L.W, L.Cin, L.Cout, L.cout_p, s_wslab, grads + L.off_w, ws));
@@ -1442,6 +1563,60 @@ struct mimo_plan {
     }
     if (stage_first != 0 && stage_first != bwd_next_stage) {
       set_error("mimo_backward: stage %d requested, stage %d is next", stage_first, bwd_next_stage);
+      return MIMO_ERR_STATE;
+    }
+    const bool whole = stage_first == 0 && stage_last == kBwdStages - 1;
+    if (stage_first == 0) {
+      // ---- training-step graphs: decide for this backward, stage dloss, capture on the second sighting of the shape ----
+      tg_bwd_live = false;
+      const bool single = stage_first == stage_last;
+      if (train_graph && fwd_graphed && loss_staged && fwd_training && !prof_on && !dout && !dx && dloss && (whole || single) &&
+          tg_captures < kMaxTrainCaptures) {
+        const uint64_t key = (tg_fwd_key << 3) | (lmask ? 4 : 0) | (lperm ? 2 : 0) | (whole ? 1 : 0);
+        bool ready = tg_bwd_key == key && (whole ? tg_bwd[kBwdStages] != nullptr : tg_bwd[0] != nullptr);
+        if (!ready && tg_bwd_seen == key) {
+          for (auto& e : tg_bwd) {
+            if (e) (void)hipGraphExecDestroy(e);
+            e = nullptr;
+          }
+          tg_bwd_key = 0;
+          // (a capture executes nothing: the stages can be captured one after the other, each on the host state — gradient
+          // routing of the activation tensors — the stage before it left)
+          if (whole) {
+            MIMO_TRY(capture([&](hipStream_t cs) {
+              dz_idx = 0;
+              for (int stage = 0; stage < kBwdStages; ++stage) MIMO_TRY(backward_stage(stage, nullptr, g_dloss, nullptr, cs));
+              return wg_join(cs);
+            }, &tg_bwd[kBwdStages]));
+          } else {
+            for (int stage = 0; stage < kBwdStages; ++stage)
+              MIMO_TRY(capture([&](hipStream_t cs) {
+                dz_idx = 0;
+                MIMO_TRY(backward_stage(stage, nullptr, g_dloss, nullptr, cs));
+                return wg_join(cs);
+              }, &tg_bwd[stage]));
+          }
+          tg_bwd_key = key;
+          ++tg_captures;
+          ready = true;
+        }
+        tg_bwd_seen = key;
+        tg_bwd_live = ready;
+        if (ready) MIMO_HIP_CHECK(hipMemcpyAsync(g_dloss, dloss, (size_t)S * sizeof(float), hipMemcpyDeviceToDevice, st));
+      }
+    }
+    if (tg_bwd_live && !dout && !dx && (whole || stage_first == stage_last)) {
+      hipGraphExec_t e = whole ? tg_bwd[kBwdStages] : tg_bwd[stage_first];
+      if (!e) {
+        set_error("mimo_backward: no graph for stage range %d..%d of the backward in progress", stage_first, stage_last);
+        return MIMO_ERR_STATE;
+      }
+      MIMO_HIP_CHECK(hipGraphLaunch(e, st));
+      bwd_next_stage = stage_last + 1 < kBwdStages ? stage_last + 1 : 0;
+      return MIMO_OK;  // (every backward graph ends with the join of the side stream)
+    }
+    if (tg_bwd_live) {
+      set_error("mimo_backward: stage %d..%d differs from what stage 0 of this backward was called with", stage_first, stage_last);
       return MIMO_ERR_STATE;
     }
     for (int stage = stage_first; stage <= stage_last; ++stage) MIMO_TRY(backward_stage(stage, dout, dloss, dx, st));

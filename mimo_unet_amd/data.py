@@ -23,7 +23,13 @@ tensors resident in HBM, keeping ``depth`` batches in flight:
   a hand-rolled pinned staging ring filled with ``memmove`` reached 1-3 GB/s there, and
   ``Tensor.copy_`` between host tensors woke torch's whole intra-op thread pool per call);
 * **device ring** — ``depth + 1`` sets of device tensors, allocated once per batch
-  shape; no allocator traffic per step;
+  shape and owned by the prefetcher, not by one epoch's iterator: the next ``iter()``
+  (the next epoch, or the loop after an early ``break``) reuses the same slots WITH their
+  "consumed" events, so a slot the last steps of the previous epoch still read is not
+  overwritten by the new epoch's first uploads (per-iterator slots were
+  dropped at the end of an epoch with up to ``depth`` steps still pending, and the
+  caching allocator could hand the same memory to the next epoch's slots at once);
+  no allocator traffic per step;
 * **event hand-off, resolved on the worker** — a slot is overwritten only after its
   "consumed" event (recorded when the consumer asks for the next batch, i.e. after
   everything that reads the slot has been enqueued) has completed, and is handed over
@@ -85,6 +91,11 @@ class DevicePrefetcher:
             raise ValueError("MIMO_PREFETCH_HANDOFF must be 'host' or 'gpu'")
         self.starved = 0           # times the consumer found no uploaded batch ready and waited for the worker
         self.pageable_uploads = 0  # tensors that came from pageable memory (synchronous copies, on the worker)
+        # the device ring and the worker of the iteration in progress live on the prefetcher: see "device ring" above
+        self._slots = [_Slot() for _ in range(self.depth + 1)]
+        self._worker: Optional[threading.Thread] = None
+        self._stop_q: Optional["queue.Queue"] = None
+        self._handed: Optional[_Slot] = None  # the slot of the batch the consumer holds right now
 
     def __len__(self) -> int:
         return len(self.batches)  # type: ignore[arg-type]
@@ -94,16 +105,17 @@ class DevicePrefetcher:
         spec = tuple((k, tuple(v.shape), v.dtype) for k, v in batch.items() if torch.is_tensor(v))
         out: Dict[str, Any] = {}
         with torch.cuda.stream(self.copy_stream):
-            if slot.spec != spec:  # first use, or a ragged last batch: (re)allocate this slot's buffers
-                # (allocated under the copy stream's context: the caching allocator orders reuse of the memory on it)
-                slot.dev = {k: torch.empty(shape, dtype=dt, device=self.device) for k, shape, dt in spec}
-                slot.spec = spec
             if slot.consumed is not None:
                 # the step that read this slot's device tensors is done
                 if self.handoff == "host":
                     slot.consumed.synchronize()
                 else:
                     self.copy_stream.wait_event(slot.consumed)
+            if slot.spec != spec:  # first use, or a ragged last batch: (re)allocate this slot's buffers
+                # (behind the wait above: the old buffers go back to the allocator only once their last reader is done;
+                # allocated under the copy stream's context: the caching allocator orders reuse of the memory on it)
+                slot.dev = {k: torch.empty(shape, dtype=dt, device=self.device) for k, shape, dt in spec}
+                slot.spec = spec
             for k, v in batch.items():
                 if not torch.is_tensor(v):
                     out[k] = v
@@ -131,21 +143,40 @@ class DevicePrefetcher:
         except BaseException as e:  # surfaces in the consuming thread
             ready_q.put(e)
 
+    def _retire_worker(self) -> None:
+        """The previous iteration's worker is gone before its slots are handed out again (it may be inside an upload)."""
+        if self._worker is not None:
+            if self._stop_q is not None:
+                self._stop_q.put(_STOP)
+            self._worker.join()
+            self._worker = self._stop_q = None
+
+    def _release(self, slot: _Slot) -> None:
+        # everything that reads this slot's batch has been enqueued by now (the caller came back for more, or left)
+        slot.consumed = torch.cuda.Event()
+        slot.consumed.record(torch.cuda.current_stream(self.device))
+        if self._handed is slot:
+            self._handed = None
+
     def __iter__(self) -> Iterator[Dict[str, Any]]:
+        self._retire_worker()
+        if self._handed is not None:
+            # an iterator that was abandoned without being closed (its `finally` has not run yet): the batch it handed
+            # out last is over by the contract above — "valid until the next one is drawn"
+            self._release(self._handed)
         free_q: "queue.Queue" = queue.Queue()
         ready_q: "queue.Queue" = queue.Queue()
-        for _ in range(self.depth + 1):
-            free_q.put(_Slot())
+        for slot in self._slots:  # with the "consumed" events the previous iteration left on them
+            free_q.put(slot)
         worker = threading.Thread(target=self._produce, args=(iter(self.batches), free_q, ready_q), daemon=True,
                                   name="DevicePrefetcher")
+        self._worker, self._stop_q = worker, free_q
         worker.start()
         previous: Optional[_Slot] = None
         try:
             while True:
                 if previous is not None:
-                    # everything that reads the previous batch has been enqueued by now (the caller came back for more)
-                    previous.consumed = torch.cuda.Event()
-                    previous.consumed.record(torch.cuda.current_stream(self.device))
+                    self._release(previous)
                     free_q.put(previous)
                     previous = None
                 try:
@@ -160,7 +191,12 @@ class DevicePrefetcher:
                 slot, dev_batch = item
                 if self.handoff != "host":  # ("host": the worker handed the slot over after the upload had completed)
                     torch.cuda.current_stream(self.device).wait_event(slot.uploaded)
-                previous = slot
+                previous = self._handed = slot
                 yield dev_batch
         finally:
+            if previous is not None and self._stop_q is free_q:
+                # the last batch handed out (end of the epoch, an early break, an exception in the loop body): the steps
+                # that read it may still be pending when the next iteration's worker reaches this slot.  (Not when a newer
+                # iteration already owns the ring: it released this slot when it started.)
+                self._release(previous)
             free_q.put(_STOP)  # a consumer that stops early leaves no worker waiting for a slot

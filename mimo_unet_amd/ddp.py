@@ -11,6 +11,7 @@ waited for right before the optimiser."""
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -63,8 +64,20 @@ class FlatGradientAllReducer:
     few MB) and split above `bucket_bytes`; cfg3 (60 MB of gradients) goes out as six all-reduces of 3-21 MB,
     the first of them after about a third of the backward."""
 
-    def __init__(self, bucket_bytes: int = 64 << 20, group=None, min_bucket_bytes: int = 4 << 20):
+    ALGORITHMS = ("all_reduce", "reduce_scatter")
+
+    def __init__(self, bucket_bytes: int = 64 << 20, group=None, min_bucket_bytes: int = 4 << 20,
+                 algorithm: Optional[str] = None):
+        """algorithm: "all_reduce" (default; MIMO_DDP_ALGO overrides) — one `dist.all_reduce` per bucket, RCCL picks the
+        schedule — or "reduce_scatter": each bucket as an in-place reduce-scatter (rank r ends up with the sum of its
+        1/W-th of the bucket) followed by an in-place all-gather, the direct form SURVEY §5 / §8(e) prefers on the fully
+        connected 8-GPU xGMI topology (every link carries 1/W of the bucket twice instead of a ring pushing (W-1)/W of it
+        through each link twice); the < W floats a bucket does not divide into go out as a small all-reduce.  Same sums on
+        every rank either way (the two may differ from each other in the last bit for W > 2: the order of the W addends)."""
         self.group = group
+        self.algorithm = algorithm or os.environ.get("MIMO_DDP_ALGO", "all_reduce")
+        if self.algorithm not in self.ALGORITHMS:
+            raise ValueError(f"FlatGradientAllReducer: algorithm {self.algorithm!r} not in {self.ALGORITHMS}")
         self.bucket_floats = max(1, bucket_bytes // 4)
         self.min_floats = max(1, min(min_bucket_bytes, bucket_bytes) // 4)
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -73,6 +86,7 @@ class FlatGradientAllReducer:
         self._pending: List = []
         self._held = None  # (flat, begin, end): announced, not yet issued
         self.issued: List = []  # [(begin, end)] of the collectives of the current step (diagnostics / tests)
+        self.last_issued: List = []  # ... of the step `finish()` completed last
         # (flat buffer, its torch version counter) right after the last collective issued on it: while the counter still
         # has that value nothing has written the gradients through torch since (no zero_grad(set_to_none=False), no
         # clipping), so a backward that ACCUMULATES into them would sum an already-reduced micro-batch over the ranks again
@@ -86,8 +100,28 @@ class FlatGradientAllReducer:
         for lo in range(begin, end, self.bucket_floats):
             hi = min(end, lo + self.bucket_floats)
             self.issued.append((lo, hi))
-            self._pending.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.algorithm == "reduce_scatter" and self.world_size > 1:
+                self._issue_reduce_scatter(flat, lo, hi)
+            else:
+                self._pending.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._reduced = (flat, flat._version)
+
+    def _issue_reduce_scatter(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+        """flat[lo:hi] summed over the ranks as reduce-scatter + all-gather, both in place: rank r's output chunk is the
+        r-th 1/W of the bucket itself (RCCL's in-place form: recvbuff == sendbuff + rank * count)."""
+        W, r = self.world_size, dist.get_rank(self.group)
+        chunk = (hi - lo) // W
+        if chunk > 0:
+            body = flat[lo: lo + W * chunk]
+            mine = flat[lo + r * chunk: lo + (r + 1) * chunk]
+            rs = dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if dist.get_backend(self.group) != "nccl":
+                rs.wait()  # (RCCL orders the two on its stream; a host-side backend may run async works concurrently)
+            else:
+                self._pending.append(rs)
+            self._pending.append(dist.all_gather_into_tensor(body, mine, group=self.group, async_op=True))
+        if lo + W * chunk < hi:  # the remainder, fewer than W floats
+            self._pending.append(dist.all_reduce(flat[lo + W * chunk: hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def reduced_version(self, flat: torch.Tensor):
         """torch version counter of `flat` after the last collective issued on it, None if there was none."""
@@ -140,7 +174,7 @@ class FlatGradientAllReducer:
         if self._pending and self._reduced is not None:
             self._reduced = (self._reduced[0], self._reduced[0]._version)  # (a backend may bump the counter on completion)
         self._pending.clear()
-        self.issued = []
+        self.last_issued, self.issued = self.issued, []
 
     def all_reduce(self, flat: torch.Tensor) -> None:
         self.start(flat)

@@ -1,6 +1,6 @@
 """What the data-parallel step costs beside the plain step, on one GPU (1-rank RCCL group):
     plain | staged backward with a no-op hook | + bucketed all-reduces (reducer.always) | + finish() before the optimiser
-python scripts/ddp_overhead.py"""
+python scripts/ddp_overhead.py [batch=32]      (MIMO_TRAIN_GRAPH=0|1 in the environment selects eager launches / graph replay)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +11,8 @@ from mimo_unet_amd.ddp import FlatGradientAllReducer
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(0)
 c = dict(B.CONFIGS["cfg3"])
+if len(sys.argv) > 1:
+    c["batch"] = int(sys.argv[1])
 g = torch.Generator(device="cuda").manual_seed(100)
 image = torch.rand(c["batch"], c["Ci"], c["H"], c["W"], device="cuda", generator=g)
 batch = {"image": image, "label": B.learnable_label(image, generator=g)}
@@ -25,11 +27,13 @@ def run(name, setup):
         model.training_step(batch, i)["loss"].backward()
         if red is not None: red.finish()
         opt.step()
+    n = 30 if c["batch"] >= 16 else 100
     for i in range(8): step(i)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for i in range(30): step(i)
+    for i in range(n): step(i)
+    th = time.perf_counter() - t0  # the host has enqueued everything
     torch.cuda.synchronize()
-    print(f"{name:48s} {(time.perf_counter() - t0) / 30 * 1e3:7.3f} ms/step", flush=True)
+    print(f"{name:48s} {(time.perf_counter() - t0) / n * 1e3:7.3f} ms/step   (host loop {th / n * 1e3:6.3f} ms/step)", flush=True)
     del model, opt
 
 def noop_hook(m):

@@ -90,18 +90,35 @@ def amp_reference(amp_name, src_name, mode):
 # fixture, ~1.5x the reference's own statistic with a floor for the near-exact fixture — for tensors with >= 256 elements
 # (fewer: rms ~ max, one flip).
 ADAM_FLIP_RMS = {"cfg1_step.npz": 0.2, "mini_s2_step.npz": 0.08, "mini_gauss_step.npz": 0.25}
-# split16 since round 5: the weight gradient multiplies the activation as ONE fp16 value (2^-12 per element; dz keeps an
-# fp16 pair) — weight gradients carry ~1e-4 of their scale in rounding noise instead of 1e-5, so more near-zero gradient
-# elements change sign under Adam: observed 0.13 on mini_s2 (three-MFMA arithmetic, MIMO_WGRAD_NP=3: 0.06), 0.12 on cfg1 —
-# the level fp32 rounding itself produces on cfg1.  One bound for that arithmetic: 0.2.
-ADAM_FLIP_RMS_SPLIT16 = 0.2
+# ARITHMETIC-SPECIFIC bounds (DESIGN.md section 4 lists them): split16 since round 5 multiplies the activation of the weight
+# gradient as ONE fp16 value (2^-12 per element; dz keeps an fp16 pair; MIMO_WGRAD_NP=3 restores three bf16-pair MFMAs) —
+# weight gradients carry 1-4e-4 of their scale in rounding noise instead of 1e-5, so more near-zero gradient elements change
+# sign under Adam.  Derived like the fp32 table: ~1.5 x what that arithmetic was observed to do on each fixture
+# (profiles/r05/parity_errors.txt: cfg1 0.130, mini_s2 0.126, mini_gauss 0.040), never below the fp32 table's entry.
+ADAM_FLIP_RMS_NP2 = {"cfg1_step.npz": 0.2, "mini_s2_step.npz": 0.19, "mini_gauss_step.npz": 0.25}
+
+
+def wgrad_two_mfma(precision):
+    """the plan runs the weight gradient on two fp16 MFMAs per product (the split16 default since round 5)"""
+    import os
+    return precision == "split16" and os.environ.get("MIMO_WGRAD_NP") != "3"
 
 
 def adam_flip_bound(fixture, precision):
-    import os
-    if precision == "split16" and os.environ.get("MIMO_WGRAD_NP") != "3":
-        return max(ADAM_FLIP_RMS[fixture], ADAM_FLIP_RMS_SPLIT16)
-    return ADAM_FLIP_RMS[fixture]
+    return max(ADAM_FLIP_RMS[fixture], ADAM_FLIP_RMS_NP2[fixture]) if wgrad_two_mfma(precision) else ADAM_FLIP_RMS[fixture]
+
+
+# Per-tensor gradient error against the reference goldens (max |ours - ref| / max |ref|).  The north_star's tolerance is
+# 1e-3; the golden checks fail EARLIER, at ~1.3 x what each arithmetic was observed to do, so that the next precision trade
+# cannot slide in under the headline tolerance (VERDICT r5 item 4b): fp32-MFMA mode observed <= 1.7e-4, three-MFMA split16
+# <= 1.1e-4, two-MFMA split16 <= 6.2e-4 (profiles/r05/parity_errors.txt).
+GOLDEN_GRAD_TOL = {"fp32": 3e-4, "split16-np3": 3e-4, "split16": 8e-4}
+
+
+def golden_grad_tol(precision):
+    if precision == "split16":
+        return GOLDEN_GRAD_TOL["split16" if wgrad_two_mfma(precision) else "split16-np3"]
+    return GOLDEN_GRAD_TOL.get(precision, 1e-3)
 
 
 def adam_flip_statistic(ours, ref, budget):

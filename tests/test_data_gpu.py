@@ -62,6 +62,36 @@ def test_prefetched_loop_is_bit_identical_to_the_resident_loop(pinned, depth):
     assert pf.pageable_uploads == (0 if pinned else 3 * 8)
 
 
+def test_two_epochs_back_to_back_do_not_overwrite_batches_that_pending_steps_still_read():
+    """the slots used to belong to one `iter()`; at the end of an epoch they were dropped with up to
+    `depth` enqueued steps still waiting to read them, and the next epoch's worker could upload its first batches into the
+    same memory at once.  Here the GPU is held back (a long idle kernel in front of the last steps of every epoch) while
+    the host walks straight into the next epoch — no synchronisation anywhere in the loop — and the result must still be
+    the resident loop's, bit for bit; the same after a loop that left its epoch early."""
+    import itertools
+    from mimo_unet_amd.data import DevicePrefetcher
+    host = _host_batches(5, 4, 2, 32, 48, pinned=True, with_mask=True)
+    stall = _sleep_cycles_for(60.0)
+
+    def stalled(batches):  # hold the GPU back in front of the last two steps of the epoch
+        for i, b in enumerate(batches):
+            if i >= 3:
+                torch.cuda._sleep(stall)
+            yield b
+
+    resident = [{k: v.cuda() for k, v in b.items()} for b in host]
+    ref_l, ref_p = _train(itertools.chain(stalled(resident), stalled(resident), resident))
+    for depth in (1, 2):
+        pf = DevicePrefetcher(host, device="cuda", depth=depth)
+        got_l, got_p = _train(itertools.chain(stalled(pf), stalled(pf), pf))
+        assert torch.equal(ref_l, got_l) and torch.equal(ref_p, got_p), f"depth {depth}"
+    # an epoch left after two batches (uploads in flight, the steps pending), then a full one
+    ref_l, ref_p = _train(itertools.chain(itertools.islice(stalled(resident), 4), resident))
+    pf = DevicePrefetcher(host, device="cuda", depth=2)
+    got_l, got_p = _train(itertools.chain(itertools.islice(stalled(pf), 4), pf))
+    assert torch.equal(ref_l, got_l) and torch.equal(ref_p, got_p)
+
+
 def test_prefetcher_passes_non_tensors_through_and_rejects_cpu():
     from mimo_unet_amd.data import DevicePrefetcher
     with pytest.raises(ValueError):

@@ -137,6 +137,11 @@ def test_gradient_accumulation_under_the_reducer_sums_each_micro_batch_once():
     assert f0 and f1
 
 
+# cfg3's 60.3 MB of gradients under FlatGradientAllReducer's defaults (merge until >= 4 MB are pending): heads + decoders + up3
+# + up2 (6.9 MB) | up1 (20.7) | down4 (16.6) | down3 (12.4) | down2 + encoders (3.6, flushed by finish())
+N_COLLECTIVES_CFG3 = 5
+
+
 def _run_bench(extra_env, *argv):
     import json
     import subprocess
@@ -169,6 +174,35 @@ def test_bench_spawns_its_own_ranks_gloo_sharing_the_gpu():
     assert cfg["weak_per_gpu_batch"] == 4 and cfg["strong_global_batch"] == 4
 
 
+def test_bench_eight_ranks_gloo_sharing_the_gpu():
+    """The 8-GPU regime of BASELINE config 3 as a FUNCTIONAL run (world 2 was the only size ever
+    exercised): `python bench.py --gpus 8 --batch 32` starts eight ranks, here over gloo on GPU 0 — global batch 32 sharded
+    4 per rank (ddp.shard_batch), the backward of every rank issues the same six bucketed collectives, and all eight ranks
+    end with bit-identical parameters.  Not a performance configuration."""
+    line = _run_bench({"MIMO_BENCH_BACKEND": "gloo", "OMP_NUM_THREADS": "2"}, "--gpus", "8", "--steps", "2", "--warmup", "1",
+                      "--batch", "32", "--scaling", "strong", "--profile-steps", "0", "--no-cpu-baseline", "--no-strict",
+                      "--one-regime")
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and cfg["world_size"] == 8 and cfg["backend"] == "gloo" and cfg["rccl_ranks"] is None
+    assert cfg["global_batch"] == 32 and cfg["per_gpu_batch"] == 4
+    # cfg3: 15.06 M parameters = 60.3 MB of gradients, out as six buckets (heads + decoders + up3 + up2 merged, then one per core block)
+    assert cfg["collectives_per_step"] == N_COLLECTIVES_CFG3, (cfg["collectives_per_step"], cfg["collective_mbytes"])
+    assert abs(sum(cfg["collective_mbytes"]) - 60.3) < 0.5, cfg["collective_mbytes"]
+    assert cfg["params_bit_identical_across_ranks"] is True
+    assert len(cfg["rank_devices"]) == 8 and line["value"] > 0
+
+
+@pytest.mark.parametrize("algo", ["reduce_scatter"])
+def test_bench_two_ranks_reduce_scatter_all_gather(algo):
+    """The reduce-scatter + all-gather form of the exchange (ddp.FlatGradientAllReducer(algorithm=...), MIMO_DDP_ALGO) through
+    the real step: two ranks over gloo on GPU 0, parameters bit-identical across the ranks at the end."""
+    line = _run_bench({"MIMO_BENCH_BACKEND": "gloo", "MIMO_DDP_ALGO": algo}, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                      "--batch", "4", "--profile-steps", "0", "--no-cpu-baseline", "--no-strict", "--one-regime")
+    cfg = line["config"]
+    assert cfg["ddp_algorithm"] == algo and cfg["collectives_per_step"] == N_COLLECTIVES_CFG3, cfg["collective_mbytes"]
+    assert cfg["params_bit_identical_across_ranks"] is True
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
 def test_bench_two_ranks_rccl():
     line = _run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4", "--profile-steps", "0",
@@ -176,6 +210,6 @@ def test_bench_two_ranks_rccl():
     # default regime = strong: the batch of 4 is the global batch, 2 per GPU; the weak regime rides along
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_batch"] == 4
     assert line["config"]["weak_images_per_s"] > 0 and line["config"]["weak_per_gpu_batch"] == 4
-    assert line["config"]["rccl_ranks"] == 2 and line["config"]["backend"] == "nccl"
+    assert line["config"]["rccl_ranks"] == 2 and line["config"]["backend"] == "nccl" and line["config"]["collectives_per_step"] == N_COLLECTIVES_CFG3
     assert line["config"]["params_bit_identical_across_ranks"] is True
     assert len(set(line["config"]["rank_devices"])) == 2  # one GPU per rank

@@ -7,7 +7,8 @@ import pytest
 import torch
 
 from oracle import mimo_oracle as O
-from tests.helpers import adam_flip_bound, adam_flip_statistic, cfg_from_meta, load_npz, rel_err, report, state_from
+from tests.helpers import (adam_flip_bound, adam_flip_statistic, cfg_from_meta, golden_grad_tol, load_npz, rel_err, report,
+                           state_from, wgrad_two_mfma)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -34,9 +35,10 @@ def is_prebn_bias(k):
 
 
 def check_grads(named_grads, ref_grads, tol=TOL):
-    """Per-tensor max error relative to the tensor's scale, 1e-3 in both arithmetic modes (observed on the golden
-    fixtures: fp32 <= 6e-5, split16 <= 1e-4 — no ReLU / max-pool mask of these fixtures flips under the split
-    arithmetic; profiles/r02/parity_errors.txt)."""
+    """Per-tensor max error relative to the tensor's scale.  The north_star's tolerance is 1e-3; the checks against the
+    reference GOLDENS pass `golden_grad_tol(precision)` — 3e-4 for the fp32 mode and the three-MFMA weight gradient, 8e-4
+    for the two-MFMA weight gradient (observed <= 1.7e-4 / 1.1e-4 / 6.2e-4, profiles/r05/parity_errors.txt): a precision
+    trade shows as a red test before it reaches the headline tolerance."""
     worst = ("", 0.0)
     for k, ref in ref_grads.items():
         g = named_grads[k].double()
@@ -79,7 +81,8 @@ def test_train_steps_match_reference_golden(name, precision):
             preds = out_dict["preds"].view(N, S, half, *image.shape[-2:]).cpu()
             e_out = rel_err(preds, ref_out[:, :, :half])
             grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
-            worst = check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")})
+            worst = check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")},
+                                tol=golden_grad_tol(precision))
             report(f"{name} [{precision}]: out err {e_out:.2e}, worst grad err {worst[1]:.2e} at {worst[0]}")
             assert e_out < TOL
             sd = model.state_dict()
@@ -105,7 +108,8 @@ def test_train_steps_match_reference_golden(name, precision):
             # after `steps` optimiser steps: with the two-MFMA weight gradient (split16 since round 5) the parameters of the
             # later steps differ by Adam's sign flips (below), and the deepest layers normalise over a dozen samples per
             # channel (mini_s2: 3 images of 2 x 2 pixels) — observed 2.3e-3 there; the first step's buffers are held to 1e-4 above
-            assert rel_err(ours, v) < (5e-3 if adam_flip_bound(name, precision) > 0.1 and precision == "split16" else TOL), name_
+            # (ARITHMETIC-SPECIFIC bound: 5e-3 under the two-MFMA weight gradient, 1e-3 otherwise)
+            assert rel_err(ours, v) < (5e-3 if wgrad_two_mfma(precision) else TOL), name_
         else:  # Adam turns rounding-level gradient differences into sign-level update differences
             d = np.abs(ours - v)
             assert d.max() <= 2.02 * budget + 1e-5 * np.abs(v).max(), (name_, d.max())  # two runs, opposite signs
@@ -136,7 +140,7 @@ def test_input_gradient_and_generic_backward_cfg1(precision):
     report(f"[{precision}] dx err {e:.2e}")
     assert e < TOL
     grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
-    check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")})
+    check_grads(grads, {k[len("s0/grad/"):]: v for k, v in fx.items() if k.startswith("s0/grad/")}, tol=golden_grad_tol(precision))
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -159,7 +163,7 @@ def test_elementwise_center_final_dropout_golden(precision):
     loss.mean().backward()
     e_dx = rel_err(x.grad.cpu(), fx["dx"])
     grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in model.named_parameters()}
-    worst = check_grads(grads, {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")})
+    worst = check_grads(grads, {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")}, tol=golden_grad_tol(precision))
     report(f"elem dropout [{precision}]: out {e_out:.2e} dx {e_dx:.2e} worst grad {worst[1]:.2e} at {worst[0]}")
     assert e_out < TOL and e_dx < TOL
     # without an override the module draws its own Bernoulli masks: a different, but finite, result
@@ -977,7 +981,7 @@ def test_evidential_model_golden(precision):
     assert set(out) == {"loss", "label", "preds", "aleatoric_std_map", "err_map", "mask"}
     e_dx = rel_err(x.grad.cpu(), fx["dx"])
     grads = {k[len("model."):]: p.grad.detach().cpu() for k, p in m.named_parameters()}
-    worst = check_grads(grads, {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")})
+    worst = check_grads(grads, {k[len("grad/"):]: v for k, v in fx.items() if k.startswith("grad/")}, tol=golden_grad_tol(precision))
     report(f"evidential [{precision}]: dx {e_dx:.2e} worst grad {worst[1]:.2e} at {worst[0]}")
     assert e_dx < TOL
     m.eval()
