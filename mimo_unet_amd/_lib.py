@@ -71,6 +71,7 @@ _SIGNATURES = {
     "mimo_loss_forward": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "mimo_backward": (C.c_int, [_P, _P, _P, _P, _P]),
     "mimo_backward_stage": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "mimo_backward_stage_async": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.POINTER(C.c_void_p)]),
     "mimo_plan_encoder_param_floats": (_L, [_P]),
     "mimo_plan_num_backward_stages": (C.c_int, [_P]),
     "mimo_plan_backward_stage_range": (C.c_int, [_P, C.c_int, C.POINTER(_L), C.POINTER(_L)]),

@@ -57,6 +57,9 @@ constexpr int kBlocksBnRelu = 1536, kBlocksBnBwd = 1792, kBlocksUpBwd = 16384, k
 // The BatchNorm-backward REDUCTION runs the same 7168 waves as 448 workgroups of 1024 threads: a quarter of the partial
 // rows for the column-sum launch that follows (12.6 -> ~5 us, 24 times per step, at every batch size)
 constexpr int kBnReduceThreads = 1024, kBlocksBnReduce = kBlocksBnBwd / 4;
+// (Round 6 measured fewer, longer threads on the small tensors of a 4-image step — at least 2 / 4 / 8 pixels per thread, so
+// that the 4-6 float4 of channel constants a thread loads are not most of its memory instructions: the BatchNorm-backward
+// passes got SLOWER, 0.78 -> 0.80 / 0.91 / 1.10 ms per step; they want the threads.  profiles/r06/exp/ew_min_iters.txt)
 static dim3 pq_grid(int Cv, int64_t P, int max_blocks = kEwMaxBlocks, int T = 256) {
   const int QB = Cv < T ? Cv : T;
   const int PPI = T / QB;

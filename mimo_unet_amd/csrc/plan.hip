@@ -204,7 +204,7 @@ struct mimo_plan {
 #endif
   static constexpr int kDzBufs = MIMO_DZ_BUFS;
   static constexpr int wg_bufs = kDzBufs;
-  hipEvent_t ev_dz[kDzBufs] = {}, ev_wg[kDzBufs] = {}, ev_join = nullptr;
+  hipEvent_t ev_dz[kDzBufs] = {}, ev_wg[kDzBufs] = {}, ev_join = nullptr, ev_stage = nullptr;
   bool wg_pending[kDzBufs] = {};
   float* s_dz2[kDzBufs] = {};
   float* s_dzmax2[kDzBufs] = {};  // per-workgroup maxima of |dz| of the tensor in s_dz2[i] (two-MFMA weight gradient)
@@ -291,7 +291,7 @@ struct mimo_plan {
   hipStream_t cap_stream = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   uint64_t graph_key = 0;
-  // hipGraph replay of the TRAINING step (round 6, MIMO_TRAIN_GRAPH; mimo_unet.py:115-144 at its per-GPU shard is ~290
+  // hipGraph replay of the TRAINING step (round 6, MIMO_TRAIN_GRAPH=1, opt-in; mimo_unet.py:115-144 at its per-GPU shard is ~290
   // launches of which ~200 run < 20 us): the training forward is one graph, the backward one graph (mimo_backward) or one
   // per stage (mimo_backward_stage: the data-parallel caller starts a stage's all-reduce between two graphs).  Captured
   // kernels only see plan-owned memory: x / perm / Dropout2d multipliers are staged in front of the forward graph, label /
@@ -386,6 +386,7 @@ struct mimo_plan {
       for (hipEvent_t e : {ev_dz[i], ev_wg[i]})
         if (e) (void)hipEventDestroy(e);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_stage) (void)hipEventDestroy(ev_stage);
   }
 
   template <typename T>
@@ -818,6 +819,7 @@ struct mimo_plan {
         for (int i = 0; i < wg_bufs; ++i)
           for (hipEvent_t* e : {&ev_dz[i], &ev_wg[i]}) MIMO_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         MIMO_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        MIMO_HIP_CHECK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
       }
     }
     MIMO_TRY(alloc_act(&s_dxpadA, cap_pad, st));
@@ -897,9 +899,12 @@ struct mimo_plan {
     MIMO_TRY(dalloc(&g_out, (size_t)N * S * Co * H * W));
     MIMO_TRY(dalloc(&g_perm, (size_t)S * N));
     {
-      // training-step graphs: on by default (MIMO_TRAIN_GRAPH=0: every training launch goes out eagerly)
+      // training-step graphs: opt-in (MIMO_TRAIN_GRAPH=1).  Built, bit-identical to eager launches, and measured NEUTRAL
+      // (profiles/r06/train_graph.txt: 4.42 vs 4.42 ms per step at 4 images per GPU, 24.1 vs 23.9 at batch 32; the host spends
+      // 0.76 ms in the hipGraphLaunch of the ~190-node backward graph — what the eager launches cost it), so the default
+      // keeps the launches eager
       const char* te = getenv("MIMO_TRAIN_GRAPH");
-      train_graph = graph_enabled && !cfg.inference_only && !(te && atoi(te) == 0);
+      train_graph = graph_enabled && !cfg.inference_only && te && atoi(te) != 0;
       if (train_graph) {
         MIMO_TRY(dalloc(&g_label, (size_t)N * (Co / 2) * H * W));
         MIMO_TRY(dalloc(&g_lmask, (size_t)N * H * W));
@@ -1532,7 +1537,13 @@ struct mimo_plan {
     }
   }
 
-  int backward(const float* dout, const float* dloss, float* dx, int stage_first, int stage_last, hipStream_t st) {
+  // ready != nullptr (mimo_backward_stage_async): the stage's gradient range need only be final on the stream returned in
+  // *ready — the side stream when the weight gradients run there (it first waits for the caller's stream: BatchNorm and head
+  // gradients are written there) — and the caller's stream is NOT made to wait for the side stream: a data-parallel caller
+  // issues the range's collective on *ready, and the main stream goes straight on with the next stage.  The last stage joins.
+  int backward(const float* dout, const float* dloss, float* dx, int stage_first, int stage_last, hipStream_t st,
+               hipStream_t* ready = nullptr) {
+    if (ready) *ready = st;
     if (!fwd_done) {
       set_error("mimo_backward: call mimo_forward first");
       return MIMO_ERR_STATE;
@@ -1570,7 +1581,9 @@ struct mimo_plan {
       // ---- training-step graphs: decide for this backward, stage dloss, capture on the second sighting of the shape ----
       tg_bwd_live = false;
       const bool single = stage_first == stage_last;
-      if (train_graph && fwd_graphed && loss_staged && fwd_training && !prof_on && !dout && !dx && dloss && (whole || single) &&
+      // (the asynchronous stages — `ready` — are eager launches: a per-stage graph has to close its fork to the side stream
+      // before it ends, which is the join that route exists to avoid)
+      if (train_graph && !ready && fwd_graphed && loss_staged && fwd_training && !prof_on && !dout && !dx && dloss && (whole || single) &&
           tg_captures < kMaxTrainCaptures) {
         const uint64_t key = (tg_fwd_key << 3) | (lmask ? 4 : 0) | (lperm ? 2 : 0) | (whole ? 1 : 0);
         bool ready = tg_bwd_key == key && (whole ? tg_bwd[kBwdStages] != nullptr : tg_bwd[0] != nullptr);
@@ -1621,6 +1634,12 @@ struct mimo_plan {
     }
     for (int stage = stage_first; stage <= stage_last; ++stage) MIMO_TRY(backward_stage(stage, dout, dloss, dx, st));
     bwd_next_stage = stage_last + 1 < kBwdStages ? stage_last + 1 : 0;
+    if (ready && wg_async && !prof_on && stage_last < kBwdStages - 1) {
+      MIMO_HIP_CHECK(hipEventRecord(ev_stage, st));
+      MIMO_HIP_CHECK(hipStreamWaitEvent(wg_stream, ev_stage, 0));
+      *ready = wg_stream;
+      return MIMO_OK;
+    }
     return wg_join(st);  // the gradients of the stages run so far are final for the caller (all-reduce)
   }
 
@@ -1895,6 +1914,18 @@ int mimo_backward_stage(mimo_plan* plan, int stage, const float* dout, const flo
     return MIMO_ERR_INVALID;
   }
   return plan->backward(dout, dloss, dx, stage, stage, (hipStream_t)stream);
+}
+
+int mimo_backward_stage_async(mimo_plan* plan, int stage, const float* dout, const float* dloss, float* dx, mimo_stream stream,
+                              mimo_stream* ready_stream) {
+  if (!plan || !ready_stream) {
+    set_error("mimo_backward_stage_async: null argument");
+    return MIMO_ERR_INVALID;
+  }
+  hipStream_t ready = nullptr;
+  const int rc = plan->backward(dout, dloss, dx, stage, stage, (hipStream_t)stream, &ready);
+  *ready_stream = (mimo_stream)ready;
+  return rc;
 }
 
 int64_t mimo_plan_encoder_param_floats(const mimo_plan* plan) { return plan ? plan->encoder_param_floats : 0; }

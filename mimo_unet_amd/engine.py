@@ -76,6 +76,7 @@ class Plan:
         self.double_conv_channels = [int(self.lib.mimo_plan_double_conv_channels(handle, i))
                                      for i in range(self.num_double_convs)]
         self._bound = None
+        self._ext_streams: Dict[int, torch.cuda.Stream] = {}  # the plan's own HIP streams as torch streams (backward(async_stage=True))
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -185,14 +186,28 @@ class Plan:
                                            loss_out.data_ptr(), L.current_stream()), "mimo_loss_forward")
 
     def backward(self, dout: Optional[torch.Tensor], dloss: Optional[torch.Tensor], dx: Optional[torch.Tensor],
-                 stage: Optional[int] = None) -> None:
-        """stage None: whole backward; else one of the `backward_stages`, in order (include/mimo_hip.h)."""
+                 stage: Optional[int] = None, async_stage: bool = False):
+        """stage None: whole backward; else one of the `backward_stages`, in order (include/mimo_hip.h).
+        async_stage (with a stage): the current stream is not made to wait for the plan's side stream; returns the
+        torch stream on which the stage's gradient range is final (None: the current stream) — the data-parallel caller
+        issues that range's collective there (mimo_backward_stage_async)."""
         if stage is None:
             L.check(self.lib.mimo_backward(self.handle, L.ptr(dout) or None, L.ptr(dloss) or None, L.ptr(dx) or None,
                                            L.current_stream()), "mimo_backward")
-        else:
+        elif not async_stage:
             L.check(self.lib.mimo_backward_stage(self.handle, stage, L.ptr(dout) or None, L.ptr(dloss) or None,
                                                  L.ptr(dx) or None, L.current_stream()), "mimo_backward_stage")
+        else:
+            cur = L.current_stream()
+            ready = C.c_void_p()
+            L.check(self.lib.mimo_backward_stage_async(self.handle, stage, L.ptr(dout) or None, L.ptr(dloss) or None,
+                                                       L.ptr(dx) or None, cur, C.byref(ready)), "mimo_backward_stage_async")
+            if ready.value is not None and ready.value != cur:
+                ext = self._ext_streams.get(ready.value)
+                if ext is None:
+                    ext = self._ext_streams[ready.value] = torch.cuda.ExternalStream(ready.value, device=self.device)
+                return ext
+        return None
 
 
     PROF_KINDS = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "bn_relu_fwd", "bn_bwd_reduce", "bn_bwd_apply",

@@ -193,6 +193,8 @@ class MimoUNet(nn.Module):
         # Dropout masks are drawn inside the engine (Philox stream keyed by torch's CUDA generator: torch.manual_seed
         # governs them); False: drawn with torch.bernoulli on the device and handed over as tensors
         self.engine_rng = os.environ.get("MIMO_ENGINE_RNG", "1") != "0"
+        # data-parallel backward: stages without a per-stage join of the engine's two streams (engine.Plan.backward)
+        self.async_stages = os.environ.get("MIMO_DDP_ASYNC_STAGES", "1") != "0"
         # one plan per (batch, H, W, device, inference-only); least recently used plans are dropped beyond
         # MIMO_PLAN_CACHE entries (a plan owns its whole activation workspace: ragged last batches, separate
         # train / val batch sizes and variable image sizes would otherwise pile up multi-GB plans)
@@ -214,10 +216,21 @@ class MimoUNet(nn.Module):
 
     # ---- execution order of the DoubleConvs == mimo_plan's (engine) order -----------------
     def double_convs(self) -> List[DoubleConv]:
-        c = self.core
-        return ([m for m in self.encoder.in_convs] + [d.conv for d in self.encoder.down1s]
-                + [c.down2.conv, c.down3.conv, c.down4.conv, c.up1.conv, c.up2.conv, c.up3.conv]
-                + [u.conv for u in self.decoder.up4s])
+        dcs = self.__dict__.get("_dc_cache")
+        if dcs is None:  # (a plain attribute, not a registered submodule list: the modules stay owned by the tree above)
+            c = self.core
+            dcs = ([m for m in self.encoder.in_convs] + [d.conv for d in self.encoder.down1s]
+                   + [c.down2.conv, c.down3.conv, c.down4.conv, c.up1.conv, c.up2.conv, c.up3.conv]
+                   + [u.conv for u in self.decoder.up4s])
+            self.__dict__["_dc_cache"] = dcs
+            self.__dict__["_drop_cache"] = ([dc.double_conv[6] for dc in dcs] + [self.core.center_dropout]
+                                            + list(self.decoder.final_dropouts))
+        return dcs
+
+    def _dropout_modules(self) -> List[nn.Module]:
+        """Dropout2d of every DoubleConv in engine order, then center_dropout, then final_dropouts[s]"""
+        self.double_convs()
+        return self.__dict__["_drop_cache"]
 
     def set_precision(self, precision: str) -> None:
         """"fp32" (f32-input MFMA, exact) or "split16" (split-bf16 MFMA, ~1e-5 relative per product)."""
@@ -238,13 +251,15 @@ class MimoUNet(nn.Module):
         return r
 
     def _ensure_flat(self, plan: Plan, device) -> None:
+        # (every step passes through here twice: the test must not walk the module tree — dict(named_parameters()) +
+        # dict(named_buffers()) per call were 1.2 of the 4.1 ms the host needed per step at 4 images per GPU, round 6)
+        if self._flat_params is not None and self._flat_device == device:
+            owner, attr, off = self._flat_probe
+            if getattr(owner, attr).data_ptr() == self._flat_params.data_ptr() + 4 * off:
+                return
         named_p = dict(self.named_parameters())
         named_b = dict(self.named_buffers())
         first = plan.specs[0]
-        ok = (self._flat_params is not None and self._flat_device == device
-              and named_p[first.name].data_ptr() == self._flat_params.data_ptr() + 4 * first.offset)
-        if ok:
-            return
         fp = torch.zeros(plan.param_floats, device=device, dtype=torch.float32)
         fb = torch.zeros(plan.buffer_floats, device=device, dtype=torch.float32)
         plist = []
@@ -268,6 +283,16 @@ class MimoUNet(nn.Module):
                              for p, sp in zip(plist, [s for s in plan.specs if s.kind == 0])]
         self._flat_device = device
         self._versioned = plist + [named_b[sp.name] for sp in plan.specs if sp.kind == 1]
+        # the probe of the early-out above: the module that owns the first engine tensor, looked up by attribute each time
+        # (a parameter object that was REPLACED — `conv.weight = nn.Parameter(...)` — is seen, like the dict lookup saw it)
+        mod_name, _, attr = first.name.rpartition(".")
+        self._flat_probe = (self.get_submodule(mod_name) if mod_name else self, attr, first.offset)
+        # BatchNorm's num_batches_tracked counters as views of ONE int64 tensor: a training forward bumps them with one
+        # add_ (torch._foreach_add_ over the 24 scalar tensors cost the host 0.67 ms per step)
+        bns = [bn for dc in self.double_convs() for bn in (dc.double_conv[1], dc.double_conv[4])]
+        self._flat_counters = torch.stack([bn.num_batches_tracked.to(device=device, dtype=torch.int64) for bn in bns])
+        for i, bn in enumerate(bns):
+            bn.num_batches_tracked.data = self._flat_counters[i]
 
     def _plan_for(self, x: torch.Tensor, perm: Optional[torch.Tensor], inference: bool = False,
                   for_autograd: bool = False) -> Plan:
@@ -324,7 +349,7 @@ class MimoUNet(nn.Module):
             return masks if any_mask else None
         # all sites in two launches: one Bernoulli draw over a flat [site][n][C] buffer with per-element keep
         # probabilities, one multiply by 1/(1-p); the per-site masks are contiguous views of it
-        active = tuple((dc.dropout.p if dc.dropout.training else 0.0) for dc in dcs)
+        active = tuple((d.p if d.training else 0.0) for d in self._dropout_modules()[:len(dcs)])
         if not any(p > 0.0 for p in active):
             return None
         key = (n, str(device), active)
@@ -348,8 +373,11 @@ class MimoUNet(nn.Module):
     # ---- element-wise dropout (nn.Dropout: center after down4, final in front of each head) ----
     def _elem_dropout_masks(self, n: int, h: int, w: int, device) -> Optional[List[Optional[torch.Tensor]]]:
         S, f = self.num_subnetworks, self.filter_base_count
-        sites = [("center", self.core.center_dropout, (n, 8 * f * S, h // 16, w // 16))]
-        sites += [(f"final{s}", d, (n, f, h, w)) for s, d in enumerate(self.decoder.final_dropouts)]
+        elem = self._dropout_modules()[len(self.double_convs()):]
+        if self.elem_mask_override is None and not any(d.p > 0.0 and d.training for d in elem):
+            return None
+        sites = [("center", elem[0], (n, 8 * f * S, h // 16, w // 16))]
+        sites += [(f"final{s}", d, (n, f, h, w)) for s, d in enumerate(elem[1:])]
         out, any_mask = [], False
         for key, d, shape in sites:
             m = None
@@ -368,8 +396,7 @@ class MimoUNet(nn.Module):
         masks are injected.  Advances torch's CUDA generator offset like a torch dropout call would."""
         if not self.engine_rng or self.mask_override is not None or self.elem_mask_override is not None:
             return None
-        drops = [dc.dropout for dc in self.double_convs()] + [self.core.center_dropout] + list(self.decoder.final_dropouts)
-        sites = [bool(d.p > 0.0 and d.training) for d in drops]
+        sites = [bool(d.p > 0.0 and d.training) for d in self._dropout_modules()]
         if not any(sites):
             return None
         gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
@@ -378,11 +405,10 @@ class MimoUNet(nn.Module):
         return sites, seed, offset
 
     def _bn_training(self) -> bool:
-        return self.encoder.in_convs[0].norm.training
+        return self.double_convs()[0].double_conv[1].training
 
     def _bump_batch_counters(self) -> None:
-        counters = [bn.num_batches_tracked for dc in self.double_convs() for bn in (dc.double_conv[1], dc.double_conv[4])]
-        torch._foreach_add_(counters, 1)  # one launch for the 2 x #DoubleConv counters instead of one each
+        self._flat_counters.add_(1)  # the 2 x #DoubleConv counters are views of this tensor (_ensure_flat)
 
     # ---- forward ----------------------------------------------------------------------------
     def _call(self, x, label, lmask, perm):
@@ -465,9 +491,15 @@ class MimoUNet(nn.Module):
             # data-parallel overlap: one stage per core block (heads + decoders first, the encoders last); each
             # stage's slice of the flat gradient buffer is final when it returns and its all-reduce runs while
             # the later stages back-propagate
+            # (MIMO_DDP_ASYNC_STAGES, default on: a stage does not make this stream wait for the side stream's weight
+            # gradients; its range is final on the stream the engine names, and the collective is issued THERE)
             for st, (b, e) in enumerate(plan.backward_stages):
-                plan.backward(dout, dloss, dx, stage=st)
-                hook(g, b, e)
+                ready = plan.backward(dout, dloss, dx, stage=st, async_stage=self.async_stages)
+                if ready is None:
+                    hook(g, b, e)
+                else:
+                    with torch.cuda.stream(ready):
+                        hook(g, b, e)
         for p, v in views:
             if p.grad is None:
                 p.grad = v

@@ -31,7 +31,10 @@ def _cpu_randperms_on_device(k: int, count: int, device) -> torch.Tensor:
     else:
         slot = ring["slots"][ring["next"]]
         ring["next"] = (ring["next"] + 1) % _PINNED_DEPTH
-        slot[1].synchronize()  # returns at once unless the host is more than _PINNED_DEPTH draws ahead of the GPU
+        # (query first: on ROCm Event.synchronize() of an event that completed long ago still cost the host 0.34 ms per step,
+        # scripts/host_profile.py, round 6; it only has to wait when the host is more than _PINNED_DEPTH draws ahead of the GPU)
+        if not slot[1].query():
+            slot[1].synchronize()
     for s in range(count):
         torch.randperm(k, out=slot[0][s])
     dev = slot[0].to(device, non_blocking=True)

@@ -46,9 +46,15 @@ def reducer(always):
 run("plain, before the process group exists", lambda m: None)
 run("plain, before the process group exists", lambda m: None)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+def with_async(flag, setup):
+    def f(m):
+        m.model.async_stages = flag
+        return setup(m)
+    return f
 for rep in range(2):
     run("plain", lambda m: None)
-    run("staged backward, no-op hook", noop_hook)
-    run("staged + reducer attached, no collectives", reducer(False))
-    run("staged + 1-rank RCCL all-reduces", reducer(True))
+    for flag in (False, True):
+        tag = "async stages" if flag else "joined stages"
+        run(f"staged backward ({tag}), no-op hook", with_async(flag, noop_hook))
+        run(f"staged ({tag}) + 1-rank RCCL all-reduces", with_async(flag, reducer(True)))
 dist.destroy_process_group()

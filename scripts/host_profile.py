@@ -57,6 +57,41 @@ torch.cuda.synchronize()
 tg = time.perf_counter() - t0
 print(f"batch {batch} ddp {int(ddp)} graph {os.environ.get('MIMO_TRAIN_GRAPH', '1')}: host loop {th / steps * 1e3:.3f} ms/step, "
       f"with the GPU drained {tg / steps * 1e3:.3f} ms/step")
+# the backward runs on autograd's own thread (cProfile does not see it): time its layers by hand
+from mimo_unet_amd.engine import Plan
+from mimo_unet_amd.models.mimo_components import model as M
+acc = {"_NetFunction.backward": 0.0, "MimoUNet._run_backward": 0.0, "Plan.backward (C calls)": 0.0, "grad_ready_hook": 0.0}
+
+
+def timed(fn, key):
+    def w(*a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            acc[key] += time.perf_counter() - t
+    return w
+
+
+M._NetFunction.backward = staticmethod(timed(M._NetFunction.backward, "_NetFunction.backward"))
+M.MimoUNet._run_backward = timed(M.MimoUNet._run_backward, "MimoUNet._run_backward")
+Plan.backward = timed(Plan.backward, "Plan.backward (C calls)")
+if model.model.grad_ready_hook is not None:
+    model.model.grad_ready_hook = timed(model.model.grad_ready_hook, "grad_ready_hook")
+t0 = time.perf_counter()
+tb = 0.0
+for i in range(steps):
+    opt.zero_grad()
+    out = model.training_step(b, i)
+    t = time.perf_counter()
+    out["loss"].backward()
+    tb += time.perf_counter() - t
+    if red is not None:
+        red.finish()
+    opt.step()
+torch.cuda.synchronize()
+print(f"loss.backward() {tb / steps * 1e3:.3f} ms per step on the host, of which: " +
+      ", ".join(f"{k} {v / steps * 1e3:.3f}" for k, v in acc.items()))
 pr = cProfile.Profile()
 pr.enable()
 for i in range(steps):
