@@ -299,6 +299,16 @@ int mimo_validation_epilogue(const float* out, const float* label, const float* 
                              float* aleatoric_std, float* epistemic_std, float* err, float* scalars, double* scratch,
                              int32_t scratch_blocks, mimo_stream stream);
 
+/* ---- loss-buffer step: replaces MimoUnetModel._calculate_train_loss's arithmetic on the [S] loss vector
+ * (mimo_unet.py:223-247: weights = loss_buffer.get_weights() read BEFORE loss_buffer.add(loss); loss_buffer.py:43-74:
+ * ring mean over ALL rows incl. still-zero ones, softmax(mean / T) * S) — one launch instead of ~9 tensor operations.
+ * ring    device [size][S], updated in place: row `index` <- loss (the caller advances its index, loss_buffer.py:52)
+ * loss    device [S] (mimo_loss_forward's output); weights / w_over_s: device [S] each = the weights, and weights / S
+ *         (the gradient of mean(loss * weights) w.r.t. loss: mimo_backward's dloss); scalars: device [2] =
+ *         mean(loss * weights), mean(loss).  1 <= S <= 64. */
+int mimo_loss_buffer_step(float* ring, int32_t size, int32_t index, int32_t s, float temperature, const float* loss,
+                          float* weights, float* w_over_s, float* scalars, mimo_stream stream);
+
 /* ---- training-step epilogue: replaces, after the fused forward + loss, the no_grad tail of
  * MimoUnetModel.training_step (mimo_unet.py:121-144): the per-subnetwork label gather of apply_input_transform
  * (utils.py:38-48), loss_fn.mode / loss_fn.std (losses.py:166-192), the error map and compute_regression_metrics

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "mimo_evidential_forward": (C.c_int, [_P, _P, _P, _I, _L, _P, _P, _P]),
     "mimo_evidential_backward": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _P, _P]),
     "mimo_validation_epilogue": (C.c_int, [_P, _P, _P, _I, _I, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "mimo_loss_buffer_step": (C.c_int, [_P, _I, _I, _I, _F, _P, _P, _P, _P, _P]),
     "mimo_training_epilogue": (C.c_int, [_P, _P, _P, _I, _I, _I, _L, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mimo_op_conv3x3_forward": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mimo_op_conv3x3_dgrad": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -188,7 +188,7 @@ size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad);
 // dz_absmax != nullptr: the slabs carry the factor wg_dz_scale(*dz_absmax) (WgradLaunch::np == 2), removed here
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map,
                         int cin_p, int cin, int cout, float* dw, hipStream_t stream, const float* dz_absmax = nullptr,
-                        int dz_absmax_n = 0);
+                        int dz_absmax_n = 0, hipEvent_t done = nullptr);  // done: recorded when the reduction completes
 
 // All weight repacks of a step in ONE launch (a per-layer launch each cost more in dispatch gaps than in
 // work): a device table of jobs, blockIdx.y = job.  kind 0: fp32 [tap][rows_pad][cols]; 1 / 2: fp16 / bf16

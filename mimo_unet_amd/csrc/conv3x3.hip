@@ -11,6 +11,8 @@
 // N = output channels (16 per fragment), K = 9 taps x input channels (4 per MFMA).
 #include <algorithm>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace mimo {
@@ -487,7 +489,7 @@ size_t wgrad_reduce_scratch(int splits, int cin_pad, int cout_pad) {
 }
 
 int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_pad, const int* cin_map, int cin_p,
-                        int cin, int cout, float* dw, hipStream_t stream, const float* dz_absmax, int dz_absmax_n) {
+                        int cin, int cout, float* dw, hipStream_t stream, const float* dz_absmax, int dz_absmax_n, hipEvent_t done) {
   const size_t slab = (size_t)9 * cin_pad * cout_pad;
   const float* src = partial;
   int n = splits;
@@ -504,8 +506,9 @@ int wgrad_reduce_launch(const float* partial, int splits, int cin_pad, int cout_
     src = out;
     n = groups;
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, src, n, cin_pad, cout_pad, cin_map, cin_p,
-                     cin, cout, dw, dz_absmax, dz_absmax_n);
+  // (`done`: recorded when the last kernel of the reduction completes, attached to its launch — elementwise.hip bn_bwd_apply_launch)
+  hipExtLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, nullptr, done, 0, src, n, cin_pad, cout_pad,
+                        cin_map, cin_p, cin, cout, dw, dz_absmax, dz_absmax_n);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

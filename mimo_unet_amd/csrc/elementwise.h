@@ -171,7 +171,8 @@ int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
                         int C, const float* c1, const float* c2, int Cp, int N, int H, int W, void* dz, int split_out,
                         float* partial, int* rows, hipStream_t st, float* absmax = nullptr,
-                        int* absmax_n = nullptr);  // absmax: *absmax_n per-workgroup maxima of |dz| (WgradLaunch::dz_absmax, <= kDzMaxSlots)
+                        int* absmax_n = nullptr,  // absmax: *absmax_n per-workgroup maxima of |dz| (WgradLaunch::dz_absmax, <= kDzMaxSlots)
+                        hipEvent_t done = nullptr);  // != nullptr: recorded when the kernel completes (attached to the launch)
 // dst[p] = [hi Cp bf16 | lo Cp bf16] of src[p][Cp] — the storage the bf16-pair convolution kernels read
 // (split_out != 0 above writes dz in this form directly)
 // absmax != nullptr: *absmax_n per-workgroup maxima of |src| are left there (WgradLaunch::dz_absmax; capacity kDzMaxSlots floats)

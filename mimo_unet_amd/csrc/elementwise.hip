@@ -10,6 +10,8 @@
 //   OutConv 1x1 ........................... components.py:123-129
 //   LaplaceNLL / GaussianNLL .............. mimo/losses.py:47-79,132-164
 //   apply_input_transform gather .......... mimo/models/utils.py:38-48
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -1726,7 +1728,7 @@ __global__ __launch_bounds__(256, (SRC == GS_PLAIN || SRC == GS_FOLD) ? MIMO_APP
 int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int ldz,
                         const float* scale, const float* shift, const float* mean, const float* invstd, const float* mask,
                         int C, const float* c1, const float* c2, int Cp, int N, int H, int W, void* dz, int split_out,
-                        float* partial, int* rows, hipStream_t st, float* absmax, int* absmax_n) {
+                        float* partial, int* rows, hipStream_t st, float* absmax, int* absmax_n, hipEvent_t done) {
   MIMO_TRY(check_grad_src(src, dta, dtz));
   const int Cv = Cp / 4;
   const int64_t units = src.kind == GS_POOL ? (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) : (int64_t)N * H * W;
@@ -1741,9 +1743,11 @@ int bn_bwd_apply_launch(const GradSrc& src, int dta, const void* z, int dtz, int
     set_error("bn_bwd_apply: pair-split dz exists for fp32 storage only");
     return MIMO_ERR_INVALID;
   }
+  // `done`: recorded when THIS kernel completes, carried by the launch itself (hipExtLaunchKernelGGL stop event) — a separate
+  // hipEventRecord behind the kernel costs the stream 2.9-5 us per hand-off (scripts/micro/event_cost.hip), this one ~1
 #define APPLY_LAUNCH(TZ, TA, SRC)                                                                                              \
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<TZ, TA, SRC>), grid, dim3(256), 0, st, src, (const TZ*)z, ldz, scale, shift, mean, invstd, \
-                     mask, C, c1, c2, Cv, N, H, W, (TA*)dz, split_out, partial, absmax)
+  hipExtLaunchKernelGGL((bn_bwd_apply_kernel<TZ, TA, SRC>), grid, dim3(256), 0, st, nullptr, done, 0, src, (const TZ*)z, ldz, scale, \
+                        shift, mean, invstd, mask, C, c1, c2, Cv, N, H, W, (TA*)dz, split_out, partial, absmax)
   if (src.kind == GS_POOL) {
     APPLY_LAUNCH(float, float, GS_POOL);
   } else if (src.kind == GS_HEAD) {

@@ -264,6 +264,46 @@ __global__ void train_finalize_kernel(const double* __restrict__ partial, int bl
   }
 }
 
+// Loss-buffer step of MimoUnetModel._calculate_train_loss (mimo_unet.py:223-247 over loss_buffer.py:43-74) in one launch:
+// weights = softmax(mean over ALL ring rows / T) * S, read BEFORE the current loss is written into row `index`; then
+// out = {weights [S], weights / S [S] (the gradient of the weighted mean w.r.t. the losses), mean(loss * weights), mean(loss)}.
+// One wave; S <= 64 (one subnetwork per lane).
+__global__ void loss_buffer_step_kernel(float* __restrict__ ring, int size, int index, int S, float T,
+                                        const float* __restrict__ loss, float* __restrict__ weights,
+                                        float* __restrict__ w_over_s, float* __restrict__ scalars) {
+  const int s = threadIdx.x;
+  const bool on = s < S;
+  float m = 0.f;
+  if (on) {
+    for (int r = 0; r < size; ++r) m += ring[(size_t)r * S + s];
+    m = m / (float)size / T;  // (torch: buffer.mean(dim=0) / temperature)
+  }
+  float mx = on ? m : -INFINITY;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  const float e = on ? expf(m - mx) : 0.f;
+  float den = e;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) den += __shfl_xor(den, d);
+  const float w = e / den * (float)S;
+  const float l = on ? loss[s] : 0.f;
+  float lw = l * w, ls = l;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    lw += __shfl_xor(lw, d);
+    ls += __shfl_xor(ls, d);
+  }
+  if (on) {
+    weights[s] = w;
+    w_over_s[s] = w / (float)S;
+    ring[(size_t)index * S + s] = l;
+  }
+  if (s == 0) {
+    scalars[0] = lw / (float)S;
+    scalars[1] = ls / (float)S;
+  }
+}
+
 }  // namespace mimo
 
 extern "C" int mimo_training_epilogue(const float* out, const float* label, const int64_t* perm, int32_t n, int32_t s,
@@ -478,6 +518,20 @@ extern "C" int mimo_uncertainties(const float* p1, const float* p2, int32_t n, i
   const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 4096);
   hipLaunchKernelGGL(uncertainty_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p1, p2, n, s, (int64_t)c * hw,
                      loss_kind, mean, aleatoric, epistemic);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
+}
+
+extern "C" int mimo_loss_buffer_step(float* ring, int32_t size, int32_t index, int32_t s, float temperature, const float* loss,
+                                     float* weights, float* w_over_s, float* scalars, mimo_stream stream) {
+  using namespace mimo;
+  if (!ring || !loss || !weights || !w_over_s || !scalars || size < 1 || index < 0 || index >= size || s < 1 || s > 64 ||
+      !(temperature > 0.f)) {
+    set_error("mimo_loss_buffer_step: invalid argument (1 <= S <= 64, 0 <= index < size, temperature > 0)");
+    return MIMO_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(loss_buffer_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ring, size, index, s, temperature, loss,
+                     weights, w_over_s, scalars);
   MIMO_KERNEL_CHECK();
   return MIMO_OK;
 }

@@ -194,13 +194,21 @@ struct mimo_plan {
   // test hook (MIMO_DEBUG_WGRAD_DELAY_US, read per plan): an idle kernel of that many microseconds in front of every weight
   // gradient, on the stream it runs on — the consumer of dz and its max |dz| slots arrives late (tests/test_streams_gpu.py)
   int wg_delay_us = 0;
+  // the hand-off events between the two streams ride on the launches that produce what they announce (hipExtLaunchKernelGGL
+  // stop event) instead of hipEventRecord calls behind them: MIMO_EVENT_ON_LAUNCH=0 restores the records (A/B; read per plan)
+  bool ev_attach = true;
   // BatchNorm backward forms the gradient arriving at a pooled tensor / at the head's input itself (GS_POOL / GS_HEAD):
   // fp32 storage, MIMO_FUSE_BWD_SRC=0 switches it off (read per plan)
   bool fuse_bwd_src = false;
   bool fuse_bwd_pool = false, fuse_bwd_head = false;  // (MIMO_FUSE_BWD_SRC=2: pooled tensors only, 3: head only — A/B)
   hipStream_t wg_stream = nullptr;
 #ifndef MIMO_DZ_BUFS
-#define MIMO_DZ_BUFS 2  // dz buffers (with their max |dz| slots) the side stream's weight gradients may lag behind
+// dz buffers (with their max |dz| slots) the side stream's weight gradients may lag behind.  Round 6: 4 buffers, released in
+// PAIRS — the main stream waits for the side stream once per two layers (in front of an even buffer, for the event of the odd
+// one behind it: the side stream is in order, so that covers both) instead of once per layer.  A cross-stream wait in front
+// of a kernel costs the waiting stream ~4 us on this stack even when it is already satisfied (scripts/micro/event_cost.hip);
+// 2 buffers with a wait per layer (rounds 2-5) remain as the A/B build -DMIMO_DZ_BUFS=2.
+#define MIMO_DZ_BUFS 4
 #endif
   static constexpr int kDzBufs = MIMO_DZ_BUFS;
   static constexpr int wg_bufs = kDzBufs;
@@ -664,6 +672,8 @@ struct mimo_plan {
       const char* e = getenv("MIMO_WGRAD_CUS");
       const int v = e ? atoi(e) : 0;
       wg_cus = (v >= 8 && v <= 256) ? v : sched::wg_side_cus((long)N * H * W, S * f);
+      const char* ea = getenv("MIMO_EVENT_ON_LAUNCH");
+      ev_attach = !(ea && atoi(ea) == 0);
       const char* d = getenv("MIMO_DEBUG_WGRAD_DELAY_US");
       wg_delay_us = d ? std::max(0, std::min(atoi(d), 5000)) : 0;
     }
@@ -1342,28 +1352,43 @@ struct mimo_plan {
     float* dz = s_dz2[b];
     if (async) {
       dz_idx = (dz_idx + 1) % wg_bufs;
-      if (wg_pending[b]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));  // last reader of this dz buffer
+      // last reader of this dz buffer (and, released in pairs, of the one after it)
+      if (kDzBufs >= 4 && (kDzBufs & 1) == 0) {
+        if ((b & 1) == 0) {
+          const int w = wg_pending[b + 1] ? b + 1 : b;
+          if (wg_pending[w]) MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[w], 0));
+          wg_pending[b] = wg_pending[b + 1] = false;  // (their last readers are behind this wait)
+        } else if (wg_pending[b]) {  // not covered by the pair's wait: cannot happen in cyclic order, kept as the safe path
+          MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));
+        }
+      } else if (wg_pending[b]) {
+        MIMO_HIP_CHECK(hipStreamWaitEvent(st, ev_wg[b], 0));
+      }
     }
     // the image convolution's weight gradient on the plain-FMA kernel reads dz as fp32 (no data gradient wanted: nothing
     // else reads this dz)
     const bool thin_wg = L.thin && !mixed && !need_dgrad && wgrad_thin_ok(L.Cin, L.cout_p, L.N, L.H, L.W);
     pr = prof_begin(MIMO_PROF_BN_BWD_APPLY, st);
     int dzmax_n = 0;  // per-workgroup maxima of |dz| that launch leaves (two-MFMA weight gradient)
+    // "dz exists" travels with the launch that writes it (a stop event on the kernel, no hipEventRecord behind it) whenever that
+    // launch is the last writer — not when a split copy of dz follows — and not under stream capture
+    const bool needs_split_copy = L.wg_split && !L.dg_split && !thin_wg;
+    const bool ev_on_launch = async && ev_attach && !capturing && !needs_split_copy;
     MIMO_TRY(bn_bwd_apply_launch(src, this->st, L.z, L.dtz, L.cout_p, L.scale, L.shift, L.mean, L.invstd, mask,
                                  L.Cout, L.c1, L.c2, L.cout_p, L.N, L.H, L.W, dz, (L.dg_split && !mixed && !thin_wg) ? 1 : 0,
                                  fwd_training ? nullptr : s_partial, &rows, st, (L.wg_np2 && !thin_wg) ? s_dzmax2[b] : nullptr,
-                                 &dzmax_n));
+                                 &dzmax_n, ev_on_launch ? ev_dz[b] : nullptr));
     prof_end(pr, 0.0, (8.0 + src_b) * (double)P * L.cout_p, st);
     // dz storage: bf16 hi|lo pairs when the data-gradient kernel is the bf16-pair one (then the weight
     // gradient is too); fp32 otherwise, with a split copy for a bf16-pair weight gradient
     const float* dz_wg = dz;
-    if (L.wg_split && !L.dg_split && !thin_wg) {
+    if (needs_split_copy) {
       float* dzs = s_dzs2[b];
       MIMO_TRY(split_pairs_launch(dz, dzs, P, L.cout_p, st));
       dz_wg = dzs;
     }
     // wgrad(L) may start as soon as dz exists, next to dgrad(L)
-    if (async) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
+    if (async && !ev_on_launch) MIMO_HIP_CHECK(hipEventRecord(ev_dz[b], st));
     // conv bias gradient: exactly zero in front of a training-mode BatchNorm (written by bn_bwd_stats above);
     // a real column sum of dz only after an eval-mode forward (running statistics: dz = scale * dy)
     if (!fwd_training) MIMO_TRY(colsum_vec_launch(s_partial, rows, L.cout_p, L.Cout, grads + L.off_b, colsum(), st));
@@ -1435,15 +1460,16 @@ struct mimo_plan {
     else
       MIMO_TRY(wgrad_launch(wg, ws));
     prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), ws);
+    const bool wg_ev_on_launch = async && ev_attach && !capturing && !thin_wg;
     if (!thin_wg)  // (the plain-FMA kernel's launch reduces its own partials)
       MIMO_TRY(wgrad_reduce_launch(s_wslab, L.wg_splits, L.wg_cin_pad, L.wg_cout_pad, L.cin_map, L.cin_p, L.Cin, L.Cout,
-                                   grads + L.off_w, ws, wg.dz_absmax, wg.dz_absmax_n));
+                                   grads + L.off_w, ws, wg.dz_absmax, wg.dz_absmax_n, wg_ev_on_launch ? ev_wg[b] : nullptr));
     if (async) {
       // dz buffer b AND its max |dz| slots are free again — recorded behind the REDUCTION: it reads the slots too (to take the
       // two-MFMA kernel's scale out again), and the BatchNorm backward of the layer after next overwrites them.  (Until the
       // end of round 5 the event sat in front of the reduction: a race that showed as a weight gradient off by > 1e-4 of
       // its scale in one small-geometry test when that test ran alone.)
-      MIMO_HIP_CHECK(hipEventRecord(ev_wg[b], wg_stream));
+      if (!wg_ev_on_launch) MIMO_HIP_CHECK(hipEventRecord(ev_wg[b], wg_stream));
       wg_pending[b] = true;
     }
     return MIMO_OK;

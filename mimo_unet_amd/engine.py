@@ -325,6 +325,40 @@ def evidential_head_loss(logits: torch.Tensor, label: Optional[torch.Tensor] = N
     return ev, (loss if label is not None else None)
 
 
+class _LossBufferStep(torch.autograd.Function):
+    """(mean(loss * weights), weights, mean(loss)) with `loss` written into row `index` of the ring — one launch
+    (include/mimo_hip.h mimo_loss_buffer_step).  d mean(loss * weights) / d loss = weights / S: the weights carry no
+    gradient, they come from the DETACHED losses of earlier steps (mimo_unet.py:243-245)."""
+
+    @staticmethod
+    def forward(ctx, loss, ring, index, temperature):
+        lib = L.load()
+        size, S = ring.shape
+        ld = loss.detach()
+        if not (ld.is_contiguous() and ld.dtype == torch.float32):
+            ld = ld.contiguous().float()
+        out = torch.empty(2 * S + 2, device=ring.device, dtype=torch.float32)
+        weights, w_over_s, scalars = out[:S], out[S:2 * S], out[2 * S:]
+        L.check(lib.mimo_loss_buffer_step(ring.data_ptr(), size, index, S, float(temperature), ld.data_ptr(), weights.data_ptr(),
+                                          w_over_s.data_ptr(), scalars.data_ptr(), L.current_stream()), "mimo_loss_buffer_step")
+        ctx.save_for_backward(w_over_s)
+        train_loss = scalars[1]
+        ctx.mark_non_differentiable(weights, train_loss)
+        return scalars[0], weights, train_loss
+
+    @staticmethod
+    def backward(ctx, grad, _gw, _gt):
+        (w_over_s,) = ctx.saved_tensors
+        return grad * w_over_s, None, None, None
+
+
+def loss_buffer_step(ring: torch.Tensor, index: int, temperature: float, loss: torch.Tensor):
+    """One launch for MimoUnetModel._calculate_train_loss's [S] arithmetic: returns (the differentiable mean(loss * weights),
+    weights [S] read before `loss` enters the ring, mean(loss)); row `index` of `ring` [size, S] now holds the detached loss."""
+    assert ring.is_cuda and ring.dtype == torch.float32 and ring.is_contiguous() and loss.shape == (ring.shape[1],)
+    return _LossBufferStep.apply(loss, ring, index, temperature)
+
+
 VAL_SCALARS = ("nll_combined", "mae", "mse", "rmse", "r2", "aleatoric_std_mean", "epistemic_std_mean", "count")
 
 

@@ -8,6 +8,11 @@ between its forward and its backward."""
 import torch
 
 
+import os
+
+_FUSED_STEP = os.environ.get("MIMO_LOSS_STEP_FUSED", "1") != "0"  # 0: the [S]-sized torch operations of rounds 1-5 (A/B)
+
+
 def softmax_temperature(x: torch.Tensor, temperature: float = 1.0) -> torch.Tensor:
     if not temperature > 0:
         raise AssertionError("Temperature should be positive.")
@@ -32,6 +37,27 @@ class LossBuffer:
             self.buffer = self.buffer.to(loss.device)  # once: the ring lives where the losses are produced
         self.buffer[self.index] = loss.detach()
         self.index = (self.index + 1) % self.buffer_size
+
+    def step(self, loss: torch.Tensor):
+        """get_weights() followed by add(loss) and the weighted mean, as `MimoUnetModel._calculate_train_loss` runs them
+        (mimo_unet.py:243-247: the weights are read BEFORE the current loss enters the ring), in ONE kernel on the device
+        (engine.loss_buffer_step) — the [S]-sized torch operations were ~9 launches per training step.  Returns
+        (mean(loss * weights) — differentiable w.r.t. `loss` —, weights, mean(loss)); None when the fused path does not
+        apply (losses on the host, an empty ring, more than 64 subnetworks): the caller then uses get_weights() / add()."""
+        if not loss.is_cuda or self.buffer_size == 0 or self.subnetworks > 64 or not _FUSED_STEP:
+            return None
+        # a subclass or an instance that replaces get_weights / add (fixed weights in the parity tests, a custom schedule)
+        # keeps its say: the fused kernel only stands in for THIS class's arithmetic
+        cls = type(self)
+        if (cls.get_weights is not LossBuffer.get_weights or cls.add is not LossBuffer.add or cls.get_mean is not LossBuffer.get_mean
+                or "get_weights" in self.__dict__ or "add" in self.__dict__ or "get_mean" in self.__dict__):
+            return None
+        if self.buffer.device != loss.device:
+            self.buffer = self.buffer.to(loss.device)  # once: the ring lives where the losses are produced
+        from ...engine import loss_buffer_step
+        res = loss_buffer_step(self.buffer, self.index, self.temperature, loss)
+        self.index = (self.index + 1) % self.buffer_size
+        return res
 
     def get_mean(self) -> torch.Tensor:
         if self.buffer_size == 0:

@@ -119,13 +119,17 @@ class MimoUnetModel(LightningModule):
         out, loss = self.model.forward_with_loss(image, label, mask, perms)
         half = self.out_channels // 2
         p1, p2 = out[:, :, :half, ...], out[:, :, half:, ...]
-        weights = self.loss_buffer.get_weights().to(loss.device)  # read BEFORE the add (mimo_unet.py:243-245)
-        self.loss_buffer.add(loss.detach())
-        loss_weighted = loss * weights
-        loss_mean = loss_weighted.mean()  # the differentiable scalar, outside the no_grad section below
+        fused = self.loss_buffer.step(loss)  # weights read BEFORE the add (mimo_unet.py:243-245), one kernel
+        if fused is not None:
+            loss_mean, weights, train_loss = fused
+        else:
+            weights = self.loss_buffer.get_weights().to(loss.device)
+            self.loss_buffer.add(loss.detach())
+            loss_mean = (loss * weights).mean()  # the differentiable scalar, outside the no_grad section below
+            train_loss = None
         with torch.no_grad():
             mask_t = gather_subnetworks(mask, perms)
-            self._log_train_loss_and_weights(loss.detach(), weights)
+            self._log_train_loss_and_weights(loss.detach(), weights, train_loss)
             if out.is_cuda and self.loss_name in ("laplace_nll", "gaussian_nll"):
                 # label gather, mode / std, error map and the regression metrics in one pass
                 # (engine.training_epilogue; the reference runs ~20 full-tensor torch ops here)
@@ -228,8 +232,8 @@ class MimoUnetModel(LightningModule):
     def _log(self, name, value, **kw):
         self.log(name, value, batch_size=self._batch_size(), **kw)
 
-    def _log_train_loss_and_weights(self, loss: torch.Tensor, weights: torch.Tensor) -> None:
-        self._log("train_loss", loss.mean())
+    def _log_train_loss_and_weights(self, loss: torch.Tensor, weights: torch.Tensor, loss_mean: Optional[torch.Tensor] = None) -> None:
+        self._log("train_loss", loss.mean() if loss_mean is None else loss_mean)
         for i in range(loss.shape[0]):
             self._log(f"train_loss_{i}", loss[i])
             self._log(f"train_weight_{i}", weights[i])

@@ -36,8 +36,8 @@ def is_prebn_bias(k):
 
 def check_grads(named_grads, ref_grads, tol=TOL):
     """Per-tensor max error relative to the tensor's scale.  The north_star's tolerance is 1e-3; the checks against the
-    reference GOLDENS pass `golden_grad_tol(precision)` — 3e-4 for the fp32 mode and the three-MFMA weight gradient, 8e-4
-    for the two-MFMA weight gradient (observed <= 1.7e-4 / 1.1e-4 / 6.2e-4, profiles/r05/parity_errors.txt): a precision
+    reference GOLDENS pass `golden_grad_tol(precision)` — 3e-4 for the fp32 mode, 5e-4 with the three-MFMA weight gradient,
+    8e-4 with the two-MFMA weight gradient (observed <= 1.7e-4 / 3.6e-4 / 6.2e-4, tests/helpers.py): a precision
     trade shows as a red test before it reaches the headline tolerance."""
     worst = ("", 0.0)
     for k, ref in ref_grads.items():
