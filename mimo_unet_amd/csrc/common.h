@@ -89,7 +89,19 @@ struct ConvLaunch {
   // fp16 weight images (modes 1 and 6): device word with the float bits of the layer's max |w| the image was packed with
   // (w16_scale); nullptr: the image carries the fixed 2^8 (per-operator entry points)
   const unsigned* wmax = nullptr;
+  // > 1 (wave-specialised 256-pixel kernel, split16 modes 0 / 1, cin_p a multiple of 32; conv3x3_ksplit): the K walk over
+  // the input channels is split ksplit-fold across workgroups; slab k of y — [ksplit][N][Ho][Wo][ldy] — receives the partial
+  // sums of chunk range k (bias, stats and the inference epilogue must be null: conv_ksplit_reduce_launch adds them up)
+  int ksplit = 1;
 };
+// K split of a launch by cost (1 = none): few pixel tiles and a long K walk — the 16x16 / 32x32 layers at a few images per
+// GPU — finish sooner as wide channel tiles on ksplit x the workgroups plus one reduction pass than as narrow channel tiles
+// whose every phase is mostly fixed cost.  MIMO_CONV_KSPLIT: 0 = never, n >= 2 = n wherever the geometry allows (tests).
+int conv3x3_ksplit(int mode, int N, int cin_p, int cout_pad, int Ho, int Wo);
+// conv3x3_bf16x3_launch with the K split of conv3x3_ksplit when kpart (>= kpart_floats floats of scratch) can hold its
+// slabs: the partial launch, then out = bias + sum of the slabs with the BatchNorm partial rows (forward) in one pass
+int conv3x3_bf16x3_launch_k(const ConvLaunch& a, int mode, int* rows, hipStream_t stream, float* kpart, size_t kpart_floats);
+size_t conv3x3_ksplit_scratch(int mode, int N, int cin_p, int cout_pad, int Ho, int Wo, int ldy);  // floats; 0: no split
 // 1 when conv3x3_bf16x3_launch(mode) runs this launch on a kernel whose loaders can apply ConvLaunch::in_scale / in_shift
 int conv3x3_split_fuses_input(int mode, int wide, int Ho, int Wo);
 // returns number of partial-stat rows (spatial blocks) through *rows when stats != nullptr

@@ -465,11 +465,19 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #else
   constexpr int abl = 0;
 #endif
-  const int v_ = xcd_order ? xcd_virtual_index((int)blockIdx.x, gx * coTiles) : (int)blockIdx.x;
-  const int vbx = v_ / coTiles;
-  const int co0 = (v_ - vbx * coTiles) * NB;
+  // K split (ConvLaunch::ksplit > 1; round 6): the workgroups of a (pixel-tile column, channel tile) pair come ksplit-fold, each
+  // walks nck consecutive 32-channel chunks from ck0 and stores its partial sums into slab ks of a.y; ksplit == 1: ck0 = 0,
+  // nck = nchunks, one slab — the arithmetic below is then the old one.  Virtual order: (column, split, channel tile), so
+  // the channel tiles that read the same input chunks stay neighbours.
+  const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+  const int v_ = xcd_order ? xcd_virtual_index((int)blockIdx.x, gx * coTiles * ksplit) : (int)blockIdx.x;
+  const int vks_ = v_ / coTiles;
+  const int vbx = vks_ / ksplit, ks = vks_ - vbx * ksplit;
+  const int co0 = (v_ - vks_ * coTiles) * NB;
+  const int cpk_ = (nchunks + ksplit - 1) / ksplit;
+  const int ck0 = ks * cpk_, nck = min(cpk_, nchunks - ck0);  // (the launch guarantees nck >= 1)
   const int ntiles_mine = vbx < numTiles ? (numTiles - 1 - vbx) / gx + 1 : 0;
-  const int nstages = ntiles_mine * nchunks;  // input-tile stages (tile, chunk); 3 phases each
+  const int nstages = ntiles_mine * nck;  // input-tile stages (tile, chunk); 3 phases each
 
   if (wave >= 4) {
     // =============================== producers ===============================
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     f32x4 in_sc = f32x4{0.f, 0.f, 0.f, 0.f}, in_sh = in_sc, in_sc_n = in_sc, in_sh_n = in_sc;
 #define WS_LOAD_SS(SC, SH, STAGE)                                                                    \
   if (FIN) {                                                                                         \
-    const int c_ = ((STAGE) % nchunks) * 32 + 4 * (ptid & 7);                                        \
+    const int c_ = (ck0 + (STAGE) % nck) * 32 + 4 * (ptid & 7);                                      \
     /* UNCONDITIONAL (kFinSlack zero floats behind the layer's channels, plan.hip): exactly two loads per stage */ \
     SC = *reinterpret_cast<const f32x4*>(a.in_scale + c_);                                           \
     SH = *reinterpret_cast<const f32x4*>(a.in_shift + c_);                                           \
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #define WS_LOAD_X(K0, K1, STAGE)                                                                     \
   {                                                                                                  \
     const int st_ = (STAGE);                                                                         \
-    const int ti_ = st_ / nchunks, ck_ = st_ - ti_ * nchunks;                                        \
+    const int ti_ = st_ / nck, ck_ = ck0 + st_ - ti_ * nck;                                          \
     int t_ = vbx + ti_ * gx;                                                                         \
     const int tx_ = t_ % tilesX;                                                                     \
     t_ /= tilesX;                                                                                    \
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #define WS_LOAD_W(SLOT, PH)                                                                          \
   {                                                                                                  \
     const int phw_ = (PH);                                                                           \
-    const int ck_ = (phw_ / 3) % nchunks, r_ = phw_ % 3;                                             \
+    const int ck_ = ck0 + (phw_ / 3) % nck, r_ = phw_ % 3;                                           \
     _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                              \
       const int u_ = min(ptid + k_ * 256, WUNITS - 1);                                               \
       const int t_ = u_ / (NB * 8);                                                                  \
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
 #define WS_DMA_W(BUF, PH)                                                                            \
   {                                                                                                  \
     const int phw_ = (PH);                                                                           \
-    const int ck_ = (phw_ / 3) % nchunks, r_ = phw_ % 3;                                             \
+    const int ck_ = ck0 + (phw_ / 3) % nck, r_ = phw_ % 3;                                           \
     const u32x4* src_ = wpk + ((size_t)(ck_ * 9 + r_ * 3) * a.cout_pad + co0) * 8;                   \
     _Pragma("unroll") for (int k_ = 0; k_ < WU; ++k_) {                                              \
       if (ptid + k_ * 256 < WUNITS) { /* a multiple of 128 units: whole waves */                     \
@@ -866,7 +874,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     const int ty_ = t_ % tilesY;                                                                     \
     const int n_ = t_ / tilesY;                                                                      \
     const int y0_ = ty_ * TR, x0_ = tx_ * TC;                                                        \
-    OT* yimg = reinterpret_cast<OT*>(a.y) + (size_t)n_ * a.Ho * a.Wo * a.ldy + co0 + g * 4;          \
+    OT* yimg = reinterpret_cast<OT*>(a.y) + ((size_t)ks * a.N + n_) * a.Ho * a.Wo * a.ldy + co0 + g * 4; \
     if (abl & 32) { /* timing only: keep the accumulators alive, no stores / arithmetic per element */ \
       f32x4 k_ = acc[0][0];                                                                          \
       _Pragma("unroll") for (int m = 0; m < MF; ++m)                                                 \
@@ -940,7 +948,7 @@ __global__ __launch_bounds__(512, (MF_ == 2 && NF <= 2) ? 4 : 2) void conv3x3_ws
     C_TAP(0, (P) ^ 1, false)                                                                         \
     C_TAP(1, P, false)                                                                               \
     C_TAP(2, (P) ^ 1, true)                                                                          \
-    tile_done = r_ == (PAIR ? 1 : 2) && (j_ + 1) % nchunks == 0;                                     \
+    tile_done = r_ == (PAIR ? 1 : 2) && (j_ + 1) % nck == 0;                                         \
     ++ph;                                                                                            \
     if (PAIR) { /* third phase of a paired chunk: nothing to multiply */                             \
       if (ph < nphases && ph % 3 == 2 && (ph / 3 + 1) % nchunks == 0) {                              \
@@ -1034,12 +1042,21 @@ static int launch_ws(const ConvLaunch& a, int* rows, hipStream_t stream) {
   // persistent: one workgroup per CU (two for the 128-pixel / <= 32-channel instances), every workgroup of a
   // launch walks the same number of tiles
   constexpr int kWgPerCU = (MF == 2 && NF <= 2) ? 2 : 1;
-  int gx = max(1, 256 * kWgPerCU / coTiles);
+  const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+  if (ksplit > 1) {
+    const int nchunks = ceil_div(a.cin_p, 32), cpk = ceil_div(nchunks, ksplit);
+    if (MODE > 1 || a.pair || a.bias || a.stats || a.ep_scale || a.cin_p % 32 != 0 || cpk * (ksplit - 1) >= nchunks) {
+      set_error("conv3x3 split: K split %d needs a split16 launch without bias / stats / epilogue, whole 32-channel chunks "
+                "and at least one chunk per split (cin_p %d)", ksplit, a.cin_p);
+      return MIMO_ERR_INVALID;
+    }
+  }
+  int gx = max(1, 256 * kWgPerCU / (coTiles * ksplit));
   if (gx > numTiles) gx = numTiles;
   const int per = ceil_div(numTiles, gx);
   gx = ceil_div(numTiles, per);
   if (rows) *rows = gx;  // one partial-statistics row per workgroup
-  dim3 grid(gx * coTiles);
+  dim3 grid(gx * coTiles * ksplit);
   static const int xcd_ = !(getenv("MIMO_CONV_XCD_ORDER") && atoi(getenv("MIMO_CONV_XCD_ORDER")) == 0);
   // MIMO_CONV_WDMA=0: weights staged through registers (ds_write) as before
   static const bool wdma = !(getenv("MIMO_CONV_WDMA") && atoi(getenv("MIMO_CONV_WDMA")) == 0);
@@ -1117,7 +1134,7 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
     // batch of a strong-scaling run) finishes sooner with narrow channel tiles on many CUs than with wide ones on a
     // few: time ~ (tiles per workgroup) x (per-phase fixed cost + NF x MFMA time), fixed cost ~ one NF unit.
     static const bool adapt = !(getenv("MIMO_CONV_ADAPTIVE_NF") && atoi(getenv("MIMO_CONV_ADAPTIVE_NF")) == 0);
-    if (adapt) {
+    if (adapt && a.ksplit <= 1) {  // (a K split keeps the widest channel tile: conv3x3_ksplit priced it that way)
       int TR, TC;
       pick_tile_n(a.Ho, a.Wo, WsTile<4>::NPIX, WsTile<4>::MAXPIX, &TR, &TC);
       const int numTiles = a.N * ceil_div(a.Ho, TR) * ceil_div(a.Wo, TC);
@@ -1162,6 +1179,116 @@ static int conv3x3_split_dispatch(const ConvLaunch& a, int* rows, hipStream_t st
     case 2: return launch_bf16x3<2, 2, MODE>(a, rows, stream);
     default: return launch_bf16x3<2, 1, MODE>(a, rows, stream);
   }
+}
+
+// ---- K split (round 6) ------------------------------------------------------------------------------------------
+// Cost in the units of the channel-tile rule above: a phase of a persistent workgroup costs (1 + NF) — one unit of fixed
+// cost (barrier, pipeline latency) and one per 16-channel fragment of MFMA work.  Unsplit: the rule's own optimum over NF.
+// Split ks-fold: the widest channel tile, ceil(nchunks / ks) chunks per workgroup, plus the reduction pass (priced at
+// kKsplitReduceUnits: one more launch over ks + 1 small tensors).  Taken when it wins by >= 15 %.
+constexpr int kKsplitReduceUnits = 14;
+int conv3x3_ksplit(int mode, int N, int cin_p, int cout_pad, int Ho, int Wo) {
+  static const int force = [] { const char* e = getenv("MIMO_CONV_KSPLIT"); return e ? atoi(e) : -1; }();
+  static const bool wdma = !(getenv("MIMO_CONV_WDMA") && atoi(getenv("MIMO_CONV_WDMA")) == 0);
+  if (force == 0 || (mode != 0 && mode != 1) || !conv_ws_enabled() || !wdma || Ho * Wo < 256 || cin_p % 32 != 0 ||
+      cout_pad % 16 != 0)
+    return 1;
+  const int nchunks = cin_p / 32;
+  if (nchunks < 2) return 1;
+  auto legal = [&](int ks) { return ks >= 2 && ceil_div(nchunks, ks) * (ks - 1) < nchunks; };
+  if (force >= 2) {
+    int ks = min(force, nchunks);
+    while (ks >= 2 && !legal(ks)) --ks;
+    return ks >= 2 ? ks : 1;
+  }
+  int TR, TC;
+  pick_tile_n(Ho, Wo, WsTile<4>::NPIX, WsTile<4>::MAXPIX, &TR, &TC);
+  const int numTiles = N * ceil_div(Ho, TR) * ceil_div(Wo, TC);
+  const int nfr = cout_pad / 16;
+  long unsplit = -1;
+  for (int c = 4; c >= 1; --c) {
+    if (nfr % c) continue;
+    const int gx = max(1, min(numTiles, 256 / (nfr / c)));
+    const long cost = (long)ceil_div(numTiles, gx) * (1 + c) * nchunks * 3;
+    if (unsplit < 0 || cost < unsplit) unsplit = cost;
+  }
+  int nf = 4;
+  while (nfr % nf != 0) --nf;
+  const int coTiles = nfr / nf;
+  int best = 1;
+  long best_cost = -1;
+  for (int ks = 2; ks <= 8 && ks <= nchunks; ++ks) {
+    if (!legal(ks) || coTiles * ks > 256) continue;
+    const int gx = max(1, min(numTiles, 256 / (coTiles * ks)));
+    const long cost = (long)ceil_div(numTiles, gx) * (1 + nf) * ceil_div(nchunks, ks) * 3 + kKsplitReduceUnits;
+    if (best_cost < 0 || cost < best_cost) best_cost = cost, best = ks;
+  }
+  return (best_cost >= 0 && best_cost * 100 < unsplit * 85) ? best : 1;
+}
+
+size_t conv3x3_ksplit_scratch(int mode, int N, int cin_p, int cout_pad, int Ho, int Wo, int ldy) {
+  const int ks = conv3x3_ksplit(mode, N, cin_p, cout_pad, Ho, Wo);
+  return ks > 1 ? (size_t)ks * N * Ho * Wo * ldy : 0;
+}
+
+// out[p][c] = bias[c] + sum over the slabs of part[k][p][c]; stats != nullptr: one row [2][cout_pad] of (sum, sum of squares)
+// per workgroup, the layout of the convolution epilogue's BatchNorm partial rows.  256 threads = QB channel quads x PPI pixels.
+__global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const float* __restrict__ part, int ksplit, int P, int ld, int Cv,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int ldo, float* __restrict__ stats, int cout_pad) {
+  __shared__ f32x4 red[2][256];
+  const int QB = Cv < 256 ? Cv : 256, PPI = 256 / QB;
+  const int ql = threadIdx.x % QB, pl = threadIdx.x / QB;
+  const int q = blockIdx.y * QB + ql;
+  const bool active = pl < PPI && q < Cv;
+  f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  if (active) {
+    const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t slab = (size_t)P * ld;
+    for (int p = blockIdx.x * PPI + pl; p < P; p += gridDim.x * PPI) {
+      const float* src = part + (size_t)p * ld + 4 * q;
+      f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(src + k * slab);
+      v += b;
+      *reinterpret_cast<f32x4*>(out + (size_t)p * ldo + 4 * q) = v;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  if (!stats) return;
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (pl == 0 && q < Cv) {
+    for (int i = 1; i < PPI; ++i) {
+      s1 += red[0][i * QB + ql];
+      s2 += red[1][i * QB + ql];
+    }
+    float* row = stats + (size_t)blockIdx.x * 2 * cout_pad;
+    *reinterpret_cast<f32x4*>(row + 4 * q) = s1;
+    *reinterpret_cast<f32x4*>(row + cout_pad + 4 * q) = s2;
+  }
+}
+
+int conv3x3_bf16x3_launch_k(const ConvLaunch& a, int mode, int* rows, hipStream_t stream, float* kpart, size_t kpart_floats) {
+  const int ks = (a.wide || a.ep_scale || !kpart) ? 1 : conv3x3_ksplit(mode, a.N, a.cin_p, a.cout_pad, a.Ho, a.Wo);
+  const size_t need = (size_t)ks * a.N * a.Ho * a.Wo * a.ldy;
+  if (ks <= 1 || a.pair || need > kpart_floats || a.cout_store % 4 != 0 || a.ldy % 4 != 0 || (size_t)a.N * a.Ho * a.Wo > (1u << 30))
+    return conv3x3_bf16x3_launch(a, mode, rows, stream);
+  ConvLaunch p = a;
+  p.y = kpart;
+  p.bias = nullptr;
+  p.stats = nullptr;
+  p.ksplit = ks;
+  MIMO_TRY(conv3x3_bf16x3_launch(p, mode, nullptr, stream));
+  const int P = a.N * a.Ho * a.Wo, Cv = a.cout_store / 4;
+  const int QB = Cv < 256 ? Cv : 256, PPI = 256 / QB;
+  const int gx = max(1, min(ceil_div(P, PPI * 2), 256));  // <= 256 partial rows, >= 2 pixels per thread
+  if (rows) *rows = gx;
+  hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(gx, ceil_div(Cv, QB)), dim3(256), 0, stream, kpart, ks, P, a.ldy, Cv, a.bias,
+                     a.y, a.ldy, a.stats, a.cout_pad);
+  MIMO_KERNEL_CHECK();
+  return MIMO_OK;
 }
 
 // mode: see MIMO_CONV_MODE_CONSTANTS (0 split16 dgrad, 1 split16 forward, 2 bf16 forward, 3 bf16 dgrad)

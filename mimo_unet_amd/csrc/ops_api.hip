@@ -167,9 +167,12 @@ int mimo_op_conv3x3_forward(const float* x, const float* w, const float* bias, f
   // (an image convolution — <= 4 input channels in an 8-channel pixel — runs on the plain-FMA kernel, as in the plan)
   if (!mixed && cin_p < 16 && conv3x3_thin_ok(cin, cout_p))
     MIMO_TRY(conv3x3_thin_launch(a, cin, &rows, st));
-  else if (split)
-    MIMO_TRY(conv3x3_bf16x3_launch(a, fmode, &rows, st));
-  else
+  else if (split) {
+    // (with the K split the plan would use for this geometry, conv3x3_ksplit: scratch for its partial slabs)
+    const size_t kfl = (mixed || wide) ? 0 : conv3x3_ksplit_scratch(fmode, n, cin_p, cout_pad, h, wd, cout_p);
+    float* kpart = kfl ? t.get<float>(kfl) : nullptr;
+    MIMO_TRY(conv3x3_bf16x3_launch_k(a, fmode, &rows, st, kpart, kfl));
+  } else
     MIMO_TRY(conv3x3_launch(a, &rows, st));
   if (mixed) MIMO_TRY(from16(z16, z, nz, f16s, st));
   if (stats) {
@@ -253,9 +256,11 @@ int mimo_op_conv3x3_dgrad(const float* dz, const float* w, float* dx, int32_t n,
   a.wpk = wpk;
   a.pair = pair;
   a.wide = wide;
-  if (split)
-    MIMO_TRY(conv3x3_bf16x3_launch(a, dmode, nullptr, st));
-  else
+  if (split) {
+    const size_t kfl = (mixed || wide) ? 0 : conv3x3_ksplit_scratch(dmode, n, cout_p, rows_pad, h + 2, wd + 2, cin_p);
+    float* kpart = kfl ? t.get<float>(kfl) : nullptr;
+    MIMO_TRY(conv3x3_bf16x3_launch_k(a, dmode, nullptr, st, kpart, kfl));
+  } else
     MIMO_TRY(conv3x3_launch(a, nullptr, st));
   if (mixed) {
     MIMO_TRY(fold_slice_launch(dxpad, f16s ? ST_F16 : ST_BF16, cin_p, 0, dx16, cin_p, n, h, wd, cin_p, 0, st));

@@ -183,6 +183,8 @@ struct mimo_plan {
   ColsumScratch colsum() const { return ColsumScratch{s_sums, s_tickets, d_status}; }
   int* d_status = nullptr;  // numerics status word (mimo_plan_status)
   size_t cap_act = 0, cap_pad = 0, cap_slab = 0, cap_partial = 0, cap_sums = 0;
+  float* s_kpart = nullptr;  // partial-sum slabs of the K-split convolution launches (conv3x3_bf16x3_launch_k)
+  size_t cap_kpart = 0;
 
   // MIMO_WGRAD_STREAM (default 1): weight gradients on a side stream — wgrad(L) (matrix-pipe bound, little HBM
   // traffic) overlaps the bandwidth-bound BatchNorm / gather kernels of the layers below it on the caller's stream;
@@ -489,6 +491,12 @@ struct mimo_plan {
     if (cfg.precision == MIMO_PREC_SPLIT16 || mixed) {  // decomposition per layer and direction (sched::wide_config)
       if (L.fwd_split) L.fwd_wide = conv3x3_wide_rows(fwd_mode(), n, L.cin_p, L.cout_p, h, w);
       if (L.dg_split) L.dg_wide = conv3x3_wide_rows(dgrad_mode(), n, L.cout_p, L.cin_p, h + 2, w + 2);
+    }
+    if (cfg.precision == MIMO_PREC_SPLIT16) {  // K split of the few-tile / long-K launches (conv3x3_ksplit): scratch for the slabs
+      if (L.fwd_split && !L.fwd_wide && !cfg.inference_only)
+        cap_kpart = std::max(cap_kpart, conv3x3_ksplit_scratch(fwd_mode(), n, L.cin_p, L.cout_pad, h, w, L.cout_p));
+      if (L.dg_split && !L.dg_wide && train_bufs)
+        cap_kpart = std::max(cap_kpart, conv3x3_ksplit_scratch(dgrad_mode(), n, L.cout_p, L.dg_rows, h + 2, w + 2, L.cin_p));
     }
     if (L.fwd_split && (cfg.precision == MIMO_PREC_SPLIT16 || cfg.precision == MIMO_PREC_FP16_MIXED)) {
       // one array for all layers' words: every pack zeroes it in one memset and takes the maxima afresh (pack_all)
@@ -835,6 +843,7 @@ struct mimo_plan {
     MIMO_TRY(alloc_act(&s_dxpadA, cap_pad, st));
     MIMO_TRY(alloc_act(&s_dxpadB, cap_pad, st));
     MIMO_TRY(dalloc(&s_wslab, cap_slab));
+    if (cap_kpart) MIMO_TRY(dalloc(&s_kpart, cap_kpart));
     MIMO_TRY(dalloc(&s_partial, cap_partial));
     if (fuse_bwd_src) MIMO_TRY(dalloc(&s_headpart, (size_t)kBnReduceMaxBlocks * (2 * pad_channels(f) + 2)));
     MIMO_TRY(dalloc(&s_sums, cap_sums));
@@ -1001,8 +1010,8 @@ struct mimo_plan {
     a.pair = (L.fwd_split && !L.fwd_wide) ? conv3x3_pair_tail(fwd_mode(), L.cin_p, L.H, L.W) : 0;
     a.wide = L.fwd_wide;
     int pr = prof_begin(MIMO_PROF_CONV_FWD, st);
-    if (L.fwd_split)
-      MIMO_TRY(conv3x3_bf16x3_launch(a, fwd_mode(), &rows, st));
+    if (L.fwd_split)  // (training forward: with the K split of conv3x3_ksplit where that pays — few tiles, a long K walk)
+      MIMO_TRY(conv3x3_bf16x3_launch_k(a, fwd_mode(), &rows, st, (training && !fused) ? s_kpart : nullptr, cap_kpart));
     else if (L.thin)
       MIMO_TRY(conv3x3_thin_launch(a, L.Cin, &rows, st));
     else
@@ -1415,7 +1424,7 @@ struct mimo_plan {
       a.wide = L.dg_wide;
       pr = prof_begin(MIMO_PROF_CONV_DGRAD, st);
       if (L.dg_split)
-        MIMO_TRY(conv3x3_bf16x3_launch(a, dgrad_mode(), nullptr, st));
+        MIMO_TRY(conv3x3_bf16x3_launch_k(a, dgrad_mode(), nullptr, st, s_kpart, cap_kpart));
       else
         MIMO_TRY(conv3x3_launch(a, nullptr, st));
       prof_end(pr, 18.0 * L.Cin * L.Cout * (double)P, 4.0 * (double)P * (L.Cin + L.Cout), st);

@@ -48,6 +48,10 @@ CONV_CASES = [
     # workgroup with a half-empty last one, odd sizes, a 3-chunk input with a short tail, many images
     (2, 64, 64, 60, 60), (1, 64, 96, 45, 30), (3, 32, 32, 120, 72), (1, 48, 40, 90, 45), (12, 32, 32, 48, 96),
     (1, 37, 53, 40, 100),
+    # K split of the wave-specialised kernel (round 6, conv3x3_ksplit: few pixel tiles, a long K walk — the deep layers at a few
+    # images per GPU): the cost rule takes it on these (forward and data gradient); tests/test_variants_gpu.py::conv_ksplit_forced
+    # forces it on every geometry with whole 32-channel chunks (odd split counts, one chunk per split)
+    (4, 16, 16, 480, 480), (2, 32, 32, 960, 240), (1, 16, 16, 256, 96),
 ]
 
 

@@ -34,6 +34,9 @@ VARIANTS = {
     },
     "conv_wide_forced": {"MIMO_CONV_WIDE": "2"},  # every supported convolution on conv_wide.hip
     "image_conv_wgrad_forced": {"MIMO_CONV_THIN": "2"},  # 1-2-channel weight gradients on conv_thin.hip at every size
+    # K split (conv3x3_ksplit) forced three-fold wherever a launch has whole 32-channel chunks (cfg1's 32 / 64 / 128-channel
+    # layers; the 64- and 96-channel operator cases: a last split with one chunk)
+    "conv_ksplit_forced": {"MIMO_CONV_KSPLIT": "3"},
     # the three-MFMA bf16-pair weight gradient of rounds 1-4 (the tests then apply its tighter bounds: tests/helpers.py)
     "wgrad_three_mfma": {"MIMO_WGRAD_NP": "3"},
 }
