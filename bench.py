@@ -364,6 +364,8 @@ def main():
             adam_events.append((e0, e1))
         return out["loss"]
 
+    host_loop_s = []
+
     def timed_pass(r=None):
         """--warmup untimed steps, then EXACTLY --steps steps between barrier + synchronize; max over ranks"""
         for i in range(args.warmup):
@@ -374,6 +376,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             loss = step(i, r=r)
+        host_loop_s.append(time.perf_counter() - t0)  # the host has enqueued every step (it may run ahead of the GPU)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -497,6 +500,9 @@ def main():
                               f"the step waited for its worker {prefetcher.starved} times, {prefetcher.pageable_uploads} tensors from pageable memory"),
                    # host time to enqueue one step on an idle GPU (rank 0): well below ms_per_step = the GPU, not the launch path, bounds the step
                    "host_enqueue_ms_per_step": None if host_enqueue_ms is None else round(host_enqueue_ms, 3),
+                   # host time of the TIMED loop per step, up to the point where every step was enqueued (below ms_per_step: the
+                   # host ran ahead of the GPU; equal to it: the launch path — or a back-pressure wait — paces the step)
+                   "host_loop_ms_per_step": round(host_loop_s[0] / args.steps * 1e3, 3),
                    "streams": ("weight gradients on the caller's stream" if os.environ.get("MIMO_WGRAD_STREAM") == "0" else
                                "weight gradients on a side stream beside the BatchNorm-backward kernels of the layer below "
                                "(MIMO_WGRAD_STREAM=1, default); the second pass that times the kernel classes serialises them")},

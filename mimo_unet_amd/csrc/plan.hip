@@ -833,7 +833,23 @@ struct mimo_plan {
       }
       if (wg_async) {
         for (int i = 1; i < wg_bufs; ++i) MIMO_TRY(alloc_act(&s_dz2[i], cap_act, st));
-        MIMO_HIP_CHECK(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
+        // LOWEST stream priority — not for the scheduling (round 4 measured no effect of the priority on the step) but for the
+        // hardware queue: the runtime deals streams of one priority class round-robin onto a handful of hardware queues
+        // (4 by default), and a side stream that lands on the caller's queue is silently serialised behind it — seen in
+        // round 6 in bench.py's one-rank RCCL route, where the process group's streams had taken the other queues: no
+        // overlap at all, 5.8 instead of 4.4 ms per step at 4 images per GPU (profiles/r06/b4/queue_collision.txt).  The
+        // priority classes draw from separate queue pools, and callers run on default-priority streams.
+        // MIMO_WGRAD_STREAM_PRIORITY=0 restores a default-priority stream (A/B).
+        {
+          int least = 0, greatest = 0;
+          MIMO_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+          const char* pe = getenv("MIMO_WGRAD_STREAM_PRIORITY");
+          const bool low = !(pe && atoi(pe) == 0) && least != greatest;
+          if (low)
+            MIMO_HIP_CHECK(hipStreamCreateWithPriority(&wg_stream, hipStreamNonBlocking, least));
+          else
+            MIMO_HIP_CHECK(hipStreamCreateWithFlags(&wg_stream, hipStreamNonBlocking));
+        }
         for (int i = 0; i < wg_bufs; ++i)
           for (hipEvent_t* e : {&ev_dz[i], &ev_wg[i]}) MIMO_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         MIMO_HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));

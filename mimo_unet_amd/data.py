@@ -84,7 +84,10 @@ class DevicePrefetcher:
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.batches, self.depth = batches, int(depth)
-        self.copy_stream = torch.cuda.Stream(self.device)
+        # high priority: not for the scheduling but for the hardware queue — streams of one priority class share a handful
+        # of hardware queues, and a copy stream that lands on the training stream's queue is serialised with its kernels
+        # (csrc/plan.hip, the side stream; profiles/r06/b4/queue_collision.txt); the priority classes use separate pools
+        self.copy_stream = torch.cuda.Stream(self.device, priority=-1)
         # "host": the worker waits for the slot events itself; "gpu": stream waits (kept for the A/B, see the module text)
         self.handoff = os.environ.get("MIMO_PREFETCH_HANDOFF", "host")
         if self.handoff not in ("host", "gpu"):
