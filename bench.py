@@ -145,7 +145,7 @@ def pmc_traffic():
     return pt, rel
 
 
-def cpu_baseline(c, batch=8, warmup=2, steps=5, threads=None):
+def cpu_baseline(c, batch=8, warmup=2, steps=5, threads=None, labels="uniform"):
     """The CPU oracle (restatement of the reference's step, pinned to reference goldens) on the host cores of
     this box: same network shape, SURVEY 8(d)'s bounded sample (batch 8, 2 warm-up + 5 timed steps, ~20 s).
     Thread count: torch's CPU convolutions stop scaling (and collapse when oversubscribed) well below this
@@ -158,7 +158,7 @@ def cpu_baseline(c, batch=8, warmup=2, steps=5, threads=None):
     ts = O.TrainState(cfg=cfg, st=O.init_state(cfg, 1), loss_buffer=O.LossBuffer(c["S"], 0.3, 10))
     g = torch.Generator().manual_seed(1)
     image = torch.rand(batch, c["Ci"], c["H"], c["W"], generator=g)
-    label = learnable_label(image, generator=g)
+    label = learnable_label(image, generator=g) if labels == "learnable" else torch.rand(batch, 1, c["H"], c["W"], generator=g)
     times = []
     for i in range(warmup + steps):
         perms = O.draw_perms(batch, c["S"], generator=g)
@@ -589,7 +589,7 @@ def main():
                                   "ms_per_step": round(sum(k["ms_per_step"] for k in bw_kernels.values()), 2),
                                   "kernels": bw_kernels}}
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(c)
+        line["cpu_baseline"] = cpu_baseline(c, labels=args.labels)
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

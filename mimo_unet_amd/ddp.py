@@ -100,7 +100,7 @@ class FlatGradientAllReducer:
         for lo in range(begin, end, self.bucket_floats):
             hi = min(end, lo + self.bucket_floats)
             self.issued.append((lo, hi))
-            if self.algorithm == "reduce_scatter" and self.world_size > 1:
+            if self.algorithm == "reduce_scatter" and (self.world_size > 1 or self.always):
                 self._issue_reduce_scatter(flat, lo, hi)
             else:
                 self._pending.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
