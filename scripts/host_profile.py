@@ -55,7 +55,7 @@ for i in range(steps):
 th = time.perf_counter() - t0
 torch.cuda.synchronize()
 tg = time.perf_counter() - t0
-print(f"batch {batch} ddp {int(ddp)} graph {os.environ.get('MIMO_TRAIN_GRAPH', '1')}: host loop {th / steps * 1e3:.3f} ms/step, "
+print(f"batch {batch} ddp {int(ddp)} graph {os.environ.get('MIMO_TRAIN_GRAPH', '0')}: host loop {th / steps * 1e3:.3f} ms/step, "
       f"with the GPU drained {tg / steps * 1e3:.3f} ms/step")
 # the backward runs on autograd's own thread (cProfile does not see it): time its layers by hand
 from mimo_unet_amd.engine import Plan

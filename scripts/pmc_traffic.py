@@ -34,7 +34,7 @@ def cls(k):
 # uncalibrated: counted x1 in `step_bytes` and x2 in `step_bytes_upper`.
 WIDE_READERS = ("conv3x3_", "wgrad_split", "wgrad_thin_kernel", "bn_relu", "bnrelu_bwd_reduce", "bn_bwd_apply", "upcat_fwd",
                 "up_bwd", "pool_bwd", "head_fwd", "head_bwd_kernel", "loss_fwd", "adam_kernel", "amp_step_kernel", "maxpool_fwd",
-                "fold_slice", "split_pairs", "train_epilogue", "val_epilogue", "elem_mask_mul", "wgrad_group_sum", "wgrad_reduce")
+                "fold_slice", "split_pairs", "conv_ksplit_reduce", "train_epilogue", "val_epilogue", "elem_mask_mul", "wgrad_group_sum", "wgrad_reduce")
 
 
 def read_factor(kernel):
