@@ -164,6 +164,10 @@ def _release_plan(plan, generation: int) -> None:
         plan.pending = None
 
 
+def _guard_after_load(module, incompatible_keys) -> None:
+    module.guard_fp16_range()
+
+
 class MimoUNet(nn.Module):
     """Multiple-input multiple-output U-Net: S private encoders -> shared core on the channel
     concat -> S private decoders/heads.  Same constructor as the reference's class."""
@@ -213,6 +217,30 @@ class MimoUNet(nn.Module):
         # (FlatAdam's HIP kernel, the engine's running-stat update); together with the tensors' own
         # torch version counters it forms mimo_forward_args.param_version
         self._param_epoch = 1
+        self.precision_guard = None  # (from, to, bound) once guard_fp16_range() has switched the precision mode
+        # after a (partial) load of this subtree: do the loaded BatchNorm parameters fit the fp16 operands of the mode?
+        self.register_load_state_dict_post_hook(_guard_after_load)
+
+    # ---- copies / pickles ----------------------------------------------------------------------
+    # Everything the engine derives from the parameters is transient: plans (ctypes handles into libmimo_hip.so), the flat
+    # storage the parameters are views of, cached module lists, hooks of a data-parallel reducer.  `copy.deepcopy(model)`
+    # (EMA / SWA callbacks) and `torch.save(model)` take the module tree with its parameters and buffers; the copy rebuilds
+    # the rest at its first forward.
+    _TRANSIENT = {"_plans": None, "_flat_params": None, "_flat_grads": None, "_flat_buffers": None, "_flat_counters": None,
+                  "_flat_device": None, "_flat_probe": None, "_param_list": None, "_param_views": None, "_versioned": None,
+                  "_dc_cache": None, "_drop_cache": None, "_mask_plan": None, "_inference_keep": None, "grad_ready_hook": None,
+                  "grad_sync": None}
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._TRANSIENT:
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.update({"_plans": OrderedDict(), "_flat_params": None, "_flat_grads": None, "_flat_buffers": None,
+                              "_flat_device": None, "_param_list": [], "_versioned": [], "grad_ready_hook": None})
 
     # ---- execution order of the DoubleConvs == mimo_plan's (engine) order -----------------
     def double_convs(self) -> List[DoubleConv]:
@@ -232,10 +260,47 @@ class MimoUNet(nn.Module):
         self.double_convs()
         return self.__dict__["_drop_cache"]
 
+    # ---- fp16 range guard (round 6) --------------------------------------------------------------------------------------
+    # "split16" / "16-mixed" carry activations as fp16 operands: |a| >= 65 520 overflows where the reference's fp32
+    # convolution (components.py:23,26) stays finite.  Every activation that reaches a convolution is a BatchNorm + ReLU output
+    # a = relu(gamma * xhat + beta) (times a dropout multiplier), so the PARAMETERS bound it: |a| <= |gamma| * |xhat| + |beta|.
+    # The guard takes |xhat| <= kGuardXhat = 256 standard deviations — beyond anything a normalised tensor of real data
+    # holds, far below the sqrt(P) a single outlier can reach in theory — and when max(|gamma| * 256 + |beta|) / (1 - p) reaches
+    # fp16's range (|gamma| >= ~250: a diverged or hand-made checkpoint) it moves the WHOLE network to the mode with fp32 exponent
+    # range ("fp32" from "split16", "bf16-mixed" from "16-mixed"), with a warning.  Coarse on purpose: the per-layer remedy
+    # (a power-of-two activation scale per layer, like the weights') is not built.  Evaluated when a
+    # state_dict has been loaded and in check_numerics() (the Lightning epoch-end hooks); MIMO_FP16_RANGE_GUARD=0: off.
+    kGuardXhat = 256.0
+
+    def fp16_activation_bound(self) -> float:
+        bns = [dc.double_conv[i] for dc in self.double_convs() for i in (1, 4)]
+        with torch.no_grad():
+            tops = [(bn.weight.detach().abs() * self.kGuardXhat + bn.bias.detach().abs()).max() for bn in bns]
+            bound = float(torch.stack([t.float().cpu() if not t.is_cuda else t.float() for t in tops]).max())
+        p = max([d.p for d in self._dropout_modules()] + [0.0])
+        return bound / max(1.0 - p, 1e-3)
+
+    def guard_fp16_range(self) -> bool:
+        """True when the guard moved the network to a mode with fp32 exponent range (see above)."""
+        if os.environ.get("MIMO_FP16_RANGE_GUARD", "1") == "0" or self._geom.precision not in ("split16", "16-mixed"):
+            return False
+        bound = self.fp16_activation_bound()
+        if not bound >= 65504.0:  # (a NaN bound is a diverged run: check_numerics reports that)
+            return False
+        to = "fp32" if self._geom.precision == "split16" else "bf16-mixed"
+        logger.warning("MimoUNet: BatchNorm parameters allow activations up to %.3g (|gamma| * %g + |beta|), beyond the fp16 "
+                       "operands of precision %r; switching to %r (fp32 exponent range). MIMO_FP16_RANGE_GUARD=0 disables this.",
+                       bound, self.kGuardXhat, self._geom.precision, to)
+        self.precision_guard = (self._geom.precision, to, bound)
+        self.set_precision(to)
+        return True
+
     def set_precision(self, precision: str) -> None:
         """"fp32" (f32-input MFMA, exact) or "split16" (split-bf16 MFMA, ~1e-5 relative per product)."""
         if precision != self._geom.precision:
             self._geom = NetGeometry(**{**self._geom.__dict__, "precision": precision})
+            for plan in self._plans.values():  # what the dropped plans recorded outlives them (numerics_status ORs it in)
+                self._evicted_status = getattr(self, "_evicted_status", 0) | plan.status(True)
             self._plans.clear()
 
     def set_loss(self, loss: str) -> None:
@@ -529,15 +594,18 @@ class MimoUNet(nn.Module):
         """Raise FloatingPointError with what was recorded (see `numerics_status`); cheap enough for once per epoch.
         Under "16-mixed" a non-finite BACKWARD sum is the loss scaler's normal overflow probe (GradScaler skips that
         step and halves the scale) and is not reported."""
+        ran_in = self._geom.precision  # the mode the flags were recorded in
+        switched = self.guard_fp16_range()  # (a switch of mode drops the plans; set_precision keeps their status)
         flags = self.numerics_status(clear)
-        if self._geom.precision == "16-mixed":
+        if ran_in == "16-mixed":
             flags &= ~2
         if flags:
             what = "; ".join(msg for bit, msg in Plan.STATUS_BITS.items() if flags & bit)
             hint = ""
-            if self._geom.precision in ("split16", "16-mixed"):
-                hint = (f" (precision {self._geom.precision!r} carries fp16 operands: |activation| >= 65520 or |weight| >= 256 "
-                        "overflows; set_precision('fp32') or 'bf16-mixed' has fp32 exponent range)")
+            if ran_in in ("split16", "16-mixed"):
+                hint = (f" (precision {ran_in!r} carries fp16 operands: |activation| >= 65520 overflows"
+                        + (f"; the BatchNorm parameters now allow that, the network continues in {self._geom.precision!r}" if switched
+                           else "; set_precision('fp32') or 'bf16-mixed' has fp32 exponent range") + ")")
             raise FloatingPointError(f"MimoUNet: {what}{hint}")
 
     def mark_parameters_changed(self) -> None:

@@ -1177,13 +1177,94 @@ def test_two_forwards_then_the_first_ones_backward():
 
 
 @pytest.mark.gpu
-def test_numerics_status_reports_an_fp16_range_overflow_instead_of_silent_nans():
+def test_deepcopy_and_pickle_of_a_model_that_has_run():
+    """`copy.deepcopy(model)` (EMA / SWA callbacks) and `torch.save(model)` after the engine has built its plans and moved the
+    parameters into its flat storage: the copy takes the module tree, parameters and buffers (MimoUNet.__getstate__ leaves the
+    plans' ctypes handles, the flat views and reducer hooks behind), rebuilds the rest at its first forward, and computes the
+    same bits as the original; the original keeps training."""
+    import copy
+    import io
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    model = build_model(cfg, state_from(fx, "init/"))
+    model.train()
+    image, label, perms = (torch.from_numpy(fx[f"s0/{k}"]).cuda() for k in ("image", "label", "perms"))
+    opt = model.configure_optimizers()["optimizer"]
+    model.training_step_with_perms(image, label, None, perms)["loss"].backward()
+    opt.step()
+    twin = copy.deepcopy(model)
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    outs = [m.training_step_with_perms(image, label, None, perms) for m in (model, twin, loaded)]
+    for o in outs[1:]:
+        assert torch.equal(o["preds"], outs[0]["preds"]) and torch.equal(o["loss"], outs[0]["loss"])
+    for m in (twin, loaded):  # independent storage: a step of the original does not move the copies
+        before = m.model.flat_parameters().clone()
+        outs[0]["loss"].backward()
+        opt.step()
+        outs[0] = model.training_step_with_perms(image, label, None, perms)
+        assert torch.equal(before, m.model.flat_parameters())
+    bn = lambda m: int(m.model.encoder.in_convs[0].double_conv[1].num_batches_tracked)
+    assert bn(model) == 4 and bn(twin) == 2 and bn(loaded) == 2
+
+
+def test_fp16_range_guard_moves_out_of_range_batchnorm_scales_to_the_fp32_range_mode(monkeypatch):
+    """VERDICT r5 missing 5 / item 4d, the coarse remedy: a checkpoint whose BatchNorm scale drives an
+    activation past 65 520 — where the reference's fp32 convolution (components.py:23,26) stays finite — is moved to the
+    precision mode with fp32 exponent range when it is LOADED (|gamma| * 256 + |beta| >= 65504), and trains / evaluates
+    within 1e-3 of the fp32 oracle; a scale that grows past the range during training is caught by the epoch-end check,
+    which reports the poisoned step and lets the run continue in the fp32-range mode."""
+    fx = load_npz("mini_s2_step.npz")
+    cfg = cfg_from_meta(fx["meta"])
+    st = state_from(fx, "init/")
+    st["core.down2.conv.double_conv.1.weight"] = st["core.down2.conv.double_conv.1.weight"].clone()
+    st["core.down2.conv.double_conv.1.weight"][0] = 3.0e4  # activations of that channel reach ~1e5
+    model = build_model(cfg, st)  # build_model: load_state_dict, then set_precision("split16") — the guard runs again below
+    assert model.model._geom.precision == "split16"
+    model.load_state_dict({"model." + k: v for k, v in st.items()})
+    assert model.model._geom.precision == "fp32" and model.model.precision_guard[0] == "split16"
+    image, label, perms = (torch.from_numpy(fx[f"s0/{k}"]) for k in ("image", "label", "perms"))
+    model.train()
+    out = model.training_step_with_perms(image.cuda(), label.cuda(), None, perms.cuda())
+    out["loss"].backward()
+    ts = O.TrainState(cfg=cfg, st={k: v.clone() for k, v in st.items()}, loss_buffer=O.LossBuffer(cfg.num_subnetworks, 0.3, 10))
+    ref = O.train_step(ts, image, label, None, perms, apply_optimizer=False)
+    half = cfg.out_channels // 2
+    preds = out["preds"].view(image.shape[0], cfg.num_subnetworks, half, *image.shape[-2:]).cpu()
+    e_out = rel_err(preds, ref["out"][:, :, :half])
+    e_loss = abs(out["loss"].item() - float(ref["total"])) / abs(float(ref["total"]))
+    report(f"fp16 range guard: train out {e_out:.2e} loss {e_loss:.2e} in mode {model.model._geom.precision}")
+    assert torch.isfinite(out["loss"]) and e_out < TOL and e_loss < TOL and model.model.numerics_status() == 0
+    model.on_train_epoch_end()  # nothing to report
+    # a scale that leaves the range DURING training: the step that overflowed is reported once, the run continues in fp32
+    m2 = build_model(cfg, state_from(fx, "init/"))
+    m2.train()
+    with torch.no_grad():
+        dict(m2.model.named_parameters())["core.down2.conv.double_conv.1.weight"][0] = 3.0e4
+    m2.training_step_with_perms(image.cuda(), label.cuda(), None, perms.cuda())
+    with pytest.raises(FloatingPointError, match="continues in 'fp32'"):
+        m2.on_train_epoch_end()
+    assert m2.model._geom.precision == "fp32"
+    out2 = m2.training_step_with_perms(image.cuda(), label.cuda(), None, perms.cuda())
+    assert torch.isfinite(out2["loss"]) and m2.model.numerics_status() == 0
+    m2.on_train_epoch_end()
+    # switched off: the mode stays (and the overflow is only reported)
+    monkeypatch.setenv("MIMO_FP16_RANGE_GUARD", "0")
+    m3 = build_model(cfg, st)
+    m3.load_state_dict({"model." + k: v for k, v in st.items()})
+    assert m3.model._geom.precision == "split16"
+
+
+def test_numerics_status_reports_an_fp16_range_overflow_instead_of_silent_nans(monkeypatch):
     """The default split16 forward carries fp16 (hi, lo) pairs: an ACTIVATION >= 65520 (here: a BatchNorm scale of 3e5)
     turns into fp16 inf and poisons the next convolution's output where the reference's fp32 path does not.  (Weights are
     range-safe since round 5: test_weights_beyond_the_old_fixed_fp16_scale_stay_finite_and_close.)  The kernels record
     non-finite BatchNorm statistics / logits in the plan's status word; `check_numerics` (called by the Lightning epoch-end
     hooks) turns it into an error that says so, the fp32 mode runs the same parameters cleanly, and the word is cleared
     by the read."""
+    monkeypatch.setenv("MIMO_FP16_RANGE_GUARD", "0")  # this test is about the REPORT; the guard has its own test above
     fx = load_npz("mini_s2_step.npz")
     cfg = cfg_from_meta(fx["meta"])
     model = build_model(cfg, state_from(fx, "init/"))
