@@ -22,6 +22,10 @@ global, 4 per GPU at 8) — `value` at N > 1 is that regime; "weak" = the per-GP
 (32: the reference README's SEN12TP batch size with Lightning-DDP semantics, batch_size = per device).  At N > 1 the
 line carries both (`config.strong_images_per_s`, `config.weak_images_per_s`), each from its own timed pass.
 
+`value_strict` / `ms_per_step_strict`: the same timed pass of a second model under MIMO_WGRAD_NP=3 (three bf16-pair MFMAs per
+product in the weight gradient instead of the default's two fp16 MFMAs with the activation as one fp16 value): the fp32-class
+figure next to the headline (`--no-strict` skips it).
+
 The timed region runs WITHOUT instrumentation.  A second, shorter pass with HIP events recorded on the launch
 stream around every kernel class and every resolution tier gives the roofline numbers; at N=1 the CPU oracle
 is timed on this box's host cores for the same workload shape.  ONE JSON line on rank 0.
