@@ -61,7 +61,7 @@ class FlatGradientAllReducer:
     encoders — which walks the flat buffer (encoder | core | decoder | heads) from its tail to its head, so
     consecutive announcements are adjacent in memory.  Ranges are merged until `min_bucket_bytes` are pending
     (the 0.4 MB decoder and 1.3 MB up3 slices ride along with up2; xGMI collectives are latency-bound below a
-    few MB) and split above `bucket_bytes`; cfg3 (60 MB of gradients) goes out as six all-reduces of 3-21 MB,
+    few MB) and split above `bucket_bytes`; cfg3 (60 MB of gradients) goes out as five collectives of 3.6-20.7 MB,
     the first of them after about a third of the backward."""
 
     ALGORITHMS = ("all_reduce", "reduce_scatter")

@@ -177,7 +177,7 @@ def test_bench_spawns_its_own_ranks_gloo_sharing_the_gpu():
 def test_bench_eight_ranks_gloo_sharing_the_gpu():
     """The 8-GPU regime of BASELINE config 3 as a FUNCTIONAL run (world 2 was the only size ever
     exercised): `python bench.py --gpus 8 --batch 32` starts eight ranks, here over gloo on GPU 0 — global batch 32 sharded
-    4 per rank (ddp.shard_batch), the backward of every rank issues the same six bucketed collectives, and all eight ranks
+    4 per rank (ddp.shard_batch), the backward of every rank issues the same five bucketed collectives, and all eight ranks
     end with bit-identical parameters.  Not a performance configuration."""
     line = _run_bench({"MIMO_BENCH_BACKEND": "gloo", "OMP_NUM_THREADS": "2"}, "--gpus", "8", "--steps", "2", "--warmup", "1",
                       "--batch", "32", "--scaling", "strong", "--profile-steps", "0", "--no-cpu-baseline", "--no-strict",
@@ -185,7 +185,7 @@ def test_bench_eight_ranks_gloo_sharing_the_gpu():
     cfg = line["config"]
     assert line["n_gpus"] == 8 and cfg["world_size"] == 8 and cfg["backend"] == "gloo" and cfg["rccl_ranks"] is None
     assert cfg["global_batch"] == 32 and cfg["per_gpu_batch"] == 4
-    # cfg3: 15.06 M parameters = 60.3 MB of gradients, out as six buckets (heads + decoders + up3 + up2 merged, then one per core block)
+    # cfg3: 15.06 M parameters = 60.3 MB of gradients, out as five buckets (N_COLLECTIVES_CFG3 above)
     assert cfg["collectives_per_step"] == N_COLLECTIVES_CFG3, (cfg["collectives_per_step"], cfg["collective_mbytes"])
     assert abs(sum(cfg["collective_mbytes"]) - 60.3) < 0.5, cfg["collective_mbytes"]
     assert cfg["params_bit_identical_across_ranks"] is True
