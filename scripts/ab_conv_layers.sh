@@ -11,7 +11,7 @@ export MIMO_WGRAD_STREAM=0
 for V in "$A" "$B"; do
   export $VAR=$V
   L=$(basename "$V" .so)  # label of the setting in the file names (values may be paths: MIMO_HIP_LIB)
-  rocprofv3 --kernel-trace -d "$OUT/trace_$L" -o t --output-format csv -- python3 "$R/bench.py" --steps 3 --warmup 2 --profile-steps 0 --no-cpu-baseline > "$OUT/bench_$L.json" 2> "$OUT/trace_$L.err"
+  rocprofv3 --kernel-trace -d "$OUT/trace_$L" -o t --output-format csv -- python3 "$R/bench.py" --steps 3 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-strict > "$OUT/bench_$L.json" 2> "$OUT/trace_$L.err"
   python3 "$R/scripts/trace_convs.py" "$OUT/trace_$L" > "$OUT/conv_layers_$L.txt" 2>&1
   rm -rf "$OUT/trace_$L"
 done
